@@ -1,0 +1,1045 @@
+/*
+ * opal_oracle.c -- TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT PATH.
+ *
+ * A plain-C, double-precision, CPU restatement of the per-timestep PIC loop of
+ * tgblackburn/opal (Rust), following the reference source line by line,
+ * including its quirks.  It is the parity checker for the HIP kernels in
+ * opal_amd/csrc and the "port" CPU baseline timed by bench.py.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Parity status: the reference is Rust and no Rust toolchain exists in the
+ * build image, so the reference itself cannot be run.  This restatement is
+ * pinned by the reference's own analytic known-answer tests
+ *   - yee.rs:903-1079   laser_bc / conducting_bc / periodic_bc
+ *   - electron.rs:401-436 static_magnetic_field / static_electric_field
+ *   - photon_emission.rs:299-336 rate_* (five values)
+ * (see tests/test_oracle_kat.py).  Nothing in the reference pins weight/flux/
+ * deposit/fields_at values, Ion::push, migration or the loader: for those this
+ * file is "source-following, parity unpinned by reference tests".
+ * The initial particle state is NOT bit-compatible with the reference: rand /
+ * rand_xoshiro / rand_distr (Cargo.lock:540-586) are not vendored; the RNG here
+ * is xoshiro256** + SplitMix64 seeding + 53-bit floats, with Box-Muller normals
+ * and inverse-CDF exponentials (statistically equivalent only).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (Rust never fuses a*b+c, so
+ * contraction must stay off for the arithmetic to follow the reference).
+ *
+ * All "file:line" citations are relative to the reference repository root.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- src/constants.rs:4-27 (values are physical facts, truncated as there) */
+#define SPEED_OF_LIGHT 2.997925e8
+#define SPEED_OF_LIGHT_SQD 89875517873681764.0
+#define VACUUM_PERMITTIVITY 8.854188e-12
+#define VACUUM_PERMEABILITY 1.256637e-6
+#define ELECTRON_CHARGE (-1.602177e-19)
+#define ELEMENTARY_CHARGE (1.602177e-19)
+#define ELECTRON_MASS 9.109383e-31
+#define PROTON_MASS 1.672622e-27
+#define ELECTRON_MASS_MEV 0.510999
+#define CRITICAL_FIELD 1.323285e18
+#define ALPHA_FINE 7.29735257e-3
+#define COMPTON_TIME 1.28808867e-21
+
+#define PI 3.14159265358979323846264338327950288
+#define FRAC_PI_3 1.04719755119659774615421446109316763
+
+/* grid/mod.rs:22-28 */
+enum { BDY_INTERNAL = 0, BDY_LASER = 1, BDY_ABSORBING = 2, BDY_CONDUCTING = 3 };
+/* yee.rs:239-242 */
+#define GHOST_SIZE 4
+#define LASER_BDY_SIZE 4
+#define ABSORBING_BDY_SIZE 200
+#define CONDUCTING_BDY_SIZE 4
+
+enum { SPECIES_ELECTRON = 0, SPECIES_ION = 1 };
+
+/* yee.rs:84-92 */
+typedef struct {
+    double x, rho, j[3], E[3], B[3];
+} Cell;
+
+/* yee.rs:255-269 */
+typedef struct {
+    int id, ngrids, rank_to_left, rank_to_right;
+    int left_bdy, right_bdy;
+    long left_bdy_size, right_bdy_size;
+    size_t size;
+    double dx;
+    Cell *cell;
+    size_t len;
+} YeeGrid;
+
+/* electron.rs:14-27 */
+typedef struct {
+    long cell;
+    double prev_x, x, y, z, weight, gamma, u[3], chi, tau, work;
+    int flag;
+} Electron;
+
+/* ion.rs:14-26 */
+typedef struct {
+    long cell;
+    double prev_x, x, weight, Z_star, Z, A, gamma_m1, u[3], work;
+    int flag;
+} Ion;
+
+/* particle/mod.rs:141-145 */
+typedef struct {
+    int species;
+    size_t n, cap;
+    void *store;        /* Electron* or Ion* */
+    size_t gone_left, gone_right; /* state between push+sort and splice */
+} Population;
+
+typedef double (*fn1_t)(double, void *);
+typedef double (*fn2_t)(double, double, void *);
+typedef double (*fn3_t)(double, double, double, void *);
+
+/* ------------------------------------------------------------------ Vec3 */
+typedef struct { double x, y, z; } Vec3;
+static inline Vec3 v3(double x, double y, double z) { Vec3 r = {x, y, z}; return r; }
+static inline Vec3 vadd(Vec3 a, Vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); } /* vec3.rs:39-44 */
+static inline double vdot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  /* vec3.rs:55-60 */
+static inline Vec3 smul(double s, Vec3 a) { return v3(s * a.x, s * a.y, s * a.z); }       /* vec3.rs:71-76 */
+static inline Vec3 vdivs(Vec3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }      /* vec3.rs:87-92 */
+static inline Vec3 vcross(Vec3 a, Vec3 b) {                                               /* vec3.rs:103-109 */
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+/* ---------------------------------------------------- Cell::weight / flux */
+/* yee.rs:140-149 */
+double oracle_weight(double xi)
+{
+    double xhat = fabs(xi);
+    if (xhat > 1.5) return 0.0;
+    else if (xhat < 0.5) return 0.75 - xhat * xhat;
+    else return 1.125 - 1.5 * xhat + 0.5 * (xhat * xhat);
+}
+
+/* yee.rs:185-204 */
+double oracle_flux(double x_i, double x_f)
+{
+    if (fabs(x_i) < 1.0) {
+        if (fabs(x_f) >= 1.0) {
+            double a = 1.0 - fabs(x_i);
+            double v = 0.5 * (a * a);
+            return copysign(v, -x_i);
+        } else if (x_i * x_f >= 0.0) {
+            double a = 1.0 - fabs(x_f), b = 1.0 - fabs(x_i);
+            double v = 0.5 * (a * a) - 0.5 * (b * b);
+            return copysign(v, x_i - x_f);
+        } else {
+            double v = fabs(x_i) * (1.0 - 0.5 * fabs(x_i)) + fabs(x_f) * (1.0 - 0.5 * fabs(x_f));
+            return copysign(v, x_i);
+        }
+    } else if (fabs(x_f) < 1.0) {
+        double a = 1.0 - fabs(x_f);
+        double v = 0.5 * (a * a);
+        return copysign(v, x_f);
+    } else {
+        return 0.0;
+    }
+}
+
+/* ------------------------------------------------------------ GridDesign */
+/* grid/mod.rs:126-151.  Returns 0 on success. */
+int oracle_design_unbalanced(int numtasks, size_t size, double dx, size_t min_subsize,
+                             size_t *nx, double *offset)
+{
+    size_t subsize = size / (size_t)numtasks;
+    if (subsize < min_subsize) subsize = min_subsize;
+    size_t rt = 0;
+    for (int p = 0; p < numtasks; p++) {
+        nx[p] = subsize;
+        offset[p] = ((double)rt) * dx;
+        rt += subsize;
+    }
+    return 0;
+}
+
+/* grid/mod.rs:157-206.  Returns 0 on success, 1 where the reference would
+ * panic on `.unwrap()` (:179). */
+int oracle_design_balanced(int numtasks, size_t size, double xmin, double dx, size_t min_subsize,
+                           fn1_t ne, void *user, size_t *nx, double *offset)
+{
+    if (numtasks == 0) return oracle_design_unbalanced(numtasks, size, dx, min_subsize, nx, offset);
+    size_t m = size - min_subsize;
+    double *cumsum = (double *)malloc(sizeof(double) * (m ? m : 1));
+    double total = 0.0;
+    for (size_t n = 0; n < m; n++) {
+        double x = xmin + ((double)n) * dx;
+        total += dx * ne(x, user);
+        cumsum[n] = total;
+    }
+    double target = cumsum[m - 1] / ((double)numtasks);
+    size_t start = 0, ndone = 0;
+    for (int p = 1; p < numtasks; p++) {
+        size_t first = start + min_subsize, i;
+        int found = 0;
+        for (i = first; i < m; i++) {
+            if (cumsum[i] >= target * ((double)p)) { found = 1; break; }
+        }
+        if (!found) { free(cumsum); return 1; }
+        size_t pos = i - first;
+        nx[p - 1] = pos + min_subsize;
+        ndone += pos + min_subsize;
+        start += pos + min_subsize;
+    }
+    nx[numtasks - 1] = size - ndone;
+    size_t rt = 0;
+    for (int p = 0; p < numtasks; p++) {
+        offset[p] = ((double)rt) * dx;
+        rt += nx[p];
+    }
+    free(cumsum);
+    return 0;
+}
+
+/* --------------------------------------------------------------- YeeGrid */
+/* yee.rs:272-319 */
+YeeGrid *oracle_grid_build(int id, int numtasks, int left, int right, double xmin, double dx,
+                           const size_t *nx, const double *offset)
+{
+    YeeGrid *g = (YeeGrid *)calloc(1, sizeof(YeeGrid));
+    size_t ncells = nx[id];
+    double off = offset[id];
+    if (id == 0 && left == BDY_LASER) { g->left_bdy = BDY_LASER; g->left_bdy_size = LASER_BDY_SIZE; }
+    else { g->left_bdy = BDY_INTERNAL; g->left_bdy_size = GHOST_SIZE; }
+    if (id == numtasks - 1) {
+        if (right == BDY_ABSORBING) { g->right_bdy = BDY_ABSORBING; g->right_bdy_size = ABSORBING_BDY_SIZE; }
+        else if (right == BDY_CONDUCTING) { g->right_bdy = BDY_CONDUCTING; g->right_bdy_size = CONDUCTING_BDY_SIZE; }
+        else { g->right_bdy = BDY_INTERNAL; g->right_bdy_size = GHOST_SIZE; }
+    } else { g->right_bdy = BDY_INTERNAL; g->right_bdy_size = GHOST_SIZE; }
+    g->id = id;
+    g->ngrids = numtasks;
+    g->rank_to_left = (id - 1 + numtasks) % numtasks;
+    g->rank_to_right = (id + 1) % numtasks;
+    g->size = ncells;
+    g->dx = dx;
+    g->len = ncells + (size_t)g->left_bdy_size + (size_t)g->right_bdy_size;
+    g->cell = (Cell *)calloc(g->len, sizeof(Cell));
+    for (size_t c = 0; c < g->len; c++)
+        g->cell[c].x = xmin + off + (((double)c) - ((double)g->left_bdy_size)) * dx;
+    return g;
+}
+
+void oracle_grid_free(YeeGrid *g) { if (g) { free(g->cell); free(g); } }
+size_t oracle_grid_size(const YeeGrid *g) { return g->size; }
+size_t oracle_grid_len(const YeeGrid *g) { return g->len; }
+long oracle_grid_left_bdy_size(const YeeGrid *g) { return g->left_bdy_size; }
+long oracle_grid_right_bdy_size(const YeeGrid *g) { return g->right_bdy_size; }
+double oracle_grid_dx(const YeeGrid *g) { return g->dx; }
+double oracle_grid_xmin(const YeeGrid *g) { return g->cell[g->left_bdy_size].x; } /* yee.rs:531-533 */
+int oracle_grid_rank(const YeeGrid *g) { return g->id; }
+/* yee.rs:329-343: returns rank or -1 for None */
+int oracle_grid_to_left(const YeeGrid *g) { return g->left_bdy == BDY_INTERNAL ? g->rank_to_left : -1; }
+int oracle_grid_to_right(const YeeGrid *g) { return g->right_bdy == BDY_INTERNAL ? g->rank_to_right : -1; }
+Cell *oracle_grid_cells(YeeGrid *g) { return g->cell; }
+
+/* raw (ghost-inclusive) SoA views for the tests; comp: 0 x,1 rho,2-4 j,5-7 E,8-10 B */
+void oracle_grid_get_raw(const YeeGrid *g, int comp, double *out)
+{
+    for (size_t i = 0; i < g->len; i++) out[i] = ((const double *)&g->cell[i])[comp];
+}
+void oracle_grid_set_raw(YeeGrid *g, int comp, const double *in)
+{
+    for (size_t i = 0; i < g->len; i++) ((double *)&g->cell[i])[comp] = in[i];
+}
+
+/* yee.rs:543-549 */
+void oracle_grid_clear(YeeGrid *g)
+{
+    for (size_t i = 0; i < g->len; i++) {
+        g->cell[i].rho = 0.0;
+        g->cell[i].j[0] = g->cell[i].j[1] = g->cell[i].j[2] = 0.0;
+    }
+}
+
+/* yee.rs:499-529.  Returns 0, or 1 where the reference asserts (:501-502). */
+int oracle_grid_fields_at(const YeeGrid *g, long c, double xi, double *E, double *B)
+{
+    long jj = c + g->left_bdy_size;
+    if (!(jj >= g->left_bdy_size)) return 1;
+    if (!((size_t)jj < g->len - (size_t)g->right_bdy_size)) return 1;
+    size_t j = (size_t)jj;
+    const Cell *cl = g->cell;
+    E[0] = cl[j - 1].E[0] * oracle_weight(0.5 + xi)
+         + cl[j].E[0] * oracle_weight(0.5 - xi)
+         + cl[j + 1].E[0] * oracle_weight(1.5 - xi);
+    E[1] = cl[j - 1].E[1] * oracle_weight(1.0 + xi)
+         + cl[j].E[1] * oracle_weight(xi)
+         + cl[j + 1].E[1] * oracle_weight(1.0 - xi)
+         + cl[j + 2].E[1] * oracle_weight(2.0 - xi);
+    E[2] = cl[j - 1].E[2] * oracle_weight(1.0 + xi)
+         + cl[j].E[2] * oracle_weight(xi)
+         + cl[j + 1].E[2] * oracle_weight(1.0 - xi)
+         + cl[j + 2].E[2] * oracle_weight(2.0 - xi);
+    B[0] = cl[j].B[0];
+    B[1] = cl[j - 1].B[1] * oracle_weight(0.5 + xi)
+         + cl[j].B[1] * oracle_weight(0.5 - xi)
+         + cl[j + 1].B[1] * oracle_weight(1.5 - xi);
+    B[2] = cl[j - 1].B[2] * oracle_weight(0.5 + xi)
+         + cl[j].B[2] * oracle_weight(0.5 - xi)
+         + cl[j + 1].B[2] * oracle_weight(1.5 - xi);
+    return 0;
+}
+
+/* yee.rs:97-113 */
+static void overlay_ghost(Cell *self, const Cell *other)
+{
+    self->rho += other->rho;
+    self->j[0] += other->j[0];
+    self->j[1] += other->j[1];
+    self->j[2] += other->j[2];
+    memcpy(self->E, other->E, sizeof self->E);
+    memcpy(self->B, other->B, sizeof self->B);
+}
+static void overlay(Cell *self, const Cell *other)
+{
+    self->rho += other->rho;
+    self->j[0] += other->j[0];
+    self->j[1] += other->j[1];
+    self->j[2] += other->j[2];
+}
+
+/* yee.rs:353-354: what this subdomain sends to its neighbours (pre-sync state) */
+void oracle_grid_send_left(const YeeGrid *g, Cell *out) { memcpy(out, g->cell, 2 * GHOST_SIZE * sizeof(Cell)); }
+void oracle_grid_send_right(const YeeGrid *g, Cell *out)
+{
+    memcpy(out, g->cell + (g->len - 2 * GHOST_SIZE), 2 * GHOST_SIZE * sizeof(Cell));
+}
+
+/* yee.rs:411-495: ghost overlay + boundary conditions, given what was received.
+ * recv_left / recv_right may be NULL where the boundary is not Internal. */
+void oracle_grid_synchronize_apply(YeeGrid *g, const Cell *recv_left, const Cell *recv_right,
+                                   fn2_t laser_y, fn2_t laser_z, void *user, double t, double dt)
+{
+    size_t len = g->len;
+    if (g->left_bdy == BDY_INTERNAL) {
+        for (int i = 0; i < GHOST_SIZE; i++) overlay_ghost(&g->cell[i], &recv_left[i]);
+        for (int i = 0; i < GHOST_SIZE; i++) overlay(&g->cell[GHOST_SIZE + i], &recv_left[GHOST_SIZE + i]);
+    }
+    if (g->right_bdy == BDY_INTERNAL) {
+        for (int i = 0; i < GHOST_SIZE; i++) overlay(&g->cell[len - 2 * GHOST_SIZE + i], &recv_right[i]);
+        for (int i = 0; i < GHOST_SIZE; i++) overlay_ghost(&g->cell[len - GHOST_SIZE + i], &recv_right[GHOST_SIZE + i]);
+    }
+    if (g->left_bdy == BDY_LASER) { /* yee.rs:456-462 */
+        size_t start = (size_t)(g->left_bdy_size - 2);
+        double x = g->cell[start].x;
+        double r = SPEED_OF_LIGHT * dt / g->dx;
+        g->cell[start].E[1] += 2.0 * r * laser_y(t, x, user);
+        g->cell[start].E[2] += 2.0 * r * laser_z(t, x, user);
+    }
+    if (g->right_bdy == BDY_ABSORBING) { /* yee.rs:464-479 */
+        double xmin = g->cell[g->size + (size_t)g->left_bdy_size].x;
+        double xmax = g->cell[g->size + (size_t)g->left_bdy_size + (size_t)g->right_bdy_size - 1].x;
+        double sigma_max = 10.0 / ((double)g->right_bdy_size);
+        for (size_t i = len - (size_t)g->right_bdy_size + 1; i < len; i++) {
+            Cell *c = &g->cell[i];
+            double sigma = sigma_max * (c->x - xmin) / (xmax - xmin);
+            c->E[0] = (1.0 - sigma) * c->E[0];
+            c->E[1] = (1.0 - sigma) * c->E[1];
+            c->E[2] = (1.0 - sigma) * c->E[2];
+            c->B[0] = (1.0 - sigma) * c->B[0];
+            c->B[1] = (1.0 - sigma) * c->B[1];
+            c->B[2] = (1.0 - sigma) * c->B[2];
+        }
+        for (size_t i = len - 2; i < len; i++) {
+            memset(g->cell[i].E, 0, sizeof g->cell[i].E);
+            memset(g->cell[i].B, 0, sizeof g->cell[i].B);
+        }
+    } else if (g->right_bdy == BDY_CONDUCTING) { /* yee.rs:480-495 */
+        size_t start = len - (size_t)g->right_bdy_size;
+        g->cell[start].E[0] = 0.0;
+        g->cell[start].B[1] = 0.0;
+        g->cell[start].B[2] = 0.0;
+        for (size_t i = 1; i < (size_t)g->right_bdy_size; i++) {
+            g->cell[start + i].E[0] = -g->cell[start - i].E[0];
+            g->cell[start + i].E[1] = g->cell[start + 1 - i].E[1];
+            g->cell[start + i].E[2] = g->cell[start + 1 - i].E[2];
+            g->cell[start + i].B[0] = g->cell[start + 1 - i].B[0];
+            g->cell[start + i].B[1] = -g->cell[start - i].B[1];
+            g->cell[start + i].B[2] = -g->cell[start - i].B[2];
+        }
+    }
+}
+
+/* yee.rs:351-452 for a set of subdomains living in one process: every send
+ * buffer is taken from the pre-sync state (as the blocking MPI sends do), then
+ * every subdomain applies what it received.  With n == 1 this is the self-copy
+ * of yee.rs:365-370 / 390-395. */
+void oracle_world_synchronize(YeeGrid **grids, int n, fn2_t laser_y, fn2_t laser_z, void *user,
+                              double t, double dt)
+{
+    Cell *sl = (Cell *)malloc(sizeof(Cell) * 2 * GHOST_SIZE * (size_t)n);
+    Cell *sr = (Cell *)malloc(sizeof(Cell) * 2 * GHOST_SIZE * (size_t)n);
+    for (int r = 0; r < n; r++) {
+        oracle_grid_send_left(grids[r], sl + 2 * GHOST_SIZE * r);
+        oracle_grid_send_right(grids[r], sr + 2 * GHOST_SIZE * r);
+    }
+    for (int r = 0; r < n; r++) {
+        YeeGrid *g = grids[r];
+        /* recv_left is what the left neighbour sent right; recv_right what the right one sent left */
+        const Cell *rl = g->left_bdy == BDY_INTERNAL ? sr + 2 * GHOST_SIZE * g->rank_to_left : NULL;
+        const Cell *rr = g->right_bdy == BDY_INTERNAL ? sl + 2 * GHOST_SIZE * g->rank_to_right : NULL;
+        oracle_grid_synchronize_apply(g, rl, rr, laser_y, laser_z, user, t, dt);
+    }
+    free(sl);
+    free(sr);
+}
+
+/* yee.rs:839-848 */
+static void advance_B(YeeGrid *g, double dt)
+{
+    size_t end = g->len - 1;
+    Cell *c = g->cell;
+    for (size_t i = 0; i < end; i++) {
+        c[i].B[1] += dt * (c[i + 1].E[2] - c[i].E[2]) / g->dx;
+        c[i].B[2] += dt * (c[i].E[1] - c[i + 1].E[1]) / g->dx;
+    }
+}
+
+/* yee.rs:852-867 */
+static void advance_E(YeeGrid *g, double dt)
+{
+    Cell *c = g->cell;
+    double kappa = 2.0 * SPEED_OF_LIGHT * dt / (SPEED_OF_LIGHT * dt + g->dx);
+    double sigma = 1.0 - kappa;
+    c[0].E[0] = 0.0;
+    c[0].E[1] = sigma * c[0].E[1] - SPEED_OF_LIGHT * kappa * c[0].B[2];
+    c[0].E[2] = sigma * c[0].E[2] + SPEED_OF_LIGHT * kappa * c[0].B[1];
+    for (size_t i = 1; i < g->len; i++) {
+        c[i].E[0] += -dt * c[i].j[0] / VACUUM_PERMITTIVITY;
+        c[i].E[1] += dt * SPEED_OF_LIGHT_SQD * (c[i - 1].B[2] - c[i].B[2]) / g->dx - dt * c[i].j[1] / VACUUM_PERMITTIVITY;
+        c[i].E[2] += dt * SPEED_OF_LIGHT_SQD * (c[i].B[1] - c[i - 1].B[1]) / g->dx - dt * c[i].j[2] / VACUUM_PERMITTIVITY;
+    }
+}
+
+/* yee.rs:345-349 */
+void oracle_grid_advance(YeeGrid *g, double dt)
+{
+    advance_B(g, 0.5 * dt);
+    advance_E(g, dt);
+    advance_B(g, 0.5 * dt);
+}
+
+/* yee.rs:787-809 (local part; the MPI reduce is a plain sum over subdomains) */
+double oracle_grid_em_field_energy(const YeeGrid *g)
+{
+    double e2 = 0.0, b2 = 0.0;
+    for (size_t i = (size_t)g->left_bdy_size; i < g->len - (size_t)g->right_bdy_size; i++) {
+        const Cell *c = &g->cell[i];
+        e2 = e2 + c->E[0] * c->E[0] + c->E[1] * c->E[1] + c->E[2] * c->E[2];
+        b2 = b2 + c->B[0] * c->B[0] + c->B[1] * c->B[1] + c->B[2] * c->B[2];
+    }
+    return 0.5 * (VACUUM_PERMITTIVITY * e2 + b2 / VACUUM_PERMEABILITY) * g->dx;
+}
+
+/* yee.rs:815-835: out has g->size cells */
+void oracle_grid_interpolate(const YeeGrid *g, Cell *out)
+{
+    size_t lo = (size_t)g->left_bdy_size - 1;
+    for (size_t k = 0; k < g->size; k++) {
+        const Cell *a = &g->cell[lo + k], *b = &g->cell[lo + k + 1];
+        out[k].x = b->x;
+        out[k].rho = b->rho;
+        out[k].j[0] = 0.5 * (a->j[0] + b->j[0]); out[k].j[1] = b->j[1]; out[k].j[2] = b->j[2];
+        out[k].E[0] = 0.5 * (a->E[0] + b->E[0]); out[k].E[1] = b->E[1]; out[k].E[2] = b->E[2];
+        out[k].B[0] = b->B[0]; out[k].B[1] = 0.5 * (a->B[1] + b->B[1]); out[k].B[2] = 0.5 * (a->B[2] + b->B[2]);
+    }
+}
+
+/* --------------------------------------------- QED rate (electron push) */
+/* photon_emission.rs:9-57: second column (ln h) of LN_H_CHI_TABLE; the first
+ * column is only used through its first entry. */
+#define DELTA_LN_CHI 0.230258509299
+#define LN_H_CHI_0 (-4.60517019e+0)
+static const double LN_H[41] = {
+    1.64660829e+0, 1.64437994e+0, 1.64162210e+0, 1.63822181e+0, 1.63404803e+0, 1.62895132e+0,
+    1.62276454e+0, 1.61530492e+0, 1.60637755e+0, 1.59578044e+0, 1.58331053e+0, 1.56877061e+0,
+    1.55197597e+0, 1.53276058e+0, 1.51098175e+0, 1.48652339e+0, 1.45929745e+0, 1.42924408e+0,
+    1.39633080e+0, 1.36055104e+0, 1.32192247e+0, 1.28048533e+0, 1.23630061e+0, 1.18944834e+0,
+    1.14002554e+0, 1.08814410e+0, 1.03392829e+0, 9.77512163e-1, 9.19036694e-1, 8.58647059e-1,
+    7.96489918e-1, 7.32710951e-1, 6.67452686e-1, 6.00852676e-1, 5.33042051e-1, 4.64144437e-1,
+    3.94275229e-1, 3.23541171e-1, 2.52040210e-1, 1.79861566e-1, 1.07085976e-1};
+
+/* photon_emission.rs:59-79 */
+double oracle_rate(double chi, double gamma)
+{
+    double h;
+    if (chi < 0.01) {
+        h = 5.0 * FRAC_PI_3 * (1.0 - 8.0 * chi / (5.0 * sqrt(3.0)));
+    } else if (chi >= 100.0) {
+        double cbrt_chi = cbrt(chi);
+        h = -1019.4661473121777 + 1786.716527650374 * cbrt_chi * cbrt_chi;
+        h = 1750.6263395722715 + cbrt_chi * cbrt_chi * h;
+        h = -2260.1819695887225 + cbrt_chi * h;
+        h = 0.00296527643253334 * h / (chi * chi);
+    } else {
+        double index = (log(chi) - LN_H_CHI_0) / DELTA_LN_CHI;
+        double weight = index - trunc(index); /* f64::fract */
+        size_t idx = (index != index) ? 0 : (size_t)floor(index); /* NaN as usize == 0 */
+        if (idx >= 40) idx = 39; /* reference asserts index < 40 (:73) */
+        double ln_h = (1.0 - weight) * LN_H[idx] + weight * LN_H[idx + 1];
+        h = exp(ln_h);
+    }
+    return sqrt(3.0) * ALPHA_FINE * chi * h / (2.0 * PI * gamma * COMPTON_TIME);
+}
+
+/* --------------------------------------------------------------- Electron */
+/* electron.rs:85-103 */
+static Electron electron_create(long cell, double x, const double *u, double weight, double dx, double dt)
+{
+    Electron e;
+    Vec3 uu = v3(u[0], u[1], u[2]);
+    double gamma = sqrt(1.0 + vdot(uu, uu));
+    e.cell = cell;
+    e.prev_x = x - SPEED_OF_LIGHT * uu.x * dt / (gamma * dx);
+    e.x = x; e.y = 0.0; e.z = 0.0;
+    e.weight = weight; e.gamma = gamma;
+    e.u[0] = u[0]; e.u[1] = u[1]; e.u[2] = u[2];
+    e.chi = 0.0; e.tau = INFINITY; e.work = 0.0; e.flag = 0;
+    return e;
+}
+
+/* electron.rs:268-330.  Returns 1 where the reference asserts dxi < 1 (:313). */
+static int electron_vay_push(Electron *p, const double *Ea, const double *Ba, double dx, double dt)
+{
+    Vec3 E = v3(Ea[0], Ea[1], Ea[2]), B = v3(Ba[0], Ba[1], Ba[2]);
+    Vec3 u = v3(p->u[0], p->u[1], p->u[2]);
+    Vec3 v = vdivs(smul(SPEED_OF_LIGHT, u), p->gamma);
+    double alpha = ELECTRON_CHARGE * dt / (2.0 * ELECTRON_MASS * SPEED_OF_LIGHT);
+    Vec3 u_half = vadd(u, smul(alpha, vadd(E, vcross(v, B))));
+    p->work += ELECTRON_CHARGE * SPEED_OF_LIGHT * vdot(u_half, E) * dt / sqrt(1.0 + vdot(u_half, u_half));
+    double gamma_half = sqrt(1.0 + vdot(u_half, u_half));
+    {
+        Vec3 w = vadd(smul(gamma_half, E), smul(SPEED_OF_LIGHT, vcross(u_half, B)));
+        double eu = vdot(E, u_half);
+        p->chi = sqrt(vdot(w, w) - eu * eu) / CRITICAL_FIELD;
+    }
+    p->tau = p->tau - oracle_rate(p->chi, gamma_half) * dt;
+    Vec3 u_prime = vadd(u_half, smul(alpha, E));
+    double gamma_prime_sqd = 1.0 + vdot(u_prime, u_prime);
+    Vec3 tau = smul(alpha * SPEED_OF_LIGHT, B);
+    double u_star = vdot(u_prime, tau);
+    double sigma = gamma_prime_sqd - vdot(tau, tau);
+    p->gamma = sqrt(0.5 * sigma + sqrt(0.25 * (sigma * sigma) + vdot(tau, tau) + u_star * u_star));
+    Vec3 t = vdivs(tau, p->gamma);
+    double s = 1.0 / (1.0 + vdot(t, t));
+    Vec3 un = smul(s, vadd(vadd(u_prime, smul(vdot(u_prime, t), t)), vcross(u_prime, t)));
+    p->u[0] = un.x; p->u[1] = un.y; p->u[2] = un.z;
+    p->prev_x = p->x;
+    double dxi = SPEED_OF_LIGHT * un.x * dt / (dx * p->gamma);
+    int bad = !(dxi < 1.0);
+    p->x = p->x + dxi;
+    p->y = p->y + v.y * dt;
+    p->z = p->z + v.z * dt;
+    double fl = floor(p->x);
+    if (fl < 0.0) p->cell = p->cell - 1;
+    else if (fl > 0.0) p->cell = p->cell + 1;
+    p->prev_x -= fl;
+    p->x -= fl;
+    return bad;
+}
+
+/* electron.rs:122-126 */
+static double electron_ke(const Electron *p)
+{
+    double to_joules = 1.0e6 * ELECTRON_MASS_MEV * ELEMENTARY_CHARGE;
+    double u2 = p->u[0] * p->u[0] + p->u[1] * p->u[1] + p->u[2] * p->u[2];
+    return p->weight * u2 * to_joules / (p->gamma + 1.0);
+}
+
+/* -------------------------------------------------------------------- Ion */
+/* ion.rs:81-101 */
+static Ion ion_create(long cell, double x, const double *u, double weight, double dx, double dt)
+{
+    Ion p;
+    Vec3 uu = v3(u[0], u[1], u[2]);
+    double n2 = vdot(uu, uu);
+    double gamma_m1 = n2 / (1.0 + sqrt(1.0 + n2));
+    Vec3 v = vdivs(smul(SPEED_OF_LIGHT, uu), 1.0 + gamma_m1);
+    p.cell = cell;
+    p.prev_x = x - v.x * dt / dx;
+    p.x = x; p.weight = weight;
+    p.Z_star = 1.0; p.Z = 1.0; p.A = 1.0;
+    p.gamma_m1 = gamma_m1;
+    p.u[0] = u[0]; p.u[1] = u[1]; p.u[2] = u[2];
+    p.work = 0.0; p.flag = 0;
+    return p;
+}
+
+/* ion.rs:168-214 */
+static int ion_push(Ion *p, const double *Ea, const double *Ba, double dx, double dt)
+{
+    Vec3 E = v3(Ea[0], Ea[1], Ea[2]);
+    Vec3 cB = smul(SPEED_OF_LIGHT, v3(Ba[0], Ba[1], Ba[2]));
+    Vec3 u = v3(p->u[0], p->u[1], p->u[2]);
+    double q = p->Z_star * ELEMENTARY_CHARGE;
+    double M = p->A * PROTON_MASS;
+    double alpha = q * dt / (2.0 * M * SPEED_OF_LIGHT);
+    Vec3 u_minus = vadd(u, smul(alpha, E));
+    double gamma = 1.0 + vdot(u_minus, u_minus) / (1.0 + sqrt(1.0 + vdot(u_minus, u_minus)));
+    double t = alpha / gamma;
+    Vec3 u_prime = vadd(u_minus, smul(t, vcross(u_minus, cB)));
+    double t_prime = 2.0 * t / (1.0 + (t * t) * vdot(cB, cB));
+    Vec3 u_plus = vadd(u_minus, smul(t_prime, vcross(u_prime, cB)));
+    Vec3 un = vadd(u_plus, smul(alpha, E));
+    p->u[0] = un.x; p->u[1] = un.y; p->u[2] = un.z;
+    p->gamma_m1 = vdot(un, un) / (1.0 + sqrt(1.0 + vdot(un, un)));
+    p->prev_x = p->x;
+    double dxi = SPEED_OF_LIGHT * un.x * dt / (dx * (1.0 + p->gamma_m1));
+    int bad = !(dxi < 1.0);
+    p->x = p->x + dxi;
+    double fl = floor(p->x);
+    if (fl < 0.0) p->cell = p->cell - 1;
+    else if (fl > 0.0) p->cell = p->cell + 1;
+    p->prev_x -= fl;
+    p->x -= fl;
+    return bad;
+}
+
+/* ion.rs:128-134 */
+static double ion_ke(const Ion *p)
+{
+    double energy = p->gamma_m1 * (p->A * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV;
+    return p->weight * energy * 1.0e6 * ELEMENTARY_CHARGE;
+}
+
+/* single-particle entry points for the tests (electron.rs:401-436 KATs) */
+void oracle_electron_create(long cell, double x, const double *u, double weight, double dx, double dt, Electron *out)
+{
+    *out = electron_create(cell, x, u, weight, dx, dt);
+}
+int oracle_electron_push(Electron *p, const double *E, const double *B, double dx, double dt)
+{
+    return electron_vay_push(p, E, B, dx, dt);
+}
+void oracle_ion_create(long cell, double x, const double *u, double weight, double dx, double dt, Ion *out)
+{
+    *out = ion_create(cell, x, u, weight, dx, dt);
+}
+int oracle_ion_push(Ion *p, const double *E, const double *B, double dx, double dt)
+{
+    return ion_push(p, E, B, dx, dt);
+}
+
+/* ------------------------------------------------------------- RNG (own) */
+typedef struct { uint64_t s[4]; } Rng;
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t splitmix64(uint64_t *st)
+{
+    uint64_t z = (*st += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+void oracle_rng_seed(Rng *r, uint64_t seed) { for (int i = 0; i < 4; i++) r->s[i] = splitmix64(&seed); }
+uint64_t oracle_rng_next(Rng *r)
+{
+    uint64_t *s = r->s;
+    uint64_t result = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return result;
+}
+double oracle_rng_f64(Rng *r) { return (double)(oracle_rng_next(r) >> 11) * 0x1.0p-53; }
+double oracle_rng_normal(Rng *r)
+{
+    double u1 = oracle_rng_f64(r), u2 = oracle_rng_f64(r);
+    return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * PI * u2);
+}
+double oracle_rng_exp1(Rng *r) { return -log(1.0 - oracle_rng_f64(r)); }
+
+/* ------------------------------------------------------------ Population */
+static size_t psize(int species) { return species == SPECIES_ELECTRON ? sizeof(Electron) : sizeof(Ion); }
+
+Population *oracle_pop_new_empty(int species)
+{
+    Population *p = (Population *)calloc(1, sizeof(Population));
+    p->species = species;
+    return p;
+}
+void oracle_pop_free(Population *p) { if (p) { free(p->store); free(p); } }
+size_t oracle_pop_len(const Population *p) { return p->n; }
+
+static void pop_reserve(Population *p, size_t n)
+{
+    if (n > p->cap) {
+        size_t cap = p->cap ? p->cap : 1024;
+        while (cap < n) cap *= 2;
+        p->store = realloc(p->store, cap * psize(p->species));
+        p->cap = cap;
+    }
+}
+
+/* particle/mod.rs:172-203.  RNG draw order per particle: x, then (urand,
+ * nrand) for ux, uy, uz, then the species' optical depths (electron: one Exp1,
+ * electron.rs:168-172; ion: none, ion.rs:157-159). */
+Population *oracle_pop_new(int species, size_t npc, fn1_t number_density, fn3_t ux, fn3_t uy, fn3_t uz,
+                           void *user, const YeeGrid *grid, Rng *rng, double dt)
+{
+    Population *p = oracle_pop_new_empty(species);
+    double gxmin = oracle_grid_xmin(grid), dx = grid->dx;
+    for (long c = 0; c < (long)grid->size; c++) {
+        double x = gxmin + (((double)c) + 0.5) * dx;
+        double nreal = number_density(x, user) * dx;
+        double weight = nreal / ((double)npc);
+        size_t nsuper = nreal > 0.0 ? npc : 0;
+        pop_reserve(p, p->n + nsuper);
+        for (size_t i = 0; i < nsuper; i++) {
+            double xf = oracle_rng_f64(rng);
+            double real_x = gxmin + (((double)c) + xf) * dx;
+            double u[3];
+            double ur = oracle_rng_f64(rng), nr = oracle_rng_normal(rng);
+            u[0] = ux(real_x, ur, nr, user);
+            ur = oracle_rng_f64(rng); nr = oracle_rng_normal(rng);
+            u[1] = uy(real_x, ur, nr, user);
+            ur = oracle_rng_f64(rng); nr = oracle_rng_normal(rng);
+            u[2] = uz(real_x, ur, nr, user);
+            if (species == SPECIES_ELECTRON) {
+                Electron e = electron_create(c, xf, u, weight, dx, dt);
+                e.tau = oracle_rng_exp1(rng);
+                ((Electron *)p->store)[p->n++] = e;
+            } else {
+                ((Ion *)p->store)[p->n++] = ion_create(c, xf, u, weight, dx, dt);
+            }
+        }
+    }
+    return p;
+}
+
+/* main.rs:142-147 + ion.rs:236-241 */
+void oracle_pop_set_charge_state(Population *p, double zstar, double z, double a)
+{
+    if (p->species != SPECIES_ION) return;
+    Ion *s = (Ion *)p->store;
+    for (size_t i = 0; i < p->n; i++) { s[i].Z_star = zstar; s[i].Z = z; s[i].A = a; }
+}
+
+/* SoA import/export for the tests.  aux = gamma (electron) / gamma_m1 (ion). */
+void oracle_pop_get_soa(const Population *p, long *cell, double *x, double *prev_x, double *ux, double *uy,
+                        double *uz, double *w, double *aux)
+{
+    for (size_t i = 0; i < p->n; i++) {
+        if (p->species == SPECIES_ELECTRON) {
+            const Electron *e = &((const Electron *)p->store)[i];
+            cell[i] = e->cell; x[i] = e->x; prev_x[i] = e->prev_x;
+            ux[i] = e->u[0]; uy[i] = e->u[1]; uz[i] = e->u[2]; w[i] = e->weight; aux[i] = e->gamma;
+        } else {
+            const Ion *e = &((const Ion *)p->store)[i];
+            cell[i] = e->cell; x[i] = e->x; prev_x[i] = e->prev_x;
+            ux[i] = e->u[0]; uy[i] = e->u[1]; uz[i] = e->u[2]; w[i] = e->weight; aux[i] = e->gamma_m1;
+        }
+    }
+}
+/* electron extras: chi, tau, work, y, z */
+void oracle_pop_get_electron_extras(const Population *p, double *chi, double *tau, double *work, double *y, double *z)
+{
+    if (p->species != SPECIES_ELECTRON) return;
+    for (size_t i = 0; i < p->n; i++) {
+        const Electron *e = &((const Electron *)p->store)[i];
+        chi[i] = e->chi; tau[i] = e->tau; work[i] = e->work; y[i] = e->y; z[i] = e->z;
+    }
+}
+
+/* Builds a population from SoA arrays through T::create (so prev_x and
+ * gamma / gamma_m1 are those of electron.rs:85-103 / ion.rs:81-101). */
+Population *oracle_pop_from_soa(int species, size_t n, const long *cell, const double *x, const double *ux,
+                                const double *uy, const double *uz, const double *w, double dx, double dt)
+{
+    Population *p = oracle_pop_new_empty(species);
+    pop_reserve(p, n);
+    for (size_t i = 0; i < n; i++) {
+        double u[3] = {ux[i], uy[i], uz[i]};
+        if (species == SPECIES_ELECTRON) ((Electron *)p->store)[i] = electron_create(cell[i], x[i], u, w[i], dx, dt);
+        else ((Ion *)p->store)[i] = ion_create(cell[i], x[i], u, w[i], dx, dt);
+    }
+    p->n = n;
+    return p;
+}
+/* overwrite prev_x and aux (gamma / gamma_m1) after from_soa, for mid-run states */
+void oracle_pop_set_prev_aux(Population *p, const double *prev_x, const double *aux)
+{
+    for (size_t i = 0; i < p->n; i++) {
+        if (p->species == SPECIES_ELECTRON) {
+            Electron *e = &((Electron *)p->store)[i];
+            if (prev_x) e->prev_x = prev_x[i];
+            if (aux) e->gamma = aux[i];
+        } else {
+            Ion *e = &((Ion *)p->store)[i];
+            if (prev_x) e->prev_x = prev_x[i];
+            if (aux) e->gamma_m1 = aux[i];
+        }
+    }
+}
+
+/* particle/mod.rs:227-240 (local part) */
+double oracle_pop_total_kinetic_energy(const Population *p)
+{
+    double sum = 0.0;
+    for (size_t i = 0; i < p->n; i++)
+        sum += p->species == SPECIES_ELECTRON ? electron_ke(&((const Electron *)p->store)[i])
+                                              : ion_ke(&((const Ion *)p->store)[i]);
+    return sum;
+}
+
+static inline long pcell(const Population *p, size_t i)
+{
+    return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].cell : ((const Ion *)p->store)[i].cell;
+}
+static inline void pshift(Population *p, void *store, size_t i, long delta)
+{
+    if (p->species == SPECIES_ELECTRON) ((Electron *)store)[i].cell += delta;
+    else ((Ion *)store)[i].cell += delta;
+}
+
+/* particle/mod.rs:247-293: gather + push every particle, count leavers, sort
+ * by cell, re-base right-leavers.  The sort is a stable counting sort (the
+ * reference's par_sort_unstable_by_key leaves tie order unspecified).
+ * Returns the number of particles that tripped an assert (fields_at bounds,
+ * dxi < 1). */
+size_t oracle_pop_push_and_sort(Population *p, const YeeGrid *grid, double dt, int nthreads)
+{
+    double dx = grid->dx;
+    long max = (long)grid->size;
+    size_t num = p->n, bad = 0, gl = 0, gr = 0;
+    (void)nthreads;
+#pragma omp parallel for reduction(+ : bad, gl, gr) schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (size_t i = 0; i < num; i++) {
+        double E[3], B[3];
+        long c;
+        if (p->species == SPECIES_ELECTRON) {
+            Electron *e = &((Electron *)p->store)[i];
+            if (oracle_grid_fields_at(grid, e->cell, e->x, E, B)) { bad++; continue; }
+            bad += (size_t)electron_vay_push(e, E, B, dx, dt);
+            e->flag = 0;
+            c = e->cell;
+        } else {
+            Ion *e = &((Ion *)p->store)[i];
+            if (oracle_grid_fields_at(grid, e->cell, e->x, E, B)) { bad++; continue; }
+            bad += (size_t)ion_push(e, E, B, dx, dt);
+            e->flag = 0;
+            c = e->cell;
+        }
+        if (c < 0) gl++;
+        else if (c >= max) gr++;
+    }
+    /* stable counting sort on cell in [-1, max] (anything outside is clamped into the end bins) */
+    if (num) {
+        size_t nb = (size_t)max + 2, sz = psize(p->species);
+        size_t *count = (size_t *)calloc(nb + 1, sizeof(size_t));
+        char *out = (char *)malloc(num * sz);
+        for (size_t i = 0; i < num; i++) {
+            long c = pcell(p, i);
+            long b = c < 0 ? 0 : (c >= max ? max + 1 : c + 1);
+            count[b + 1]++;
+        }
+        for (size_t b = 0; b < nb; b++) count[b + 1] += count[b];
+        for (size_t i = 0; i < num; i++) {
+            long c = pcell(p, i);
+            long b = c < 0 ? 0 : (c >= max ? max + 1 : c + 1);
+            memcpy(out + (count[b]++) * sz, (char *)p->store + i * sz, sz);
+        }
+        memcpy(p->store, out, num * sz);
+        free(out);
+        free(count);
+    }
+    for (size_t i = num - gr; i < num; i++) pshift(p, p->store, i, -max); /* mod.rs:291-293 */
+    p->gone_left = gl;
+    p->gone_right = gr;
+    return bad;
+}
+
+size_t oracle_pop_gone_left(const Population *p) { return p->gone_left; }
+size_t oracle_pop_gone_right(const Population *p) { return p->gone_right; }
+/* mod.rs:296-297: raw AoS slices of the leavers */
+const void *oracle_pop_send_left(const Population *p) { return p->store; }
+const void *oracle_pop_send_right(const Population *p)
+{
+    return (const char *)p->store + (p->n - p->gone_right) * psize(p->species);
+}
+size_t oracle_pop_particle_size(const Population *p) { return psize(p->species); }
+
+/* particle/mod.rs:365-373: shift arrivals from the right by +max, splice the
+ * arrivals over the leavers.  recv_* are AoS arrays of the species struct. */
+void oracle_pop_splice(Population *p, const YeeGrid *grid, const void *recv_left, size_t nl,
+                       const void *recv_right, size_t nr)
+{
+    size_t sz = psize(p->species), num = p->n, gl = p->gone_left, gr = p->gone_right;
+    long max = (long)grid->size;
+    size_t keep = num - gl - gr, newn = nl + keep + nr;
+    char *out = (char *)malloc((newn ? newn : 1) * sz);
+    if (nl) memcpy(out, recv_left, nl * sz);
+    memcpy(out + nl * sz, (char *)p->store + gl * sz, keep * sz);
+    if (nr) memcpy(out + (nl + keep) * sz, recv_right, nr * sz);
+    for (size_t i = nl + keep; i < newn; i++) pshift(p, out, i, max);
+    free(p->store);
+    p->store = out;
+    p->n = newn;
+    p->cap = newn ? newn : 1;
+    p->gone_left = p->gone_right = 0;
+}
+
+/* Population::advance (mod.rs:247-376) for a set of subdomains in one process.
+ * Leavers through a non-Internal edge are dropped (to_left()/to_right() is
+ * None, yee.rs:329-343); a single periodic subdomain copies to itself
+ * (mod.rs:313-315, 324-326). */
+size_t oracle_world_pop_advance(Population **pops, YeeGrid **grids, int n, double dt, int nthreads)
+{
+    size_t bad = 0;
+    for (int r = 0; r < n; r++) bad += oracle_pop_push_and_sort(pops[r], grids[r], dt, nthreads);
+    /* snapshot all send buffers first */
+    void **sl = (void **)calloc((size_t)n, sizeof(void *)), **sr = (void **)calloc((size_t)n, sizeof(void *));
+    size_t *nl = (size_t *)calloc((size_t)n, sizeof(size_t)), *nr = (size_t *)calloc((size_t)n, sizeof(size_t));
+    for (int r = 0; r < n; r++) {
+        size_t sz = psize(pops[r]->species);
+        nl[r] = pops[r]->gone_left; nr[r] = pops[r]->gone_right;
+        sl[r] = malloc((nl[r] ? nl[r] : 1) * sz); sr[r] = malloc((nr[r] ? nr[r] : 1) * sz);
+        memcpy(sl[r], oracle_pop_send_left(pops[r]), nl[r] * sz);
+        memcpy(sr[r], oracle_pop_send_right(pops[r]), nr[r] * sz);
+    }
+    for (int r = 0; r < n; r++) {
+        int L = oracle_grid_to_left(grids[r]), R = oracle_grid_to_right(grids[r]);
+        /* from the left neighbour we get what it sent right; from the right one what it sent left */
+        const void *rl = L >= 0 ? sr[L] : NULL; size_t cl = L >= 0 ? nr[L] : 0;
+        const void *rr = R >= 0 ? sl[R] : NULL; size_t cr = R >= 0 ? nl[R] : 0;
+        oracle_pop_splice(pops[r], grids[r], rl, cl, rr, cr);
+    }
+    for (int r = 0; r < n; r++) { free(sl[r]); free(sr[r]); }
+    free(sl); free(sr); free(nl); free(nr);
+    return bad;
+}
+
+/* yee.rs:551-641.  nthreads plays rayon::current_num_threads(): it fixes the
+ * chunking and hence the summation order.  Returns the number of particles
+ * that tripped the index asserts (:578-579). */
+size_t oracle_grid_deposit(YeeGrid *g, const Population *p, double dt, int nthreads)
+{
+    double dx = g->dx;
+    size_t size = g->len, bad = 0;
+    long left_bdy_size = g->left_bdy_size;
+    if (p->n == 0) return 0;
+    if (nthreads < 1) nthreads = 1;
+    size_t chunk_len = p->n > (size_t)nthreads ? p->n / (size_t)nthreads : p->n;
+    size_t nchunks = (p->n + chunk_len - 1) / chunk_len;
+    double(*jall)[4] = (double(*)[4])calloc(size * nchunks, sizeof(double[4]));
+#pragma omp parallel for reduction(+ : bad) schedule(static) num_threads(nthreads)
+    for (size_t k = 0; k < nchunks; k++) {
+        double(*j)[4] = jall + k * size;
+        size_t lo = k * chunk_len, hi = lo + chunk_len < p->n ? lo + chunk_len : p->n;
+        for (size_t i = lo; i < hi; i++) {
+            long c; double x, prev_x, macrocharge, vel[3];
+            if (p->species == SPECIES_ELECTRON) {
+                const Electron *e = &((const Electron *)p->store)[i];
+                c = e->cell; x = e->x; prev_x = e->prev_x;
+                macrocharge = e->weight * ELECTRON_CHARGE;
+                /* electron.rs:148-151 */
+                vel[0] = SPEED_OF_LIGHT * e->u[0] / e->gamma;
+                vel[1] = SPEED_OF_LIGHT * e->u[1] / e->gamma;
+                vel[2] = SPEED_OF_LIGHT * e->u[2] / e->gamma;
+            } else {
+                const Ion *e = &((const Ion *)p->store)[i];
+                c = e->cell; x = e->x; prev_x = e->prev_x;
+                macrocharge = e->weight * (e->Z_star * ELEMENTARY_CHARGE);
+                /* ion.rs:123-126 */
+                vel[0] = SPEED_OF_LIGHT * e->u[0] / (1.0 + e->gamma_m1);
+                vel[1] = SPEED_OF_LIGHT * e->u[1] / (1.0 + e->gamma_m1);
+                vel[2] = SPEED_OF_LIGHT * e->u[2] / (1.0 + e->gamma_m1);
+            }
+            long idx = c + left_bdy_size;
+            if (!(idx >= 2) || !((size_t)idx < size - 2)) { bad++; continue; }
+            size_t index = (size_t)idx;
+            j[index    ][0] += macrocharge * oracle_flux( 0.5 - prev_x,  0.5 - x) / dt;
+            j[index - 1][0] += macrocharge * oracle_flux(-0.5 - prev_x, -0.5 - x) / dt;
+            j[index - 2][0] += macrocharge * oracle_flux(-1.5 - prev_x, -1.5 - x) / dt;
+            j[index + 1][0] += macrocharge * oracle_flux( 1.5 - prev_x,  1.5 - x) / dt;
+            j[index + 2][0] += macrocharge * oracle_flux( 2.5 - prev_x,  2.5 - x) / dt;
+
+            j[index - 1][1] += macrocharge * vel[1] * oracle_weight(1.0 + x) / dx;
+            j[index    ][1] += macrocharge * vel[1] * oracle_weight(      x) / dx;
+            j[index + 1][1] += macrocharge * vel[1] * oracle_weight(1.0 - x) / dx;
+            j[index + 2][1] += macrocharge * vel[1] * oracle_weight(2.0 + x) / dx; /* sic, :597 */
+
+            j[index - 1][2] += macrocharge * vel[2] * oracle_weight(1.0 + x) / dx;
+            j[index    ][2] += macrocharge * vel[2] * oracle_weight(      x) / dx;
+            j[index + 1][2] += macrocharge * vel[2] * oracle_weight(1.0 - x) / dx;
+            j[index + 2][2] += macrocharge * vel[2] * oracle_weight(2.0 + x) / dx; /* sic, :602 */
+
+            j[index - 1][3] += macrocharge * oracle_weight(1.0 + x) / dx;
+            j[index    ][3] += macrocharge * oracle_weight(      x) / dx;
+            j[index + 1][3] += macrocharge * oracle_weight(1.0 - x) / dx;
+            j[index - 2][3] += macrocharge * oracle_weight(2.0 - x) / dx; /* sic, :609 */
+        }
+    }
+    /* yee.rs:616-640 */
+    for (size_t i = 0; i < size; i++) {
+        double total[4] = {0.0, 0.0, 0.0, 0.0};
+        for (size_t k = 0; k < nchunks; k++) {
+            total[0] += jall[k * size + i][0];
+            total[1] += jall[k * size + i][1];
+            total[2] += jall[k * size + i][2];
+            total[3] += jall[k * size + i][3];
+        }
+        g->cell[i].j[0] += total[0];
+        g->cell[i].j[1] += total[1];
+        g->cell[i].j[2] += total[2];
+        g->cell[i].rho += total[3];
+    }
+    free(jall);
+    return bad;
+}
+
+/* main.rs:238-267 for in-process subdomains, no QED: one timestep.
+ * pops_e / pops_i may be NULL (npc == 0).  Returns assert-trip count. */
+size_t oracle_world_step(YeeGrid **grids, Population **pops_e, Population **pops_i, int n,
+                         int current_deposition, fn2_t laser_y, fn2_t laser_z, void *user,
+                         double t, double dt, int nthreads)
+{
+    size_t bad = 0;
+    if (pops_e) bad += oracle_world_pop_advance(pops_e, grids, n, dt, nthreads);
+    if (pops_i) bad += oracle_world_pop_advance(pops_i, grids, n, dt, nthreads);
+    if (current_deposition) {
+        for (int r = 0; r < n; r++) {
+            oracle_grid_clear(grids[r]);
+            if (pops_e) bad += oracle_grid_deposit(grids[r], pops_e[r], dt, nthreads);
+            if (pops_i) bad += oracle_grid_deposit(grids[r], pops_i[r], dt, nthreads);
+        }
+    }
+    oracle_world_synchronize(grids, n, laser_y, laser_z, user, t, dt);
+    for (int r = 0; r < n; r++) oracle_grid_advance(grids[r], dt);
+    return bad;
+}
+
+static double zero_laser(double t, double x, void *u) { (void)t; (void)x; (void)u; return 0.0; }
+
+/* n_steps of main.rs:238-267 with no laser (periodic runs); used by the CPU
+ * baseline so that no Python sits in the timed loop. */
+size_t oracle_world_run_periodic(YeeGrid **grids, Population **pops_e, Population **pops_i, int n,
+                                 int current_deposition, double t0, double dt, size_t n_steps, int nthreads)
+{
+    size_t bad = 0;
+    double t = t0;
+    for (size_t s = 0; s < n_steps; s++) {
+        bad += oracle_world_step(grids, pops_e, pops_i, n, current_deposition, zero_laser, zero_laser, NULL, t, dt, nthreads);
+        t += dt;
+    }
+    return bad;
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
