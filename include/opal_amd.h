@@ -1,0 +1,223 @@
+/*
+ * opal_amd.h -- C ABI of the MI355X-native PIC step (libopal_amd.so).
+ *
+ * This is the drop-in boundary for opal's per-timestep loop: one flat function
+ * per method of `trait Grid` (src/grid/mod.rs:47-120) and of `Population<T>`
+ * (src/particle/mod.rs:147-376) that the time loop (src/main.rs:238-267) uses,
+ * plus the host-side set-up the loop needs (GridDesign, the loader, the YAML
+ * driver).  Opaque handles, plain pointers and sizes; no C++ or torch types.
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Conventions
+ *  - every function returning `int` returns an opal_status (0 = OK); on failure
+ *    opal_last_error() holds a message for the calling thread.
+ *  - the library owns all device memory.  Host arrays passed in/out are plain
+ *    host pointers; nothing here takes or returns a device pointer except the
+ *    exchange buffers of opal_link_t, which the transport owner asked for.
+ *  - work is enqueued on the HIP stream given at creation (NULL = the default
+ *    stream); calls that return values to the host synchronise that stream.
+ *  - physics invariants that the reference enforces with `assert!` (particle
+ *    moved >= 1 cell, electron.rs:313 / ion.rs:199; gather or deposit index out
+ *    of the ghost range, yee.rs:501-502,578-579) are detected on the device and
+ *    surface as OPAL_ERR_ASSERT from the next synchronising call.
+ *  - calls on one handle are not re-entrant; `synchronize`, `advance` and the
+ *    energy reductions are collective over subdomains exactly as in the
+ *    reference ("must be called on all processes").
+ */
+#ifndef OPAL_AMD_H
+#define OPAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct opal_grid opal_grid_t; /* YeeGrid, src/grid/yee.rs:255-269 */
+typedef struct opal_pop opal_pop_t;   /* Population<Electron|Ion>, src/particle/mod.rs:141-145 */
+typedef struct opal_link opal_link_t; /* neighbour exchange; stands in for `impl Communicator` */
+typedef struct opal_sim opal_sim_t;   /* main()'s state, src/main.rs:48-215 */
+
+/* enum Boundary, src/grid/mod.rs:22-28 */
+enum opal_boundary { OPAL_BDY_INTERNAL = 0, OPAL_BDY_LASER = 1, OPAL_BDY_ABSORBING = 2, OPAL_BDY_CONDUCTING = 3 };
+/* Electron = Vay push (electron.rs:268-330); Ion = Boris push with Z*, A (ion.rs:168-214) */
+enum opal_species { OPAL_ELECTRON = 0, OPAL_ION = 1 };
+
+enum opal_status {
+    OPAL_OK = 0,
+    OPAL_ERR_ARG = 1,      /* bad argument / handle */
+    OPAL_ERR_HIP = 2,      /* HIP runtime error, or no GPU / extension unusable */
+    OPAL_ERR_ASSERT = 3,   /* a reference `assert!` would have fired */
+    OPAL_ERR_CAPACITY = 4, /* population or exchange buffer capacity exceeded */
+    OPAL_ERR_CONFIG = 5,   /* ConfigError, src/setup.rs:33-61 */
+    OPAL_ERR_IO = 6,
+    OPAL_ERR_LINK = 7      /* exchange callback failed */
+};
+
+/* raw grid component ids for opal_grid_get_raw / set_raw (ghost-inclusive arrays) */
+enum opal_comp {
+    OPAL_X = 0, OPAL_RHO = 1, OPAL_JX = 2, OPAL_JY = 3, OPAL_JZ = 4,
+    OPAL_EX = 5, OPAL_EY = 6, OPAL_EZ = 7, OPAL_BX = 8, OPAL_BY = 9, OPAL_BZ = 10
+};
+
+typedef double (*opal_fn1)(double x, void *user);
+typedef double (*opal_fn2)(double t, double x, void *user);                    /* laser Ey/Ez, main.rs:89-90 */
+typedef double (*opal_fn3)(double x, double urand, double nrand, void *user);  /* ux/uy/uz, main.rs:121-123 */
+
+const char *opal_last_error(void);
+const char *opal_version(void);
+/* number of visible GPUs; OPAL_ERR_HIP when there is none */
+int opal_device_count(int *count);
+int opal_set_device(int device);
+
+/* ------------------------------------------------------------------ GridDesign
+ * src/grid/mod.rs:126-151 (unbalanced) and :157-206 (balanced).  nx / offset
+ * have `numtasks` entries.  balanced returns OPAL_ERR_CONFIG where the reference
+ * panics on unwrap (:179). */
+int opal_design_unbalanced(int numtasks, size_t size, double dx, size_t min_subsize, size_t *nx, double *offset);
+int opal_design_balanced(int numtasks, size_t size, double xmin, double dx, size_t min_subsize,
+                         opal_fn1 ne, void *user, size_t *nx, double *offset);
+
+/* ------------------------------------------------------------------------ Grid */
+/* Grid::build, grid/mod.rs:49, yee.rs:272-319 */
+int opal_grid_build(opal_grid_t **out, int id, int numtasks, int left, int right, double xmin, double dx,
+                    const size_t *nx, const double *offset, void *hip_stream);
+int opal_grid_free(opal_grid_t *g);
+int opal_grid_rank(const opal_grid_t *g);          /* yee.rs:321 */
+int opal_grid_ngrids(const opal_grid_t *g);        /* yee.rs:325 */
+int opal_grid_to_left(const opal_grid_t *g);       /* yee.rs:329; -1 = None */
+int opal_grid_to_right(const opal_grid_t *g);      /* yee.rs:337; -1 = None */
+double opal_grid_xmin(const opal_grid_t *g);       /* yee.rs:531 */
+double opal_grid_dx(const opal_grid_t *g);         /* yee.rs:535 */
+size_t opal_grid_size(const opal_grid_t *g);       /* yee.rs:539: interior cells */
+size_t opal_grid_len(const opal_grid_t *g);        /* interior + boundary cells */
+size_t opal_grid_left_bdy_size(const opal_grid_t *g);
+size_t opal_grid_right_bdy_size(const opal_grid_t *g);
+size_t opal_grid_min_size(void);                   /* yee.rs:783 */
+int opal_grid_clear(opal_grid_t *g);               /* yee.rs:543 */
+/* yee.rs:551-641: adds the currents/charge of `pop` (needs prev_x, i.e. a prior opal_pop_advance) */
+int opal_grid_deposit(opal_grid_t *g, const opal_pop_t *pop, double dt);
+/* yee.rs:351-496: halo exchange through `link` (NULL = single subdomain), then
+ * the laser / absorbing / conducting boundary conditions.  laser_y / laser_z are
+ * evaluated on the host at exactly one (t, x), as the reference does (:458-461);
+ * they may be NULL when the left boundary is not a laser. */
+int opal_grid_synchronize(opal_grid_t *g, opal_link_t *link, opal_fn2 laser_y, opal_fn2 laser_z, void *user,
+                          double t, double dt);
+int opal_grid_advance(opal_grid_t *g, double dt);  /* yee.rs:345-349: B(dt/2), E(dt), B(dt/2) */
+/* yee.rs:499-529 for n (cell, offset) pairs; E, B are [n][3] host arrays */
+int opal_grid_fields_at(const opal_grid_t *g, size_t n, const int32_t *c, const double *xi, double *E, double *B);
+/* yee.rs:787-809: this subdomain's part; the caller sums over subdomains (the MPI reduce) */
+int opal_grid_em_field_energy(const opal_grid_t *g, double *energy);
+/* yee.rs:815-835: `size` rows of 11 doubles (x rho jx jy jz Ex Ey Ez Bx By Bz), the payload of write_data */
+int opal_grid_interpolate(const opal_grid_t *g, double *out);
+/* yee.rs:749-781 for a single subdomain: writes "{dir}/{index}_grid.dat" */
+int opal_grid_write_data(const opal_grid_t *g, const char *dir, size_t index);
+/* ghost-inclusive component arrays (len doubles), for tests and for drivers that inject currents */
+int opal_grid_get_raw(const opal_grid_t *g, int comp, double *out);
+int opal_grid_set_raw(opal_grid_t *g, int comp, const double *in);
+
+/* ------------------------------------------------------------------ Population */
+/* Population::new_empty (mod.rs:156); `capacity` slots are reserved on the device */
+int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_stream);
+int opal_pop_free(opal_pop_t *p);
+/* Population::new, mod.rs:172-203, with this library's documented RNG (xoshiro256**,
+ * SplitMix64 seeding, seed = `seed`); draw order per particle as in the reference. */
+int opal_pop_new(opal_pop_t **out, int species, size_t npc, opal_fn1 number_density, opal_fn3 ux, opal_fn3 uy,
+                 opal_fn3 uz, void *user, const opal_grid_t *grid, uint64_t seed, double dt, void *hip_stream);
+/* Ion::with_charge_state applied to every ion (main.rs:142-147, ion.rs:236-241) */
+int opal_pop_set_charge_state(opal_pop_t *p, double z_star, double z, double a);
+/* T::create for n particles (electron.rs:85-103, ion.rs:81-101): prev_x is derived from u, dx, dt */
+int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const double *x, const double *ux,
+                        const double *uy, const double *uz, const double *w, double dx, double dt);
+/* live particles only, in storage order; any pointer may be NULL.  prev_x is valid after advance. */
+int opal_pop_download_soa(const opal_pop_t *p, int32_t *cell, double *x, double *prev_x, double *ux,
+                          double *uy, double *uz, double *w);
+int opal_pop_len(const opal_pop_t *p, size_t *n);  /* store.len() */
+/* Population::advance, mod.rs:247-376: gather + push + migration to the neighbours
+ * of `grid` through `link` (NULL = single subdomain: periodic self-wrap, or deletion
+ * at open edges).  Stores prev_x for a later opal_grid_deposit. */
+int opal_pop_advance(opal_pop_t *p, opal_link_t *link, const opal_grid_t *grid, double dt);
+/* The fused hot path: advance + this population's deposit into `grid` in ONE pass
+ * over the particles (same result as opal_pop_advance then opal_grid_deposit up to
+ * floating-point summation order).  Particles deleted at an open edge deposit nothing,
+ * as in the reference where deletion precedes deposition (main.rs:239-257). */
+int opal_pop_advance_deposit(opal_pop_t *p, opal_link_t *link, opal_grid_t *grid, double dt);
+/* mod.rs:227-240: this subdomain's part */
+int opal_pop_total_kinetic_energy(const opal_pop_t *p, double *energy);
+/* Re-bins the particles by cell (the reference sorts inside every advance, mod.rs:288).
+ * Results never depend on it being called; throughput does. */
+int opal_pop_sort(opal_pop_t *p, const opal_grid_t *grid);
+/* 0 = never re-bin automatically; n = every n calls of advance; <0 = adaptive (default) */
+int opal_pop_set_sort_interval(opal_pop_t *p, int interval);
+/* carry y, z, chi, work, tau for electrons (electron.rs:18-25); off by default */
+int opal_pop_track_extras(opal_pop_t *p, int on);
+int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z);
+
+/* ------------------------------------------------------------------------ Link
+ * Neighbour exchange for one subdomain of `size`.  The library fills fixed-size
+ * send buffers and calls `exchange` once per exchange point; the callee moves
+ * send_left -> left neighbour's recv_right and send_right -> right neighbour's
+ * recv_left (e.g. RCCL/NCCL or gloo send/recv) and returns 0.  Buffers are
+ * device memory when device_buffers != 0 (stream-ordered transports such as
+ * RCCL: the callee must order its transfers after/before work on `hip_stream`),
+ * else pinned host memory (the library synchronises around the call). */
+typedef int (*opal_exchange_fn)(void *user, const void *send_left, const void *send_right, void *recv_left,
+                                void *recv_right, size_t nbytes);
+int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, size_t particle_capacity,
+                     opal_exchange_fn exchange, void *user, void *hip_stream);
+int opal_link_free(opal_link_t *l);
+size_t opal_link_message_bytes(const opal_link_t *l);
+
+/* ------------------------------------------------------------------ Simulation
+ * main() of the reference (src/main.rs:48-286) for the hot-path configurations:
+ * reads the same YAML input file, builds grid + populations for subdomain `rank`
+ * of `numtasks`, and runs the time loop (no QED). */
+int opal_sim_create(opal_sim_t **out, const char *yaml_path, int rank, int numtasks, opal_link_t *link,
+                    void *hip_stream);
+int opal_sim_create_from_string(opal_sim_t **out, const char *yaml_text, const char *output_dir, int rank,
+                                int numtasks, opal_link_t *link, void *hip_stream);
+int opal_sim_free(opal_sim_t *s);
+/* `n` iterations of main.rs:238-267 */
+int opal_sim_step(opal_sim_t *s, size_t n);
+/* the whole of main.rs:217-283, writing {i}_energy.dat / {i}_grid.dat into the output directory */
+int opal_sim_run(opal_sim_t *s);
+int opal_sim_sync(opal_sim_t *s);
+double opal_sim_time(const opal_sim_t *s);
+double opal_sim_dt(const opal_sim_t *s);
+size_t opal_sim_total_steps(const opal_sim_t *s);      /* main.rs:186 */
+size_t opal_sim_steps_between_outputs(const opal_sim_t *s); /* main.rs:187 */
+size_t opal_sim_n_outputs(const opal_sim_t *s);
+opal_grid_t *opal_sim_grid(opal_sim_t *s);
+opal_pop_t *opal_sim_electrons(opal_sim_t *s);
+opal_pop_t *opal_sim_ions(opal_sim_t *s);
+/* write_energies, main.rs:23-42: em_field, electrons, ions (this subdomain's parts) */
+int opal_sim_energies(opal_sim_t *s, double *em_field, double *electrons, double *ions);
+/* 1 = use the fused advance+deposit pass (default), 0 = the reference's operator sequence */
+int opal_sim_set_fused(opal_sim_t *s, int fused);
+/* per-kernel timing with HIP events on the library's stream */
+int opal_prof_enable(int on);
+int opal_prof_reset(void);
+/* kernel ids: 0 = fused advance+deposit, 1 = advance, 2 = deposit, 3 = field solve, 4 = sort */
+int opal_prof_get(int kernel, uint64_t *launches, double *total_ms);
+
+/* ------------------------------------------------------------------- Config
+ * src/setup.rs: typed reads of `section.field` with the `constants` context. */
+typedef struct opal_config opal_config_t;
+int opal_config_from_file(opal_config_t **out, const char *path);
+int opal_config_from_string(opal_config_t **out, const char *text);
+int opal_config_free(opal_config_t *c);
+int opal_config_contains(const opal_config_t *c, const char *section);
+int opal_config_read_f64(const opal_config_t *c, const char *section, const char *field, double *out);
+int opal_config_read_usize(const opal_config_t *c, const char *section, const char *field, size_t *out);
+int opal_config_read_bool(const opal_config_t *c, const char *section, const char *field, int *out);
+/* Config::func / func2 / func3 evaluated at a point (args beyond the arity are ignored) */
+int opal_config_eval(const opal_config_t *c, const char *section, const char *field, int nargs,
+                     const char *const *arg_names, const double *arg_values, double *out);
+/* bare expression against the config's context (meval grammar) */
+int opal_config_eval_expr(const opal_config_t *c, const char *expr, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPAL_AMD_H */

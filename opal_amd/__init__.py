@@ -1,0 +1,379 @@
+"""opal_amd: MI355X-native implementation of opal's per-timestep PIC loop.
+
+Python mirror of the reference's operator surface -- `Grid` (trait Grid,
+src/grid/mod.rs:47-120; YeeGrid, src/grid/yee.rs) and `Population`
+(src/particle/mod.rs:141-376) -- over the C ABI in include/opal_amd.h.  Method
+names and argument meaning follow the reference; errors the reference raises
+as ConfigError or panics surface as `OpalError`.  All compute is in the HIP
+library; nothing here has a CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FN1, FN2, FN3
+
+BDY_INTERNAL, BDY_LASER, BDY_ABSORBING, BDY_CONDUCTING = 0, 1, 2, 3
+ELECTRON, ION = 0, 1
+COMP = {"x": 0, "rho": 1, "jx": 2, "jy": 3, "jz": 4, "Ex": 5, "Ey": 6, "Ez": 7, "Bx": 8, "By": 9, "Bz": 10}
+KERNELS = {"fused": 0, "advance": 1, "deposit": 2, "field": 3, "sort": 4}
+
+# src/constants.rs
+SPEED_OF_LIGHT = 2.997925e8
+
+
+class OpalError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"[opal status {status}] {message}")
+        self.status = status
+
+
+def _check(rc):
+    if rc != 0:
+        raise OpalError(rc, _lib.load().opal_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(_lib.load().opal_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(i):
+    _check(_lib.load().opal_set_device(i))
+
+
+def design_unbalanced(numtasks, size, dx, min_subsize=8):
+    """GridDesign::unbalanced (grid/mod.rs:126-151)."""
+    nx = np.zeros(numtasks, dtype=np.uint64)
+    off = np.zeros(numtasks, dtype=np.float64)
+    _check(_lib.load().opal_design_unbalanced(numtasks, size, dx, min_subsize, _ptr(nx), _ptr(off)))
+    return nx, off
+
+
+def design_balanced(numtasks, size, xmin, dx, ne, min_subsize=8):
+    """GridDesign::balanced (grid/mod.rs:157-206)."""
+    nx = np.zeros(numtasks, dtype=np.uint64)
+    off = np.zeros(numtasks, dtype=np.float64)
+    cb = FN1(lambda x, u: float(ne(x)))
+    _check(_lib.load().opal_design_balanced(numtasks, size, xmin, dx, min_subsize, cb, None, _ptr(nx), _ptr(off)))
+    return nx, off
+
+
+class Grid:
+    """YeeGrid on the GPU."""
+
+    def __init__(self, rank, ngrids, left, right, xmin, dx, nx, offset, stream=None, _handle=None):
+        self._lib = _lib.load()
+        self._owned = _handle is None
+        if _handle is None:
+            nx = np.ascontiguousarray(nx, dtype=np.uint64)
+            offset = np.ascontiguousarray(offset, dtype=np.float64)
+            h = C.c_void_p()
+            _check(self._lib.opal_grid_build(C.byref(h), rank, ngrids, left, right, xmin, dx, _ptr(nx), _ptr(offset), stream))
+            self.h = h
+        else:
+            self.h = C.c_void_p(_handle)
+        self.size = self._lib.opal_grid_size(self.h)
+        self.len = self._lib.opal_grid_len(self.h)
+        self.left_bdy_size = self._lib.opal_grid_left_bdy_size(self.h)
+        self.right_bdy_size = self._lib.opal_grid_right_bdy_size(self.h)
+        self.dx = self._lib.opal_grid_dx(self.h)
+
+    @classmethod
+    def single(cls, nx, xmin, dx, left=BDY_INTERNAL, right=BDY_INTERNAL, stream=None):
+        n, off = design_unbalanced(1, nx, dx)
+        return cls(0, 1, left, right, xmin, dx, n, off, stream)
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "h", None):
+            self._lib.opal_grid_free(self.h)
+            self.h = None
+
+    def rank(self):
+        return self._lib.opal_grid_rank(self.h)
+
+    def ngrids(self):
+        return self._lib.opal_grid_ngrids(self.h)
+
+    def to_left(self):
+        return self._lib.opal_grid_to_left(self.h)
+
+    def to_right(self):
+        return self._lib.opal_grid_to_right(self.h)
+
+    def xmin(self):
+        return self._lib.opal_grid_xmin(self.h)
+
+    def clear(self):
+        _check(self._lib.opal_grid_clear(self.h))
+
+    def deposit(self, pop, dt):
+        _check(self._lib.opal_grid_deposit(self.h, pop.h, dt))
+
+    def synchronize(self, laser_y=None, laser_z=None, t=0.0, dt=0.0, link=None):
+        ly = FN2(lambda t_, x_, u: float(laser_y(t_, x_))) if laser_y else FN2()
+        lz = FN2(lambda t_, x_, u: float(laser_z(t_, x_))) if laser_z else FN2()
+        _check(self._lib.opal_grid_synchronize(self.h, link.h if link else None, ly, lz, None, t, dt))
+
+    def advance(self, dt):
+        _check(self._lib.opal_grid_advance(self.h, dt))
+
+    def fields_at(self, c, xi):
+        c = np.ascontiguousarray(np.atleast_1d(c), dtype=np.int32)
+        xi = np.ascontiguousarray(np.atleast_1d(xi), dtype=np.float64)
+        E = np.empty((len(c), 3))
+        B = np.empty((len(c), 3))
+        _check(self._lib.opal_grid_fields_at(self.h, len(c), _ptr(c), _ptr(xi), _ptr(E), _ptr(B)))
+        return E, B
+
+    def em_field_energy(self):
+        e = C.c_double()
+        _check(self._lib.opal_grid_em_field_energy(self.h, C.byref(e)))
+        return e.value
+
+    def interpolate(self):
+        out = np.empty((self.size, 11))
+        _check(self._lib.opal_grid_interpolate(self.h, _ptr(out)))
+        return out
+
+    def write_data(self, directory, index):
+        _check(self._lib.opal_grid_write_data(self.h, directory.encode(), index))
+
+    def raw(self, name):
+        out = np.empty(self.len)
+        _check(self._lib.opal_grid_get_raw(self.h, COMP[name], _ptr(out)))
+        return out
+
+    def set_raw(self, name, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self.len,)
+        _check(self._lib.opal_grid_set_raw(self.h, COMP[name], _ptr(a)))
+
+
+class Population:
+    """Population<Electron> / Population<Ion> on the GPU (SoA in HBM)."""
+
+    def __init__(self, species, capacity=0, stream=None, _handle=None):
+        self._lib = _lib.load()
+        self.species = species
+        self._owned = _handle is None
+        if _handle is None:
+            h = C.c_void_p()
+            _check(self._lib.opal_pop_create(C.byref(h), species, capacity, stream))
+            self.h = h
+        else:
+            self.h = C.c_void_p(_handle)
+
+    @classmethod
+    def new(cls, species, npc, number_density, ux, uy, uz, grid, seed, dt, stream=None):
+        """Population::new (mod.rs:172-203)."""
+        lib = _lib.load()
+        d = FN1(lambda x, u: float(number_density(x)))
+        fx = FN3(lambda x, ur, nr, u: float(ux(x, ur, nr)))
+        fy = FN3(lambda x, ur, nr, u: float(uy(x, ur, nr)))
+        fz = FN3(lambda x, ur, nr, u: float(uz(x, ur, nr)))
+        h = C.c_void_p()
+        _check(lib.opal_pop_new(C.byref(h), species, npc, d, fx, fy, fz, None, grid.h, seed, dt, stream))
+        p = cls(species, _handle=h.value)
+        p._owned = True
+        return p
+
+    @classmethod
+    def from_soa(cls, species, cell, x, ux, uy, uz, w, dx, dt, capacity=None, stream=None):
+        n = len(cell)
+        p = cls(species, capacity if capacity is not None else n + n // 8 + 1024, stream)
+        p.upload(cell, x, ux, uy, uz, w, dx, dt)
+        return p
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and getattr(self, "h", None):
+            self._lib.opal_pop_free(self.h)
+            self.h = None
+
+    def upload(self, cell, x, ux, uy, uz, w, dx, dt):
+        cell = np.ascontiguousarray(cell, dtype=np.int32)
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, ux, uy, uz, w)]
+        _check(self._lib.opal_pop_upload_soa(self.h, len(cell), _ptr(cell), *[_ptr(a) for a in arrs], dx, dt))
+
+    def set_charge_state(self, z_star, z, a):
+        _check(self._lib.opal_pop_set_charge_state(self.h, z_star, z, a))
+
+    def __len__(self):
+        n = C.c_size_t()
+        _check(self._lib.opal_pop_len(self.h, C.byref(n)))
+        return n.value
+
+    def soa(self, prev_x=False):
+        n = len(self)
+        cell = np.empty(n, dtype=np.int32)
+        out = {k: np.empty(n) for k in ("x", "ux", "uy", "uz", "w")}
+        px = np.empty(n) if prev_x else None
+        _check(self._lib.opal_pop_download_soa(self.h, _ptr(cell), _ptr(out["x"]), _ptr(px), _ptr(out["ux"]),
+                                               _ptr(out["uy"]), _ptr(out["uz"]), _ptr(out["w"])))
+        out["cell"] = cell
+        if prev_x:
+            out["prev_x"] = px
+        return out
+
+    def advance(self, grid, dt, link=None):
+        _check(self._lib.opal_pop_advance(self.h, link.h if link else None, grid.h, dt))
+
+    def advance_deposit(self, grid, dt, link=None):
+        _check(self._lib.opal_pop_advance_deposit(self.h, link.h if link else None, grid.h, dt))
+
+    def total_kinetic_energy(self):
+        e = C.c_double()
+        _check(self._lib.opal_pop_total_kinetic_energy(self.h, C.byref(e)))
+        return e.value
+
+    def sort(self, grid):
+        _check(self._lib.opal_pop_sort(self.h, grid.h))
+
+    def set_sort_interval(self, interval):
+        _check(self._lib.opal_pop_set_sort_interval(self.h, interval))
+
+    def track_extras(self, on=True):
+        _check(self._lib.opal_pop_track_extras(self.h, 1 if on else 0))
+
+    def extras(self):
+        n = len(self)
+        out = {k: np.empty(n) for k in ("chi", "work", "y", "z")}
+        _check(self._lib.opal_pop_download_extras(self.h, *[_ptr(out[k]) for k in ("chi", "work", "y", "z")]))
+        return out
+
+
+class Simulation:
+    """main() of the reference (src/main.rs) for one subdomain."""
+
+    def __init__(self, yaml_path=None, yaml_text=None, output_dir=".", rank=0, numtasks=1, link=None, stream=None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        lk = link.h if link else None
+        if yaml_path is not None:
+            _check(self._lib.opal_sim_create(C.byref(h), str(yaml_path).encode(), rank, numtasks, lk, stream))
+        else:
+            _check(self._lib.opal_sim_create_from_string(C.byref(h), yaml_text.encode(), output_dir.encode(), rank,
+                                                         numtasks, lk, stream))
+        self.h = h
+        self._link = link
+        self.grid = Grid(0, 0, 0, 0, 0, 0, None, None, _handle=self._lib.opal_sim_grid(h))
+        e = self._lib.opal_sim_electrons(h)
+        i = self._lib.opal_sim_ions(h)
+        self.electrons = Population(ELECTRON, _handle=e) if e else None
+        self.ions = Population(ION, _handle=i) if i else None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._lib.opal_sim_free(self.h)
+            self.h = None
+
+    def step(self, n=1):
+        _check(self._lib.opal_sim_step(self.h, n))
+
+    def sync(self):
+        _check(self._lib.opal_sim_sync(self.h))
+
+    def run(self):
+        _check(self._lib.opal_sim_run(self.h))
+
+    def set_fused(self, fused):
+        _check(self._lib.opal_sim_set_fused(self.h, 1 if fused else 0))
+
+    @property
+    def t(self):
+        return self._lib.opal_sim_time(self.h)
+
+    @property
+    def dt(self):
+        return self._lib.opal_sim_dt(self.h)
+
+    @property
+    def total_steps(self):
+        return self._lib.opal_sim_total_steps(self.h)
+
+    @property
+    def steps_between_outputs(self):
+        return self._lib.opal_sim_steps_between_outputs(self.h)
+
+    @property
+    def n_outputs(self):
+        return self._lib.opal_sim_n_outputs(self.h)
+
+    def energies(self):
+        f, e, i = C.c_double(), C.c_double(), C.c_double()
+        _check(self._lib.opal_sim_energies(self.h, C.byref(f), C.byref(e), C.byref(i)))
+        return f.value, e.value, i.value
+
+
+class Config:
+    """Config (src/setup.rs:84-285)."""
+
+    def __init__(self, path=None, text=None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        if path is not None:
+            _check(self._lib.opal_config_from_file(C.byref(h), str(path).encode()))
+        else:
+            _check(self._lib.opal_config_from_string(C.byref(h), text.encode()))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._lib.opal_config_free(self.h)
+            self.h = None
+
+    def contains(self, section):
+        return bool(self._lib.opal_config_contains(self.h, section.encode()))
+
+    def read_f64(self, section, field):
+        v = C.c_double()
+        _check(self._lib.opal_config_read_f64(self.h, section.encode(), field.encode(), C.byref(v)))
+        return v.value
+
+    def read_usize(self, section, field):
+        v = C.c_size_t()
+        _check(self._lib.opal_config_read_usize(self.h, section.encode(), field.encode(), C.byref(v)))
+        return v.value
+
+    def read_bool(self, section, field):
+        v = C.c_int()
+        _check(self._lib.opal_config_read_bool(self.h, section.encode(), field.encode(), C.byref(v)))
+        return bool(v.value)
+
+    def func(self, section, field, args):
+        """Config::func/func2/func3: returns a Python callable of len(args) floats."""
+        names = (C.c_char_p * len(args))(*[a.encode() for a in args])
+
+        def f(*vals):
+            v = (C.c_double * len(args))(*vals)
+            out = C.c_double()
+            _check(self._lib.opal_config_eval(self.h, section.encode(), field.encode(), len(args), names, v, C.byref(out)))
+            return out.value
+
+        return f
+
+    def eval(self, expr):
+        out = C.c_double()
+        _check(self._lib.opal_config_eval_expr(self.h, expr.encode(), C.byref(out)))
+        return out.value
+
+
+def prof_enable(on=True):
+    _check(_lib.load().opal_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    _check(_lib.load().opal_prof_reset())
+
+
+def prof_get(kernel):
+    n = C.c_uint64()
+    ms = C.c_double()
+    _check(_lib.load().opal_prof_get(KERNELS[kernel], C.byref(n), C.byref(ms)))
+    return n.value, ms.value

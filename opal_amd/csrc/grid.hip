@@ -1,0 +1,547 @@
+// YeeGrid on the GPU: SoA field/current arrays resident in HBM, halo pack +
+// boundary-condition kernel, and the fused B(dt/2)-E(dt)-B(dt/2) stencil.
+//
+// HBM layout (doubles): two ping-pong field buffers d_eb[k][6][lenp] holding
+// Ex Ey Ez Bx By Bz, and d_j[4][lenp] holding jx jy jz rho; lenp = len rounded
+// up to 64 so every component row starts on a 512-byte boundary.  The field
+// solve reads d_eb[cur] and writes d_eb[cur^1]: workgroups recompute a 2-cell
+// halo in LDS instead of exchanging it, which is only race-free out of place.
+// Roofline: HBM-bound, 9 reads + 6 writes of 8 B per cell per step (120 B/cell);
+// at the BASELINE sizes (4 K - 33 K cells) it is launch-latency bound and costs
+// < 1 % of a step.
+#include "opal_internal.hpp"
+#include "pic_device.hpp"
+
+#include <cmath>
+#include <cstring>
+
+using namespace opal;
+
+namespace {
+
+constexpr int HALO_CELLS = 2 * GHOST_SIZE;    // yee.rs:353-354
+constexpr int HALO_COMPS = 10;                // rho j[3] E[3] B[3]
+constexpr int HALO_DOUBLES = HALO_CELLS * HALO_COMPS;
+
+// yee.rs:353-354: send_left = cell[0..8], send_right = cell[len-8..len]
+__global__ void k_pack_halo(const double *__restrict__ eb, const double *__restrict__ jr, size_t lenp, int len,
+                            double *__restrict__ send)
+{
+    int t = threadIdx.x;
+    if (t >= 2 * HALO_DOUBLES) return;
+    int side = t / HALO_DOUBLES, r = t % HALO_DOUBLES;
+    int k = r / HALO_COMPS, comp = r % HALO_COMPS;
+    int cellidx = side == 0 ? k : len - HALO_CELLS + k;
+    double v;
+    if (comp == 0) v = jr[3 * lenp + cellidx];                 // rho
+    else if (comp < 4) v = jr[(size_t)(comp - 1) * lenp + cellidx];  // j
+    else v = eb[(size_t)(comp - 4) * lenp + cellidx];          // E, B
+    send[t] = v;
+}
+
+struct SyncArgs {
+    double *eb;
+    double *jr;
+    size_t lenp;
+    int len, L, R;
+    const double *recv_left;   // 80 doubles or null
+    const double *recv_right;
+    int left_bdy, right_bdy;
+    double laser_y, laser_z;   // already 2 r laser(t, x), yee.rs:459-461
+    const double *damp;        // (1 - sigma) for the last R-1 cells of an absorbing layer
+};
+
+// yee.rs:411-495.  One workgroup; the received cells are staged in registers
+// before anything is written, so a self-exchange may alias send and recv.
+__global__ void k_synchronize(SyncArgs a)
+{
+    int t = threadIdx.x;
+    // (i) ghost overlay, yee.rs:424-452 + Cell::overlay_ghost / overlay (:97-113)
+    if (t < 2 * HALO_DOUBLES) {
+        int side = t / HALO_DOUBLES, r = t % HALO_DOUBLES;
+        int k = r / HALO_COMPS, comp = r % HALO_COMPS;
+        const double *recv = side == 0 ? a.recv_left : a.recv_right;
+        if (recv) {
+            double v = recv[r];
+            int cellidx = side == 0 ? k : a.len - HALO_CELLS + k;
+            bool ghost = side == 0 ? (k < GHOST_SIZE) : (k >= GHOST_SIZE);
+            if (comp == 0) a.jr[3 * a.lenp + cellidx] += v;
+            else if (comp < 4) a.jr[(size_t)(comp - 1) * a.lenp + cellidx] += v;
+            else if (ghost) a.eb[(size_t)(comp - 4) * a.lenp + cellidx] = v;
+        }
+    }
+    __syncthreads();
+    // (ii) laser, yee.rs:456-462: one cell, start = left_bdy_size - 2
+    if (a.left_bdy == OPAL_BDY_LASER && t == 0) {
+        int start = a.L - 2;
+        a.eb[1 * a.lenp + start] += a.laser_y;
+        a.eb[2 * a.lenp + start] += a.laser_z;
+    }
+    // (iii) absorbing layer, yee.rs:464-479
+    if (a.right_bdy == OPAL_BDY_ABSORBING) {
+        int first = a.len - a.R + 1;
+        for (int i = first + t; i < a.len; i += blockDim.x) {
+            double f = a.damp[i - first];
+            bool zero = i >= a.len - 2;
+            for (int c = 0; c < 6; c++) {
+                double v = f * a.eb[(size_t)c * a.lenp + i];
+                a.eb[(size_t)c * a.lenp + i] = zero ? 0.0 : v;
+            }
+        }
+    } else if (a.right_bdy == OPAL_BDY_CONDUCTING) {  // yee.rs:480-495
+        int start = a.len - a.R;
+        // every source index is < start + 1 and every destination > start except E[1], E[2], B[0]
+        // at start + 1 which read cell `start` itself: no destination is another lane's source.
+        if (t == 0) {
+            a.eb[0 * a.lenp + start] = 0.0;
+            a.eb[4 * a.lenp + start] = 0.0;
+            a.eb[5 * a.lenp + start] = 0.0;
+        }
+        __syncthreads();
+        if (t >= 1 && t < a.R) {
+            int i = t;
+            a.eb[0 * a.lenp + start + i] = -a.eb[0 * a.lenp + start - i];
+            a.eb[1 * a.lenp + start + i] = a.eb[1 * a.lenp + start + 1 - i];
+            a.eb[2 * a.lenp + start + i] = a.eb[2 * a.lenp + start + 1 - i];
+            a.eb[3 * a.lenp + start + i] = a.eb[3 * a.lenp + start + 1 - i];
+            a.eb[4 * a.lenp + start + i] = -a.eb[4 * a.lenp + start - i];
+            a.eb[5 * a.lenp + start + i] = -a.eb[5 * a.lenp + start - i];
+        }
+    }
+}
+
+constexpr int FT = 256;       // cells written per workgroup
+constexpr int FH = 2;         // halo cells recomputed on each side
+constexpr int FW = FT + 2 * FH;
+
+// YeeGrid::advance, yee.rs:345-349 = advance_B(dt/2) (:839-848), advance_E(dt)
+// (:852-867), advance_B(dt/2), fused.  Each sub-step reads only the other field,
+// so it is order-independent inside the sub-step; a workgroup loads its tile plus
+// a 2-cell halo into LDS, runs the three sub-steps there and writes its tile to
+// the other field buffer.  The array ends follow the reference loops: B is not
+// advanced in the last cell, cell 0 gets the Silver-Mueller update.
+__global__ __launch_bounds__(FT) void k_advance(const double *__restrict__ src, double *__restrict__ dst,
+                                                const double *__restrict__ jr, size_t lenp, int len, double dt,
+                                                double dx)
+{
+    __shared__ double Ex[FW], Ey[FW], Ez[FW], By[FW], Bz[FW];
+    const int t = threadIdx.x;
+    const int s = blockIdx.x * FT;  // first cell written by this workgroup
+    for (int k = t; k < FW; k += FT) {
+        int i = s - FH + k;
+        bool in = i >= 0 && i < len;
+        Ex[k] = in ? src[0 * lenp + i] : 0.0;
+        Ey[k] = in ? src[1 * lenp + i] : 0.0;
+        Ez[k] = in ? src[2 * lenp + i] : 0.0;
+        By[k] = in ? src[4 * lenp + i] : 0.0;
+        Bz[k] = in ? src[5 * lenp + i] : 0.0;
+    }
+    __syncthreads();
+    const double hdt = 0.5 * dt;
+    // B half step on local cells k in [0, FW-1): needs E[k+1]
+    for (int k = t; k < FW - 1; k += FT) {
+        int i = s - FH + k;
+        if (i >= 0 && i < len - 1) {
+            By[k] += hdt * (Ez[k + 1] - Ez[k]) / dx;
+            Bz[k] += hdt * (Ey[k] - Ey[k + 1]) / dx;
+        }
+    }
+    __syncthreads();
+    // E full step on local cells k in [1, FW-1): needs B[k-1] (post half step)
+    for (int k = 1 + t; k < FW - 1; k += FT) {
+        int i = s - FH + k;
+        if (i == 0) {
+            double kappa = 2.0 * SPEED_OF_LIGHT * dt / (SPEED_OF_LIGHT * dt + dx);
+            double sigma = 1.0 - kappa;
+            Ex[k] = 0.0;
+            Ey[k] = sigma * Ey[k] - SPEED_OF_LIGHT * kappa * Bz[k];
+            Ez[k] = sigma * Ez[k] + SPEED_OF_LIGHT * kappa * By[k];
+        } else if (i > 0 && i < len) {
+            double jx = jr[0 * lenp + i], jy = jr[1 * lenp + i], jz = jr[2 * lenp + i];
+            Ex[k] += -dt * jx / VACUUM_PERMITTIVITY;
+            Ey[k] += dt * SPEED_OF_LIGHT_SQD * (Bz[k - 1] - Bz[k]) / dx - dt * jy / VACUUM_PERMITTIVITY;
+            Ez[k] += dt * SPEED_OF_LIGHT_SQD * (By[k] - By[k - 1]) / dx - dt * jz / VACUUM_PERMITTIVITY;
+        }
+    }
+    __syncthreads();
+    // second B half step on the tile proper, then write out
+    {
+        int k = FH + t, i = s + t;
+        if (i < len) {
+            double by = By[k], bz = Bz[k];
+            if (i < len - 1) {
+                by += hdt * (Ez[k + 1] - Ez[k]) / dx;
+                bz += hdt * (Ey[k] - Ey[k + 1]) / dx;
+            }
+            dst[0 * lenp + i] = Ex[k];
+            dst[1 * lenp + i] = Ey[k];
+            dst[2 * lenp + i] = Ez[k];
+            dst[3 * lenp + i] = src[3 * lenp + i];  // Bx: "nothing happens to Bx in 1D" (yee.rs:844)
+            dst[4 * lenp + i] = by;
+            dst[5 * lenp + i] = bz;
+        }
+    }
+}
+
+// yee.rs:787-809, interior cells only; one workgroup, fixed summation tree.
+__global__ void k_field_energy(const double *__restrict__ eb, size_t lenp, int L, int size, double dx,
+                               double *__restrict__ out)
+{
+    __shared__ double se[256], sb[256];
+    int t = threadIdx.x;
+    double e2 = 0.0, b2 = 0.0;
+    for (int i = L + t; i < L + size; i += blockDim.x) {
+        double ex = eb[0 * lenp + i], ey = eb[1 * lenp + i], ez = eb[2 * lenp + i];
+        double bx = eb[3 * lenp + i], by = eb[4 * lenp + i], bz = eb[5 * lenp + i];
+        e2 = e2 + ex * ex + ey * ey + ez * ez;
+        b2 = b2 + bx * bx + by * by + bz * bz;
+    }
+    se[t] = e2;
+    sb[t] = b2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) {
+            se[t] += se[t + w];
+            sb[t] += sb[t + w];
+        }
+        __syncthreads();
+    }
+    if (t == 0) out[0] = 0.5 * (VACUUM_PERMITTIVITY * se[0] + sb[0] / VACUUM_PERMEABILITY) * dx;
+}
+
+struct GlobalFields {
+    const double *eb;
+    size_t lenp;
+    __device__ double operator()(int comp, int j) const { return eb[(size_t)comp * lenp + j]; }
+};
+
+// fields_at (yee.rs:499-529) for a batch of (cell, offset) pairs
+__global__ void k_fields_at(const double *__restrict__ eb, size_t lenp, int L, int size, int n,
+                            const int *__restrict__ c, const double *__restrict__ xi, double *__restrict__ E,
+                            double *__restrict__ B, int *err)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if ((unsigned)c[i] >= (unsigned)size) {  // yee.rs:501-502
+        atomicOr(err, 2);
+        return;
+    }
+    GlobalFields f{eb, lenp};
+    V3 e, b;
+    gather(f, c[i] + L, xi[i], e, b);
+    E[3 * i] = e.x; E[3 * i + 1] = e.y; E[3 * i + 2] = e.z;
+    B[3 * i] = b.x; B[3 * i + 1] = b.y; B[3 * i + 2] = b.z;
+}
+
+int check_grid(const opal_grid_t *g)
+{
+    if (!g) {
+        set_error("null grid handle");
+        return OPAL_ERR_ARG;
+    }
+    return OPAL_OK;
+}
+
+}  // namespace
+
+namespace opal {
+// used by particles.hip and link.cpp
+int grid_pack_halo(opal_grid_t *g)
+{
+    k_pack_halo<<<1, 192, 0, g->stream>>>(g->d_eb[g->cur], g->d_j, g->lenp, (int)g->len, g->d_send);
+    OPAL_HIP(hipGetLastError());
+    return OPAL_OK;
+}
+
+int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz)
+{
+    SyncArgs a;
+    a.eb = g->d_eb[g->cur];
+    a.jr = g->d_j;
+    a.lenp = g->lenp;
+    a.len = (int)g->len;
+    a.L = g->L;
+    a.R = g->R;
+    a.recv_left = g->left_bdy == OPAL_BDY_INTERNAL ? recv_left : nullptr;
+    a.recv_right = g->right_bdy == OPAL_BDY_INTERNAL ? recv_right : nullptr;
+    a.left_bdy = g->left_bdy;
+    a.right_bdy = g->right_bdy;
+    a.laser_y = ly;
+    a.laser_z = lz;
+    a.damp = g->d_damp;
+    k_synchronize<<<1, 256, 0, g->stream>>>(a);
+    OPAL_HIP(hipGetLastError());
+    return OPAL_OK;
+}
+
+int grid_check_err(const opal_grid_t *g)
+{
+    int err = 0;
+    OPAL_HIP(hipMemcpyAsync(&err, g->d_err, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    OPAL_HIP(hipStreamSynchronize(g->stream));
+    if (err) {
+        set_error("grid invariant violated on device (flags 0x%x): fields_at index out of range (yee.rs:501-502)", err);
+        return OPAL_ERR_ASSERT;
+    }
+    return OPAL_OK;
+}
+}  // namespace opal
+
+extern "C" {
+
+size_t opal_grid_min_size(void) { return (size_t)(2 * GHOST_SIZE); }
+
+int opal_grid_build(opal_grid_t **out, int id, int numtasks, int left, int right, double xmin, double dx,
+                    const size_t *nx, const double *offset, void *hip_stream)
+{
+    if (!out || !nx || !offset || numtasks < 1 || id < 0 || id >= numtasks) {
+        set_error("opal_grid_build: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    if (nx[id] < opal_grid_min_size() || nx[id] > (size_t)1 << 28) {
+        set_error("opal_grid_build: subdomain of %zu cells (min %zu)", nx[id], opal_grid_min_size());
+        return OPAL_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("opal_grid_build: no HIP device available (the HIP path has no CPU fallback)");
+        return OPAL_ERR_HIP;
+    }
+    opal_grid_t *g = new opal_grid_t();
+    // yee.rs:278-292
+    if (id == 0 && left == OPAL_BDY_LASER) { g->left_bdy = OPAL_BDY_LASER; g->L = LASER_BDY_SIZE; }
+    else { g->left_bdy = OPAL_BDY_INTERNAL; g->L = GHOST_SIZE; }
+    if (id == numtasks - 1 && right == OPAL_BDY_ABSORBING) { g->right_bdy = OPAL_BDY_ABSORBING; g->R = ABSORBING_BDY_SIZE; }
+    else if (id == numtasks - 1 && right == OPAL_BDY_CONDUCTING) { g->right_bdy = OPAL_BDY_CONDUCTING; g->R = CONDUCTING_BDY_SIZE; }
+    else { g->right_bdy = OPAL_BDY_INTERNAL; g->R = GHOST_SIZE; }
+    g->id = id;
+    g->ngrids = numtasks;
+    g->rank_to_left = (id - 1 + numtasks) % numtasks;
+    g->rank_to_right = (id + 1) % numtasks;
+    g->size = nx[id];
+    g->dx = dx;
+    g->xmin_global = xmin;
+    g->offset = offset[id];
+    g->len = g->size + (size_t)g->L + (size_t)g->R;
+    g->lenp = (g->len + 63) / 64 * 64;
+    g->stream = (hipStream_t)hip_stream;
+    g->cur = 0;
+    g->d_damp = nullptr;
+    size_t nb = sizeof(double) * g->lenp;
+    OPAL_HIP(hipMalloc(&g->d_eb[0], 6 * nb));
+    OPAL_HIP(hipMalloc(&g->d_eb[1], 6 * nb));
+    OPAL_HIP(hipMalloc(&g->d_j, 4 * nb));
+    OPAL_HIP(hipMalloc(&g->d_send, sizeof(double) * 2 * HALO_DOUBLES));
+    OPAL_HIP(hipMalloc(&g->d_scalar, sizeof(double) * 8));
+    OPAL_HIP(hipMalloc(&g->d_err, sizeof(int)));
+    OPAL_HIP(hipHostMalloc(&g->h_pin, sizeof(double) * 11 * g->lenp));
+    OPAL_HIP(hipMemsetAsync(g->d_eb[0], 0, 6 * nb, g->stream));
+    OPAL_HIP(hipMemsetAsync(g->d_eb[1], 0, 6 * nb, g->stream));
+    OPAL_HIP(hipMemsetAsync(g->d_j, 0, 4 * nb, g->stream));
+    OPAL_HIP(hipMemsetAsync(g->d_err, 0, sizeof(int), g->stream));
+    if (g->right_bdy == OPAL_BDY_ABSORBING) {
+        // yee.rs:465-468, evaluated once on the host with the reference's arithmetic
+        double xmin_b = g->cell_x(g->size + (size_t)g->L);
+        double xmax_b = g->cell_x(g->size + (size_t)g->L + (size_t)g->R - 1);
+        double sigma_max = 10.0 / ((double)g->R);
+        g->damp_host.resize((size_t)g->R - 1);
+        for (size_t i = g->len - (size_t)g->R + 1, k = 0; i < g->len; i++, k++) {
+            double sigma = sigma_max * (g->cell_x(i) - xmin_b) / (xmax_b - xmin_b);
+            g->damp_host[k] = 1.0 - sigma;
+        }
+        OPAL_HIP(hipMalloc(&g->d_damp, sizeof(double) * g->damp_host.size()));
+        OPAL_HIP(hipMemcpyAsync(g->d_damp, g->damp_host.data(), sizeof(double) * g->damp_host.size(),
+                                hipMemcpyHostToDevice, g->stream));
+    }
+    OPAL_HIP(hipStreamSynchronize(g->stream));
+    *out = g;
+    return OPAL_OK;
+}
+
+int opal_grid_free(opal_grid_t *g)
+{
+    if (!g) return OPAL_OK;
+    hipFree(g->d_eb[0]);
+    hipFree(g->d_eb[1]);
+    hipFree(g->d_j);
+    hipFree(g->d_send);
+    hipFree(g->d_scalar);
+    hipFree(g->d_err);
+    if (g->d_damp) hipFree(g->d_damp);
+    hipHostFree(g->h_pin);
+    delete g;
+    return OPAL_OK;
+}
+
+int opal_grid_rank(const opal_grid_t *g) { return g ? g->id : -1; }
+int opal_grid_ngrids(const opal_grid_t *g) { return g ? g->ngrids : 0; }
+int opal_grid_to_left(const opal_grid_t *g) { return g && g->left_bdy == OPAL_BDY_INTERNAL ? g->rank_to_left : -1; }
+int opal_grid_to_right(const opal_grid_t *g) { return g && g->right_bdy == OPAL_BDY_INTERNAL ? g->rank_to_right : -1; }
+double opal_grid_xmin(const opal_grid_t *g) { return g ? g->cell_x((size_t)g->L) : 0.0; }
+double opal_grid_dx(const opal_grid_t *g) { return g ? g->dx : 0.0; }
+size_t opal_grid_size(const opal_grid_t *g) { return g ? g->size : 0; }
+size_t opal_grid_len(const opal_grid_t *g) { return g ? g->len : 0; }
+size_t opal_grid_left_bdy_size(const opal_grid_t *g) { return g ? (size_t)g->L : 0; }
+size_t opal_grid_right_bdy_size(const opal_grid_t *g) { return g ? (size_t)g->R : 0; }
+
+int opal_grid_clear(opal_grid_t *g)
+{
+    if (int rc = check_grid(g)) return rc;
+    OPAL_HIP(hipMemsetAsync(g->d_j, 0, sizeof(double) * 4 * g->lenp, g->stream));
+    return OPAL_OK;
+}
+
+int opal_grid_advance(opal_grid_t *g, double dt)
+{
+    if (int rc = check_grid(g)) return rc;
+    int nblk = (int)((g->len + FT - 1) / FT);
+    prof_begin(KERNEL_FIELD, g->stream);
+    k_advance<<<nblk, FT, 0, g->stream>>>(g->d_eb[g->cur], g->d_eb[g->cur ^ 1], g->d_j, g->lenp, (int)g->len, dt, g->dx);
+    prof_end(KERNEL_FIELD, g->stream);
+    OPAL_HIP(hipGetLastError());
+    g->cur ^= 1;
+    return OPAL_OK;
+}
+
+int opal_grid_fields_at(const opal_grid_t *g, size_t n, const int32_t *c, const double *xi, double *E, double *B)
+{
+    if (int rc = check_grid(g)) return rc;
+    if (n == 0) return OPAL_OK;
+    int *dc;
+    double *dxi, *dE, *dB;
+    OPAL_HIP(hipMalloc(&dc, n * sizeof(int)));
+    OPAL_HIP(hipMalloc(&dxi, n * sizeof(double)));
+    OPAL_HIP(hipMalloc(&dE, 3 * n * sizeof(double)));
+    OPAL_HIP(hipMalloc(&dB, 3 * n * sizeof(double)));
+    OPAL_HIP(hipMemcpyAsync(dc, c, n * sizeof(int), hipMemcpyHostToDevice, g->stream));
+    OPAL_HIP(hipMemcpyAsync(dxi, xi, n * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    k_fields_at<<<(unsigned)((n + 255) / 256), 256, 0, g->stream>>>(g->d_eb[g->cur], g->lenp, g->L, (int)g->size, (int)n,
+                                                                   dc, dxi, dE, dB, g->d_err);
+    OPAL_HIP(hipGetLastError());
+    OPAL_HIP(hipMemcpyAsync(E, dE, 3 * n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    OPAL_HIP(hipMemcpyAsync(B, dB, 3 * n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    int rc = grid_check_err(g);
+    hipFree(dc); hipFree(dxi); hipFree(dE); hipFree(dB);
+    if (rc) OPAL_HIP(hipMemsetAsync(g->d_err, 0, sizeof(int), g->stream));
+    return rc;
+}
+
+int opal_grid_em_field_energy(const opal_grid_t *g, double *energy)
+{
+    if (int rc = check_grid(g)) return rc;
+    k_field_energy<<<1, 256, 0, g->stream>>>(g->d_eb[g->cur], g->lenp, g->L, (int)g->size, g->dx, g->d_scalar);
+    OPAL_HIP(hipGetLastError());
+    OPAL_HIP(hipMemcpyAsync(energy, g->d_scalar, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    OPAL_HIP(hipStreamSynchronize(g->stream));
+    return OPAL_OK;
+}
+
+static int grid_fetch(const opal_grid_t *g)
+{
+    // h_pin rows: 0 rho? keep opal_comp order 1..10 (x is computed)
+    double *h = g->h_pin;
+    size_t nb = sizeof(double) * g->lenp;
+    OPAL_HIP(hipMemcpyAsync(h + 1 * g->lenp, g->d_j + 3 * g->lenp, nb, hipMemcpyDeviceToHost, g->stream));       // rho
+    OPAL_HIP(hipMemcpyAsync(h + 2 * g->lenp, g->d_j, 3 * nb, hipMemcpyDeviceToHost, g->stream));                  // jx jy jz
+    OPAL_HIP(hipMemcpyAsync(h + 5 * g->lenp, g->d_eb[g->cur], 6 * nb, hipMemcpyDeviceToHost, g->stream));         // E, B
+    OPAL_HIP(hipStreamSynchronize(g->stream));
+    for (size_t i = 0; i < g->len; i++) h[i] = g->cell_x(i);
+    return OPAL_OK;
+}
+
+int opal_grid_get_raw(const opal_grid_t *g, int comp, double *out)
+{
+    if (int rc = check_grid(g)) return rc;
+    if (comp < 0 || comp > 10 || !out) {
+        set_error("opal_grid_get_raw: bad component %d", comp);
+        return OPAL_ERR_ARG;
+    }
+    if (comp == OPAL_X) {
+        for (size_t i = 0; i < g->len; i++) out[i] = g->cell_x(i);
+        return OPAL_OK;
+    }
+    const double *src = comp == OPAL_RHO ? g->d_j + 3 * g->lenp
+                        : comp <= OPAL_JZ ? g->d_j + (size_t)(comp - OPAL_JX) * g->lenp
+                                          : g->d_eb[g->cur] + (size_t)(comp - OPAL_EX) * g->lenp;
+    OPAL_HIP(hipMemcpyAsync(out, src, sizeof(double) * g->len, hipMemcpyDeviceToHost, g->stream));
+    OPAL_HIP(hipStreamSynchronize(g->stream));
+    return OPAL_OK;
+}
+
+int opal_grid_set_raw(opal_grid_t *g, int comp, const double *in)
+{
+    if (int rc = check_grid(g)) return rc;
+    if (comp < 1 || comp > 10 || !in) {
+        set_error("opal_grid_set_raw: bad component %d", comp);
+        return OPAL_ERR_ARG;
+    }
+    double *dst = comp == OPAL_RHO ? g->d_j + 3 * g->lenp
+                  : comp <= OPAL_JZ ? g->d_j + (size_t)(comp - OPAL_JX) * g->lenp
+                                    : g->d_eb[g->cur] + (size_t)(comp - OPAL_EX) * g->lenp;
+    OPAL_HIP(hipMemcpyAsync(dst, in, sizeof(double) * g->len, hipMemcpyHostToDevice, g->stream));
+    OPAL_HIP(hipStreamSynchronize(g->stream));
+    return OPAL_OK;
+}
+
+int opal_grid_interpolate(const opal_grid_t *g, double *out)
+{
+    if (int rc = check_grid(g)) return rc;
+    if (int rc = grid_fetch(g)) return rc;
+    const double *h = g->h_pin;
+    size_t P = g->lenp;
+    auto at = [&](int comp, size_t i) { return h[(size_t)comp * P + i]; };
+    size_t lo = (size_t)g->L - 1;
+    for (size_t k = 0; k < g->size; k++) {  // yee.rs:821-832
+        size_t a = lo + k, b = lo + k + 1;
+        double *o = out + 11 * k;
+        o[0] = at(OPAL_X, b);
+        o[1] = at(OPAL_RHO, b);
+        o[2] = 0.5 * (at(OPAL_JX, a) + at(OPAL_JX, b));
+        o[3] = at(OPAL_JY, b);
+        o[4] = at(OPAL_JZ, b);
+        o[5] = 0.5 * (at(OPAL_EX, a) + at(OPAL_EX, b));
+        o[6] = at(OPAL_EY, b);
+        o[7] = at(OPAL_EZ, b);
+        o[8] = at(OPAL_BX, b);
+        o[9] = 0.5 * (at(OPAL_BY, a) + at(OPAL_BY, b));
+        o[10] = 0.5 * (at(OPAL_BZ, a) + at(OPAL_BZ, b));
+    }
+    return OPAL_OK;
+}
+
+int opal_grid_synchronize(opal_grid_t *g, opal_link_t *link, opal_fn2 laser_y, opal_fn2 laser_z, void *user,
+                          double t, double dt)
+{
+    if (int rc = check_grid(g)) return rc;
+    double ly = 0.0, lz = 0.0;
+    if (g->left_bdy == OPAL_BDY_LASER) {  // yee.rs:456-462
+        if (!laser_y || !laser_z) {
+            set_error("opal_grid_synchronize: laser boundary needs laser_y and laser_z");
+            return OPAL_ERR_ARG;
+        }
+        double x = g->cell_x((size_t)(g->L - 2));
+        double r = SPEED_OF_LIGHT * dt / g->dx;
+        ly = 2.0 * r * laser_y(t, x, user);
+        lz = 2.0 * r * laser_z(t, x, user);
+    }
+    bool need_halo = g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL;
+    if (need_halo) {
+        if (int rc = grid_pack_halo(g)) return rc;
+    }
+    const double *recv_left = nullptr, *recv_right = nullptr;
+    if (g->ngrids == 1) {
+        // yee.rs:365-370, 390-395: a lone periodic subdomain receives its own sends
+        recv_left = g->d_send + HALO_DOUBLES;  // what it sent right
+        recv_right = g->d_send;                // what it sent left
+    } else {
+        extern int opal_link_exchange_halo(opal_link_t *, opal_grid_t *, const double **, const double **);
+        if (!link) {
+            set_error("opal_grid_synchronize: %d subdomains need a link", g->ngrids);
+            return OPAL_ERR_ARG;
+        }
+        if (int rc = opal_link_exchange_halo(link, g, &recv_left, &recv_right)) return rc;
+    }
+    return grid_apply_sync(g, recv_left, recv_right, ly, lz);
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// Host-side set-up shared by the C ABI and the YAML driver.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <vector>
+
+namespace opal {
+
+struct Rng {
+    uint64_t s[4];
+    void seed(uint64_t sd);
+    uint64_t next();
+    double uniform();
+    double normal();
+    double exp1();
+};
+
+using Fn3 = std::function<double(double, double, double)>;
+
+struct HostSoA {
+    std::vector<int32_t> cell;
+    std::vector<double> x, ux, uy, uz, w;
+    size_t size() const { return cell.size(); }
+};
+
+int design_unbalanced(int numtasks, size_t size, double dx, size_t min_subsize, size_t *nx, double *offset);
+int design_balanced(int numtasks, size_t size, double xmin, double dx, size_t min_subsize,
+                    const std::function<double(double)> &ne, size_t *nx, double *offset);
+void load_population(int species, size_t npc, const std::function<double(double)> &number_density, const Fn3 &ux,
+                     const Fn3 &uy, const Fn3 &uz, double grid_xmin, double dx, size_t ncells, Rng &rng,
+                     HostSoA &out);
+
+}  // namespace opal

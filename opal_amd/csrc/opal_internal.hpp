@@ -1,0 +1,86 @@
+// Internal host-side definitions shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/opal_amd.h"
+
+namespace opal {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define OPAL_HIP(call)                                          \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return opal::hip_fail(e_, #call); \
+    } while (0)
+
+// Device-resident counters of a population (one 64-byte record).
+struct PopCounters {
+    unsigned int n_slots;      // slots in use (live + dead), device truth
+    unsigned int n_deleted;    // particles removed at open edges since last reset
+    unsigned int n_sent_left;  // leavers packed for the left / right neighbour (this exchange)
+    unsigned int n_sent_right;
+    unsigned int n_slow;       // deposits/gathers that missed the LDS tile since last sort
+    int err;                   // bit 0: dxi >= 1; bit 1: gather index; bit 2: deposit index; bit 3: leaver overflow
+    unsigned int n_live;       // written by sort / count kernels
+    unsigned int n_nonempty;   // non-empty cells at last sort
+    unsigned int pad[8];
+};
+
+enum { KERNEL_FUSED = 0, KERNEL_ADVANCE = 1, KERNEL_DEPOSIT = 2, KERNEL_FIELD = 3, KERNEL_SORT = 4, KERNEL_COUNT = 5 };
+void prof_begin(int kernel, hipStream_t s);
+void prof_end(int kernel, hipStream_t s);
+
+}  // namespace opal
+
+struct opal_grid {
+    int id, ngrids, rank_to_left, rank_to_right;
+    int left_bdy, right_bdy;
+    int L, R;  // left / right boundary sizes (cells)
+    size_t size, len, lenp;
+    double dx, xmin_global, offset;
+    hipStream_t stream;
+    double *d_eb[2];  // ping-pong field buffers, 6 components x lenp
+    double *d_j;      // jx jy jz rho, 4 x lenp
+    int cur;
+    double *d_send;   // 2 x 80 doubles: what synchronize sends left / right
+    double *d_damp;   // absorbing layer factors (1 - sigma), R entries (or null)
+    double *d_scalar; // scratch for reductions
+    int *d_err;
+    double *h_pin;    // pinned host scratch (>= 11 * len doubles)
+    std::vector<double> damp_host;
+    double cell_x(size_t c) const { return xmin_global + offset + (((double)c) - ((double)L)) * dx; }  // yee.rs:296
+};
+
+struct opal_pop {
+    int species;
+    size_t cap;
+    size_t n_upper;  // host upper bound on slots in use
+    hipStream_t stream;
+    int *d_cell[2];
+    double *d_x[2], *d_ux[2], *d_uy[2], *d_uz[2], *d_w[2];
+    bool have_alt;
+    int cur;
+    double *d_prev_x;               // allocated on first unfused advance
+    bool prev_valid;
+    double *d_chi, *d_work, *d_y, *d_z;  // electron extras (optional)
+    bool extras;
+    double z_star, z, a;
+    opal::PopCounters *d_ctr;
+    opal::PopCounters *h_ctr;  // pinned
+    int sort_interval;         // 0 never, >0 fixed, <0 adaptive
+    int steps_since_sort;
+    int ppt;                   // particles per thread in the push kernels
+    unsigned int *d_count;     // sort scratch: ncells + 2
+    size_t count_cap;
+    double *d_partial;
+    size_t partial_cap;
+    double dx_last;
+};

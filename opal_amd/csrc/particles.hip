@@ -1,0 +1,924 @@
+// Population<Electron|Ion> on the GPU.
+//
+// HBM layout: structure of arrays, one contiguous array per attribute
+//   cell:i32  x  ux  uy  uz  w : f64          (44 B per macro-particle)
+// so that a wavefront's 64 lanes read/write 256- or 512-byte contiguous runs.
+// gamma and prev_x are recomputed in registers, never stored, on the fused
+// path; prev_x is materialised only for the reference's separate
+// advance -> deposit operator sequence.  A second copy of the arrays exists
+// only while re-binning (counting sort by cell).
+//
+// The hot kernel (k_push<...,FUSED>) is one pass per particle per step:
+//   read 44 B, gather E,B from an LDS copy of the field tile, Vay/Boris push,
+//   charge-conserving deposit into LDS accumulators (32 lane-private replicas
+//   per (cell, component) so that ds_add_f64 never serialises on an address),
+//   write 36 B; one global f64 atomic per touched (cell, component) per
+//   workgroup at the end.  Algorithmic traffic 80 B per particle-update; the
+//   bound is HBM (8 TB/s -> 1.0e11 updates/s), with f64 VALU issue close
+//   behind (about 4-6 flop/B).
+#include "opal_internal.hpp"
+#include "pic_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace opal;
+
+namespace opal {
+int grid_check_err(const opal_grid_t *g);
+}
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int TILE = 16;        // cells in a workgroup's LDS tile
+constexpr int REPL = 32;        // lane-private replicas per accumulator
+constexpr int TILE_LO = 3;      // a particle whose old cell sits at tile offset in [TILE_LO, TILE - 4]
+constexpr int TILE_HI = TILE - 4;  // gathers (rel-1..rel+2) and deposits (rel-3..rel+3) inside the tile
+
+enum { MODE_ADVANCE = 0, MODE_FUSED = 1, MODE_DEPOSIT = 2 };
+enum { EDGE_WRAP = 0, EDGE_DELETE = 1, EDGE_SEND = 2 };
+
+struct PushArgs {
+    int *cell;
+    double *x, *ux, *uy, *uz;
+    const double *w;
+    double *prev_x;
+    double *chi, *work, *y, *z;
+    const double *eb;  // 6 x lenp
+    double *jr;        // 4 x lenp
+    size_t lenp;
+    int ppt;
+    int size, L, len;
+    double dt, dt_over_dx, inv_dt, inv_dx, alpha, charge;
+    int left_mode, right_mode;
+    PopCounters *ctr;
+    // leaver buffers (EDGE_SEND): SoA blocks of `send_cap` particles
+    int *send_cell[2];
+    double *send_f[2];  // x ux uy uz w, 5 x send_cap
+    unsigned send_cap;
+};
+
+struct LdsFields {
+    const double *f;  // [6][TILE]
+    __device__ double operator()(int comp, int j) const { return f[comp * TILE + j]; }
+};
+struct GlobalFields {
+    const double *eb;
+    size_t lenp;
+    __device__ double operator()(int comp, int j) const { return eb[(size_t)comp * lenp + j]; }
+};
+
+__device__ inline void lds_add(double *p, double v)
+{
+    if (v != 0.0) atomicAdd(p, v);  // ds_add_f64
+}
+__device__ inline void glb_add(double *p, double v)
+{
+    if (v != 0.0) atomicAdd(p, v);  // global_atomic_add_f64
+}
+
+template <bool RHO>
+__device__ inline void scatter_lds(double *acc, int rel, int lane, const Taps &t)
+{
+    // acc[comp][cell][replica]
+    double *a = acc + lane;
+#pragma unroll
+    for (int k = 0; k < 5; k++) lds_add(a + ((0 * TILE + rel + k - 2) * REPL), t.jx[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) lds_add(a + ((1 * TILE + rel + k - 1) * REPL), t.jy[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) lds_add(a + ((2 * TILE + rel + k - 1) * REPL), t.jz[k]);
+    if (RHO) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) lds_add(a + ((3 * TILE + rel + k - 2) * REPL), t.rho[k]);
+    }
+}
+
+template <bool RHO>
+__device__ inline void scatter_global(double *jr, size_t lenp, int idx, const Taps &t)
+{
+#pragma unroll
+    for (int k = 0; k < 5; k++) glb_add(jr + 0 * lenp + idx + k - 2, t.jx[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) glb_add(jr + 1 * lenp + idx + k - 1, t.jy[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) glb_add(jr + 2 * lenp + idx + k - 1, t.jz[k]);
+    if (RHO) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) glb_add(jr + 3 * lenp + idx + k - 2, t.rho[k]);
+    }
+}
+
+// One workgroup = BLOCK x ppt consecutive particle slots.
+//   MODE_ADVANCE : Population::advance's per-particle body, mod.rs:268-279 (gather, push, leaver
+//                  detection); stores prev_x for a later deposit.
+//   MODE_DEPOSIT : YeeGrid::deposit's per-particle body, yee.rs:573-610.
+//   MODE_FUSED   : both in one pass (prev_x stays in registers).
+template <int SPECIES, int MODE, bool RHO, bool EXTRAS>
+__global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
+{
+    constexpr bool GATHER = MODE != MODE_DEPOSIT;
+    constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
+    __shared__ double s_field[GATHER ? 6 * TILE : 1];
+    __shared__ double s_acc[DEPOSIT ? 4 * TILE * REPL : 1];
+    __shared__ int s_min[BLOCK / 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (REPL - 1);
+    const unsigned n = a.ctr->n_slots;
+    const size_t chunk0 = (size_t)blockIdx.x * BLOCK * a.ppt;
+    if (chunk0 >= n) return;
+
+    // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin
+    {
+        size_t i = chunk0 + tid;
+        int c = i < n ? a.cell[i] : DEAD_CELL;
+        int m = c == DEAD_CELL ? 0x7fffffff : c;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) s_min[tid >> 6] = m;
+    }
+    if (DEPOSIT)
+        for (int k = tid; k < 4 * TILE * REPL; k += BLOCK) s_acc[k] = 0.0;
+    __syncthreads();
+    int cmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+    const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - 4;  // array index of tile cell 0
+    if (GATHER) {
+        for (int k = tid; k < 6 * TILE; k += BLOCK) {
+            int comp = k / TILE, j = base + (k % TILE);
+            s_field[k] = (j >= 0 && j < a.len) ? a.eb[(size_t)comp * a.lenp + j] : 0.0;
+        }
+        __syncthreads();
+    }
+
+    unsigned slow = 0;
+    int err = 0;
+    for (int p = 0; p < a.ppt; p++) {
+        size_t i = chunk0 + (size_t)p * BLOCK + tid;
+        if (i >= n) break;
+        int c = a.cell[i];
+        if (c == DEAD_CELL) continue;
+        double xi = a.x[i];
+        V3 u = {a.ux[i], a.uy[i], a.uz[i]};
+        double wt = a.w[i];
+
+        int newc = c, rel, idx;
+        double xn = xi, prev = 0.0, gam;
+        bool in_tile;
+        if (GATHER) {
+            if ((unsigned)c >= (unsigned)a.size) {  // yee.rs:501-502
+                err |= 2;
+                continue;
+            }
+            rel = c + a.L - base;
+            in_tile = rel >= TILE_LO && rel <= TILE_HI;
+            V3 E, B;
+            if (in_tile) {
+                LdsFields f{s_field};
+                gather(f, rel, xi, E, B);
+            } else {
+                GlobalFields f{a.eb, a.lenp};
+                gather(f, c + a.L, xi, E, B);
+                slow++;
+            }
+            Pushed r;
+            if (SPECIES == OPAL_ELECTRON) {
+                double gamma_old = sqrt(1.0 + dot(u, u));
+                r = vay_push<EXTRAS>(u, gamma_old, E, B, a.alpha, a.dt_over_dx, a.dt);
+                if (EXTRAS) {
+                    a.chi[i] = r.chi;
+                    a.work[i] += r.dwork;
+                    a.y[i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
+                    a.z[i] += r.v_old.z * a.dt;
+                }
+            } else {
+                r = boris_push(u, E, B, a.alpha, a.dt_over_dx);
+            }
+            if (!(r.dxi < 1.0)) err |= 1;  // electron.rs:313, ion.rs:199
+            u = r.u;
+            gam = r.gamma;
+            // electron.rs:311-329 / ion.rs:197-213
+            xn = xi + r.dxi;
+            double fl = floor(xn);
+            int s = fl < 0.0 ? -1 : (fl > 0.0 ? 1 : 0);
+            prev = xi - fl;
+            xn = xn - fl;
+            newc = c + s;
+            idx = c + a.L + s;
+            rel = rel + s;
+        } else {
+            prev = a.prev_x[i];
+            gam = sqrt(1.0 + dot(u, u));  // electron.rs:148-151 uses the stored gamma; ion.rs:123-126: 1 + gamma_m1
+            if (SPECIES == OPAL_ION) gam = 1.0 + dot(u, u) / (1.0 + gam);
+            idx = c + a.L;
+            rel = idx - base;
+            in_tile = rel >= 2 && rel <= TILE - 3;
+            if (idx < 2 || idx >= a.len - 2) {  // yee.rs:578-579
+                err |= 4;
+                continue;
+            }
+        }
+
+        // leavers: mod.rs:273-278, 291-293, 308-354; yee.rs:329-343
+        bool deleted = false;
+        int send_side = -1;
+        if (GATHER) {
+            if (newc < 0) {
+                if (a.left_mode == EDGE_WRAP) newc += a.size;
+                else if (a.left_mode == EDGE_DELETE) deleted = true;
+                else send_side = 0;
+            } else if (newc >= a.size) {
+                if (a.right_mode == EDGE_WRAP) newc -= a.size;
+                else if (a.right_mode == EDGE_DELETE) deleted = true;
+                else { send_side = 1; newc -= a.size; }  // mod.rs:291-293
+            }
+        }
+
+        if (DEPOSIT && !deleted) {
+            double macrocharge = wt * a.charge;
+            double inv_g = 1.0 / gam;
+            double vy = SPEED_OF_LIGHT * u.y * inv_g, vz = SPEED_OF_LIGHT * u.z * inv_g;
+            Taps t = deposit_taps<RHO>(xn, prev, macrocharge, vy, vz, a.inv_dt, a.inv_dx);
+            if (in_tile) {
+                scatter_lds<RHO>(s_acc, rel, lane, t);
+            } else {
+                scatter_global<RHO>(a.jr, a.lenp, idx, t);
+                if (!GATHER) slow++;
+            }
+        }
+
+        if (GATHER) {
+            if (deleted) {
+                a.cell[i] = DEAD_CELL;
+                atomicAdd(&a.ctr->n_deleted, 1u);
+            } else if (send_side >= 0) {
+                unsigned slot = atomicAdd(send_side == 0 ? &a.ctr->n_sent_left : &a.ctr->n_sent_right, 1u);
+                if (slot < a.send_cap) {
+                    a.send_cell[send_side][slot] = newc;
+                    double *f = a.send_f[send_side];
+                    f[0 * (size_t)a.send_cap + slot] = xn;
+                    f[1 * (size_t)a.send_cap + slot] = u.x;
+                    f[2 * (size_t)a.send_cap + slot] = u.y;
+                    f[3 * (size_t)a.send_cap + slot] = u.z;
+                    f[4 * (size_t)a.send_cap + slot] = wt;
+                    if (MODE == MODE_ADVANCE) f[5 * (size_t)a.send_cap + slot] = prev;
+                } else {
+                    err |= 8;
+                }
+                a.cell[i] = DEAD_CELL;
+            } else {
+                a.cell[i] = newc;
+                a.x[i] = xn;
+                a.ux[i] = u.x;
+                a.uy[i] = u.y;
+                a.uz[i] = u.z;
+                if (MODE == MODE_ADVANCE) a.prev_x[i] = prev;
+            }
+        }
+    }
+    if (slow) atomicAdd(&a.ctr->n_slow, slow);
+    if (err) atomicOr(&a.ctr->err, err);
+
+    if (DEPOSIT) {
+        __syncthreads();
+        // fold the REPL replicas of each (component, cell) and add to the grid: one lane per accumulator,
+        // rotated start so that the 64 lanes of a wave read 64 different banks.
+        constexpr int NACC = (RHO ? 4 : 3) * TILE;
+        for (int k = tid; k < NACC; k += BLOCK) {
+            double s = 0.0;
+            const double *row = s_acc + k * REPL;
+#pragma unroll 8
+            for (int r = 0; r < REPL; r++) s += row[(r + tid) & (REPL - 1)];
+            int comp = k / TILE, j = base + (k % TILE);
+            if (s != 0.0 && j >= 0 && j < a.len) atomicAdd(a.jr + (size_t)comp * a.lenp + j, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ re-binning
+__global__ void k_sort_hist(const int *__restrict__ cell, const PopCounters *ctr, unsigned *__restrict__ count)
+{
+    unsigned n = ctr->n_slots;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int c = cell[i];
+        if (c != DEAD_CELL) atomicAdd(&count[c], 1u);
+    }
+}
+
+// exclusive scan of count[0..ncells) in place, one workgroup; also the live total and non-empty cell count
+__global__ void k_sort_scan(unsigned *count, int ncells, PopCounters *ctr)
+{
+    __shared__ unsigned s_sum[1024];
+    __shared__ unsigned s_ne[1024];
+    int t = threadIdx.x, nt = blockDim.x;
+    int per = (ncells + nt - 1) / nt;
+    int lo = t * per, hi = min(lo + per, ncells);
+    unsigned sum = 0, ne = 0;
+    for (int i = lo; i < hi; i++) {
+        sum += count[i];
+        ne += count[i] != 0;
+    }
+    s_sum[t] = sum;
+    s_ne[t] = ne;
+    __syncthreads();
+    if (t == 0) {
+        unsigned run = 0, rne = 0;
+        for (int k = 0; k < nt; k++) {
+            unsigned v = s_sum[k];
+            s_sum[k] = run;
+            run += v;
+            rne += s_ne[k];
+        }
+        ctr->n_live = run;
+        ctr->n_nonempty = rne;
+    }
+    __syncthreads();
+    unsigned run = s_sum[t];
+    for (int i = lo; i < hi; i++) {
+        unsigned v = count[i];
+        count[i] = run;
+        run += v;
+    }
+}
+
+struct SortArgs {
+    const int *cell;
+    const double *f[5];
+    int *ocell;
+    double *of[5];
+    const double *prev;
+    double *oprev;
+};
+
+__global__ void k_sort_scatter(SortArgs a, const PopCounters *ctr, unsigned *__restrict__ cursor)
+{
+    unsigned n = ctr->n_slots;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int c = a.cell[i];
+        if (c == DEAD_CELL) continue;
+        unsigned d = atomicAdd(&cursor[c], 1u);
+        a.ocell[d] = c;
+#pragma unroll
+        for (int k = 0; k < 5; k++) a.of[k][d] = a.f[k][i];
+        if (a.prev) a.oprev[d] = a.prev[i];
+    }
+}
+
+__global__ void k_sort_finish(PopCounters *ctr)
+{
+    ctr->n_slots = ctr->n_live;
+    ctr->n_slow = 0;
+}
+
+// ------------------------------------------------------------- kinetic energy
+// electron.rs:122-126 / ion.rs:128-134; per-workgroup partial sums in a fixed tree, then one
+// workgroup folds the partials: the result does not depend on scheduling.
+template <int SPECIES>
+__global__ void k_kinetic(const int *__restrict__ cell, const double *__restrict__ ux, const double *__restrict__ uy,
+                          const double *__restrict__ uz, const double *__restrict__ w, const PopCounters *ctr,
+                          double a_mass, double *__restrict__ partial)
+{
+    __shared__ double s[BLOCK];
+    unsigned n = ctr->n_slots;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        if (cell[i] == DEAD_CELL) continue;
+        double u2 = ux[i] * ux[i] + uy[i] * uy[i] + uz[i] * uz[i];
+        double g = sqrt(1.0 + u2);
+        if (SPECIES == OPAL_ELECTRON) {
+            double to_joules = 1.0e6 * ELECTRON_MASS_MEV * ELEMENTARY_CHARGE;
+            acc += w[i] * u2 * to_joules / (g + 1.0);
+        } else {
+            double gamma_m1 = u2 / (1.0 + g);
+            double energy = gamma_m1 * (a_mass * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV;
+            acc += w[i] * energy * 1.0e6 * ELEMENTARY_CHARGE;
+        }
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = BLOCK / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+__global__ void k_fold(const double *__restrict__ partial, int n, double *__restrict__ out)
+{
+    __shared__ double s[BLOCK];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) acc += partial[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = BLOCK / 2; k > 0; k >>= 1) {
+        if (threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// T::create, electron.rs:85-103 / ion.rs:81-101: prev_x from the initial momentum
+template <int SPECIES>
+__global__ void k_init_prev(const int *cell, const double *x, const double *ux, const double *uy, const double *uz,
+                            double *prev_x, unsigned n, double dt, double dx)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double u2 = ux[i] * ux[i] + uy[i] * uy[i] + uz[i] * uz[i];
+    if (SPECIES == OPAL_ELECTRON) {
+        double gamma = sqrt(1.0 + u2);
+        prev_x[i] = x[i] - SPEED_OF_LIGHT * ux[i] * dt / (gamma * dx);
+    } else {
+        double gamma_m1 = u2 / (1.0 + sqrt(1.0 + u2));
+        double vx = SPEED_OF_LIGHT * ux[i] / (1.0 + gamma_m1);
+        prev_x[i] = x[i] - vx * dt / dx;
+    }
+}
+
+int check_pop(const opal_pop_t *p)
+{
+    if (!p) {
+        set_error("null population handle");
+        return OPAL_ERR_ARG;
+    }
+    return OPAL_OK;
+}
+
+int fetch_counters(const opal_pop_t *p)
+{
+    OPAL_HIP(hipMemcpyAsync(p->h_ctr, p->d_ctr, sizeof(PopCounters), hipMemcpyDeviceToHost, p->stream));
+    OPAL_HIP(hipStreamSynchronize(p->stream));
+    return OPAL_OK;
+}
+
+int check_pop_err(opal_pop_t *p)
+{
+    if (int rc = fetch_counters(p)) return rc;
+    int err = p->h_ctr->err;
+    if (err) {
+        OPAL_HIP(hipMemsetAsync(&p->d_ctr->err, 0, sizeof(int), p->stream));
+        if (err & 8) {
+            set_error("leaver buffer overflow: more particles crossed a subdomain edge in one step than the link holds");
+            return OPAL_ERR_CAPACITY;
+        }
+        set_error("particle invariant violated on device (flags 0x%x):%s%s%s", err,
+                  (err & 1) ? " moved >= 1 cell in a step (electron.rs:313 / ion.rs:199);" : "",
+                  (err & 2) ? " gather index out of range (yee.rs:501-502);" : "",
+                  (err & 4) ? " deposit index out of range (yee.rs:578-579);" : "");
+        return OPAL_ERR_ASSERT;
+    }
+    return OPAL_OK;
+}
+
+int alloc_set(opal_pop_t *p, int k)
+{
+    size_t c = p->cap;
+    OPAL_HIP(hipMalloc(&p->d_cell[k], sizeof(int) * c));
+    OPAL_HIP(hipMalloc(&p->d_x[k], sizeof(double) * c));
+    OPAL_HIP(hipMalloc(&p->d_ux[k], sizeof(double) * c));
+    OPAL_HIP(hipMalloc(&p->d_uy[k], sizeof(double) * c));
+    OPAL_HIP(hipMalloc(&p->d_uz[k], sizeof(double) * c));
+    OPAL_HIP(hipMalloc(&p->d_w[k], sizeof(double) * c));
+    return OPAL_OK;
+}
+
+void free_set(opal_pop_t *p, int k)
+{
+    hipFree(p->d_cell[k]); hipFree(p->d_x[k]); hipFree(p->d_ux[k]);
+    hipFree(p->d_uy[k]); hipFree(p->d_uz[k]); hipFree(p->d_w[k]);
+    p->d_cell[k] = nullptr;
+}
+
+int ensure_prev(opal_pop_t *p)
+{
+    if (!p->d_prev_x) OPAL_HIP(hipMalloc(&p->d_prev_x, sizeof(double) * p->cap));
+    return OPAL_OK;
+}
+
+double species_alpha(const opal_pop_t *p, double dt)
+{
+    if (p->species == OPAL_ELECTRON) return ELECTRON_CHARGE * dt / (2.0 * ELECTRON_MASS * SPEED_OF_LIGHT);  // electron.rs:276
+    double q = p->z_star * ELEMENTARY_CHARGE, M = p->a * PROTON_MASS;                                        // ion.rs:173-175
+    return q * dt / (2.0 * M * SPEED_OF_LIGHT);
+}
+double species_charge(const opal_pop_t *p)
+{
+    return p->species == OPAL_ELECTRON ? ELECTRON_CHARGE : p->z_star * ELEMENTARY_CHARGE;  // electron.rs:141, ion.rs:116
+}
+
+template <int SPECIES, int MODE>
+void launch_push(const PushArgs &a, unsigned nblk, bool extras, hipStream_t s)
+{
+    if (SPECIES == OPAL_ELECTRON && extras && MODE != MODE_DEPOSIT)
+        k_push<SPECIES, MODE, true, true><<<nblk, BLOCK, 0, s>>>(a);
+    else
+        k_push<SPECIES, MODE, true, false><<<nblk, BLOCK, 0, s>>>(a);
+}
+
+int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode)
+{
+    (void)link;
+    if (p->n_upper == 0) return OPAL_OK;
+    PushArgs a;
+    memset(&a, 0, sizeof a);
+    int k = p->cur;
+    a.cell = p->d_cell[k]; a.x = p->d_x[k]; a.ux = p->d_ux[k]; a.uy = p->d_uy[k]; a.uz = p->d_uz[k]; a.w = p->d_w[k];
+    a.prev_x = p->d_prev_x;
+    a.chi = p->d_chi; a.work = p->d_work; a.y = p->d_y; a.z = p->d_z;
+    a.eb = g->d_eb[g->cur];
+    a.jr = g->d_j;
+    a.lenp = g->lenp;
+    a.ppt = p->ppt;
+    a.size = (int)g->size; a.L = g->L; a.len = (int)g->len;
+    a.dt = dt;
+    a.dt_over_dx = dt / g->dx;
+    a.inv_dt = 1.0 / dt;
+    a.inv_dx = 1.0 / g->dx;
+    a.alpha = species_alpha(p, dt);
+    a.charge = species_charge(p);
+    auto edge = [&](int bdy, int neighbour) {
+        if (bdy != OPAL_BDY_INTERNAL) return (int)EDGE_DELETE;  // yee.rs:329-343 -> None -> leavers dropped
+        return neighbour == g->id ? (int)EDGE_WRAP : (int)EDGE_SEND;
+    };
+    a.left_mode = edge(g->left_bdy, g->rank_to_left);
+    a.right_mode = edge(g->right_bdy, g->rank_to_right);
+    a.ctr = p->d_ctr;
+    if (a.left_mode == EDGE_SEND || a.right_mode == EDGE_SEND) {
+        set_error("multi-subdomain particle migration needs a link (not wired in this build path)");
+        return OPAL_ERR_ARG;
+    }
+    size_t per_block = (size_t)BLOCK * p->ppt;
+    unsigned nblk = (unsigned)((p->n_upper + per_block - 1) / per_block);
+    int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
+    prof_begin(kid, p->stream);
+    bool ex = p->extras;
+    if (p->species == OPAL_ELECTRON) {
+        if (mode == MODE_FUSED) launch_push<OPAL_ELECTRON, MODE_FUSED>(a, nblk, ex, p->stream);
+        else if (mode == MODE_ADVANCE) launch_push<OPAL_ELECTRON, MODE_ADVANCE>(a, nblk, ex, p->stream);
+        else launch_push<OPAL_ELECTRON, MODE_DEPOSIT>(a, nblk, ex, p->stream);
+    } else {
+        if (mode == MODE_FUSED) launch_push<OPAL_ION, MODE_FUSED>(a, nblk, false, p->stream);
+        else if (mode == MODE_ADVANCE) launch_push<OPAL_ION, MODE_ADVANCE>(a, nblk, false, p->stream);
+        else launch_push<OPAL_ION, MODE_DEPOSIT>(a, nblk, false, p->stream);
+    }
+    prof_end(kid, p->stream);
+    OPAL_HIP(hipGetLastError());
+    return OPAL_OK;
+}
+
+int do_sort(opal_pop_t *p, const opal_grid_t *g)
+{
+    if (p->n_upper == 0) return OPAL_OK;
+    if (!p->have_alt) {
+        if (int rc = alloc_set(p, p->cur ^ 1)) return rc;
+        p->have_alt = true;
+    }
+    size_t ncells = g->size;
+    if (p->count_cap < ncells + 2) {
+        if (p->d_count) hipFree(p->d_count);
+        OPAL_HIP(hipMalloc(&p->d_count, sizeof(unsigned) * (ncells + 2)));
+        p->count_cap = ncells + 2;
+    }
+    double *d_prev_alt = nullptr;
+    if (p->d_prev_x && p->prev_valid) OPAL_HIP(hipMalloc(&d_prev_alt, sizeof(double) * p->cap));
+    prof_begin(KERNEL_SORT, p->stream);
+    OPAL_HIP(hipMemsetAsync(p->d_count, 0, sizeof(unsigned) * (ncells + 2), p->stream));
+    unsigned nblk = (unsigned)std::min<size_t>((p->n_upper + 255) / 256, 4096);
+    int k = p->cur, o = k ^ 1;
+    k_sort_hist<<<nblk, 256, 0, p->stream>>>(p->d_cell[k], p->d_ctr, p->d_count);
+    k_sort_scan<<<1, 1024, 0, p->stream>>>(p->d_count, (int)ncells, p->d_ctr);
+    SortArgs sa;
+    sa.cell = p->d_cell[k];
+    sa.f[0] = p->d_x[k]; sa.f[1] = p->d_ux[k]; sa.f[2] = p->d_uy[k]; sa.f[3] = p->d_uz[k]; sa.f[4] = p->d_w[k];
+    sa.ocell = p->d_cell[o];
+    sa.of[0] = p->d_x[o]; sa.of[1] = p->d_ux[o]; sa.of[2] = p->d_uy[o]; sa.of[3] = p->d_uz[o]; sa.of[4] = p->d_w[o];
+    sa.prev = d_prev_alt ? p->d_prev_x : nullptr;
+    sa.oprev = d_prev_alt;
+    k_sort_scatter<<<nblk, 256, 0, p->stream>>>(sa, p->d_ctr, p->d_count);
+    k_sort_finish<<<1, 1, 0, p->stream>>>(p->d_ctr);
+    prof_end(KERNEL_SORT, p->stream);
+    OPAL_HIP(hipGetLastError());
+    if (int rc = fetch_counters(p)) return rc;
+    if (d_prev_alt) {
+        hipFree(p->d_prev_x);
+        p->d_prev_x = d_prev_alt;
+    }
+    p->cur = o;
+    p->n_upper = p->h_ctr->n_slots;
+    p->steps_since_sort = 0;
+    // size the per-workgroup chunk so that it spans about 4 occupied cells (TILE holds ~10 with margins)
+    unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
+    double per_cell = (double)p->h_ctr->n_live / ne;
+    int ppt = (int)(4.0 * per_cell / BLOCK);
+    p->ppt = std::max(1, std::min(8, ppt));
+    return OPAL_OK;
+}
+
+int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
+{
+    p->steps_since_sort++;
+    if (p->sort_interval == 0) return OPAL_OK;
+    if (p->sort_interval > 0) {
+        if (p->steps_since_sort >= p->sort_interval) return do_sort(p, g);
+        return OPAL_OK;
+    }
+    // adaptive: every 8 steps look at the tile-miss counter (one small D2H copy); re-bin once more than
+    // 3 % of the particle-steps since the last sort missed their workgroup's LDS tile.
+    if (p->steps_since_sort % 8 != 0) return OPAL_OK;
+    if (int rc = fetch_counters(p)) return rc;
+    double work = (double)p->h_ctr->n_slots * p->steps_since_sort;
+    if ((double)p->h_ctr->n_slow > 0.03 * work) return do_sort(p, g);
+    return OPAL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_stream)
+{
+    if (!out || (species != OPAL_ELECTRON && species != OPAL_ION)) {
+        set_error("opal_pop_create: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("opal_pop_create: no HIP device available (the HIP path has no CPU fallback)");
+        return OPAL_ERR_HIP;
+    }
+    if (capacity >= (size_t)1 << 31) {
+        set_error("opal_pop_create: capacity %zu exceeds 2^31 slots per subdomain", capacity);
+        return OPAL_ERR_CAPACITY;
+    }
+    opal_pop_t *p = new opal_pop_t();
+    memset((void *)p, 0, sizeof *p);
+    p->species = species;
+    p->cap = std::max<size_t>(capacity, 1024);
+    p->stream = (hipStream_t)hip_stream;
+    p->z_star = p->z = p->a = 1.0;  // ion.rs:93-95
+    p->sort_interval = -1;
+    p->ppt = 8;
+    if (int rc = alloc_set(p, 0)) return rc;
+    OPAL_HIP(hipMalloc(&p->d_ctr, sizeof(PopCounters)));
+    OPAL_HIP(hipHostMalloc(&p->h_ctr, sizeof(PopCounters)));
+    OPAL_HIP(hipMemsetAsync(p->d_ctr, 0, sizeof(PopCounters), p->stream));
+    p->partial_cap = 2048;
+    OPAL_HIP(hipMalloc(&p->d_partial, sizeof(double) * (p->partial_cap + 8)));
+    OPAL_HIP(hipStreamSynchronize(p->stream));
+    *out = p;
+    return OPAL_OK;
+}
+
+int opal_pop_free(opal_pop_t *p)
+{
+    if (!p) return OPAL_OK;
+    free_set(p, 0);
+    if (p->have_alt || p->d_cell[1]) free_set(p, 1);
+    if (p->d_prev_x) hipFree(p->d_prev_x);
+    if (p->d_chi) { hipFree(p->d_chi); hipFree(p->d_work); hipFree(p->d_y); hipFree(p->d_z); }
+    if (p->d_count) hipFree(p->d_count);
+    hipFree(p->d_partial);
+    hipFree(p->d_ctr);
+    hipHostFree(p->h_ctr);
+    delete p;
+    return OPAL_OK;
+}
+
+int opal_pop_set_charge_state(opal_pop_t *p, double z_star, double z, double a)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (p->species != OPAL_ION) return OPAL_OK;
+    p->z_star = z_star; p->z = z; p->a = a;
+    return OPAL_OK;
+}
+
+int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const double *x, const double *ux,
+                        const double *uy, const double *uz, const double *w, double dx, double dt)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (n > p->cap) {
+        set_error("opal_pop_upload_soa: %zu particles exceed the capacity %zu", n, p->cap);
+        return OPAL_ERR_CAPACITY;
+    }
+    int k = p->cur;
+    OPAL_HIP(hipMemcpyAsync(p->d_cell[k], cell, sizeof(int) * n, hipMemcpyHostToDevice, p->stream));
+    OPAL_HIP(hipMemcpyAsync(p->d_x[k], x, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    OPAL_HIP(hipMemcpyAsync(p->d_ux[k], ux, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    OPAL_HIP(hipMemcpyAsync(p->d_uy[k], uy, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    OPAL_HIP(hipMemcpyAsync(p->d_uz[k], uz, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    OPAL_HIP(hipMemcpyAsync(p->d_w[k], w, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    p->h_ctr->n_slots = (unsigned)n;
+    OPAL_HIP(hipMemsetAsync(p->d_ctr, 0, sizeof(PopCounters), p->stream));
+    OPAL_HIP(hipMemcpyAsync(&p->d_ctr->n_slots, &p->h_ctr->n_slots, sizeof(unsigned), hipMemcpyHostToDevice, p->stream));
+    p->n_upper = n;
+    p->steps_since_sort = 0;
+    p->dx_last = dx;
+    // T::create: prev_x (only kept if the caller later uses the separate deposit operator)
+    if (n) {
+        if (int rc = ensure_prev(p)) return rc;
+        unsigned nb = (unsigned)((n + 255) / 256);
+        if (p->species == OPAL_ELECTRON)
+            k_init_prev<OPAL_ELECTRON><<<nb, 256, 0, p->stream>>>(p->d_cell[k], p->d_x[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_prev_x, (unsigned)n, dt, dx);
+        else
+            k_init_prev<OPAL_ION><<<nb, 256, 0, p->stream>>>(p->d_cell[k], p->d_x[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_prev_x, (unsigned)n, dt, dx);
+        p->prev_valid = true;
+        OPAL_HIP(hipGetLastError());
+    }
+    if (p->extras && n) {
+        OPAL_HIP(hipMemsetAsync(p->d_chi, 0, sizeof(double) * p->cap, p->stream));
+        OPAL_HIP(hipMemsetAsync(p->d_work, 0, sizeof(double) * p->cap, p->stream));
+        OPAL_HIP(hipMemsetAsync(p->d_y, 0, sizeof(double) * p->cap, p->stream));
+        OPAL_HIP(hipMemsetAsync(p->d_z, 0, sizeof(double) * p->cap, p->stream));
+    }
+    OPAL_HIP(hipStreamSynchronize(p->stream));
+    return OPAL_OK;
+}
+
+int opal_pop_len(const opal_pop_t *p, size_t *n)
+{
+    if (int rc = check_pop(p)) return rc;
+    // live = slots - dead; count on the host from the cell array (diagnostic path)
+    if (int rc = fetch_counters(p)) return rc;
+    size_t slots = p->h_ctr->n_slots;
+    std::vector<int> cell(slots);
+    if (slots) OPAL_HIP(hipMemcpy(cell.data(), p->d_cell[p->cur], sizeof(int) * slots, hipMemcpyDeviceToHost));
+    size_t live = 0;
+    for (size_t i = 0; i < slots; i++) live += cell[i] != DEAD_CELL;
+    *n = live;
+    return OPAL_OK;
+}
+
+int opal_pop_download_soa(const opal_pop_t *p, int32_t *cell, double *x, double *prev_x, double *ux, double *uy,
+                          double *uz, double *w)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (int rc = fetch_counters(p)) return rc;
+    size_t slots = p->h_ctr->n_slots;
+    if (!slots) return OPAL_OK;
+    int k = p->cur;
+    std::vector<int> hc(slots);
+    OPAL_HIP(hipMemcpy(hc.data(), p->d_cell[k], sizeof(int) * slots, hipMemcpyDeviceToHost));
+    std::vector<double> tmp(slots);
+    auto pull = [&](const double *src, double *dst) -> int {
+        if (!dst) return OPAL_OK;
+        if (!src) {
+            set_error("opal_pop_download_soa: attribute not resident (prev_x needs a prior advance)");
+            return OPAL_ERR_ARG;
+        }
+        OPAL_HIP(hipMemcpy(tmp.data(), src, sizeof(double) * slots, hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (size_t i = 0; i < slots; i++)
+            if (hc[i] != DEAD_CELL) dst[o++] = tmp[i];
+        return OPAL_OK;
+    };
+    if (int rc = pull(p->d_x[k], x)) return rc;
+    if (int rc = pull(p->prev_valid ? p->d_prev_x : nullptr, prev_x)) return rc;
+    if (int rc = pull(p->d_ux[k], ux)) return rc;
+    if (int rc = pull(p->d_uy[k], uy)) return rc;
+    if (int rc = pull(p->d_uz[k], uz)) return rc;
+    if (int rc = pull(p->d_w[k], w)) return rc;
+    if (cell) {
+        size_t o = 0;
+        for (size_t i = 0; i < slots; i++)
+            if (hc[i] != DEAD_CELL) cell[o++] = hc[i];
+    }
+    return OPAL_OK;
+}
+
+int opal_pop_track_extras(opal_pop_t *p, int on)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (p->species != OPAL_ELECTRON) return OPAL_OK;
+    if (on && !p->d_chi) {
+        OPAL_HIP(hipMalloc(&p->d_chi, sizeof(double) * p->cap));
+        OPAL_HIP(hipMalloc(&p->d_work, sizeof(double) * p->cap));
+        OPAL_HIP(hipMalloc(&p->d_y, sizeof(double) * p->cap));
+        OPAL_HIP(hipMalloc(&p->d_z, sizeof(double) * p->cap));
+        OPAL_HIP(hipMemsetAsync(p->d_chi, 0, sizeof(double) * p->cap, p->stream));
+        OPAL_HIP(hipMemsetAsync(p->d_work, 0, sizeof(double) * p->cap, p->stream));
+        OPAL_HIP(hipMemsetAsync(p->d_y, 0, sizeof(double) * p->cap, p->stream));
+        OPAL_HIP(hipMemsetAsync(p->d_z, 0, sizeof(double) * p->cap, p->stream));
+    }
+    p->extras = on != 0;
+    if (p->extras) p->sort_interval = 0;  // extras are not carried through re-binning
+    return OPAL_OK;
+}
+
+int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (!p->d_chi) {
+        set_error("opal_pop_download_extras: extras are not tracked");
+        return OPAL_ERR_ARG;
+    }
+    if (int rc = fetch_counters(p)) return rc;
+    size_t slots = p->h_ctr->n_slots;
+    std::vector<int> hc(slots);
+    std::vector<double> tmp(slots);
+    if (slots) OPAL_HIP(hipMemcpy(hc.data(), p->d_cell[p->cur], sizeof(int) * slots, hipMemcpyDeviceToHost));
+    const double *src[4] = {p->d_chi, p->d_work, p->d_y, p->d_z};
+    double *dst[4] = {chi, work, y, z};
+    for (int k = 0; k < 4; k++) {
+        if (!dst[k] || !slots) continue;
+        OPAL_HIP(hipMemcpy(tmp.data(), src[k], sizeof(double) * slots, hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (size_t i = 0; i < slots; i++)
+            if (hc[i] != DEAD_CELL) dst[k][o++] = tmp[i];
+    }
+    return OPAL_OK;
+}
+
+int opal_pop_set_sort_interval(opal_pop_t *p, int interval)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (p->extras && interval != 0) {
+        set_error("opal_pop_set_sort_interval: re-binning is disabled while electron extras are tracked");
+        return OPAL_ERR_ARG;
+    }
+    p->sort_interval = interval;
+    return OPAL_OK;
+}
+
+int opal_pop_sort(opal_pop_t *p, const opal_grid_t *grid)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (!grid) {
+        set_error("opal_pop_sort: null grid");
+        return OPAL_ERR_ARG;
+    }
+    if (p->extras) {
+        set_error("opal_pop_sort: re-binning is disabled while electron extras are tracked");
+        return OPAL_ERR_ARG;
+    }
+    return do_sort(p, grid);
+}
+
+int opal_pop_advance(opal_pop_t *p, opal_link_t *link, const opal_grid_t *grid, double dt)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (!grid) {
+        set_error("opal_pop_advance: null grid");
+        return OPAL_ERR_ARG;
+    }
+    if (int rc = ensure_prev(p)) return rc;
+    if (int rc = run_push(p, link, const_cast<opal_grid_t *>(grid), dt, MODE_ADVANCE)) return rc;
+    p->prev_valid = true;
+    if (int rc = maybe_sort(p, grid)) return rc;
+    return OPAL_OK;
+}
+
+int opal_pop_advance_deposit(opal_pop_t *p, opal_link_t *link, opal_grid_t *grid, double dt)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (!grid) {
+        set_error("opal_pop_advance_deposit: null grid");
+        return OPAL_ERR_ARG;
+    }
+    if (int rc = run_push(p, link, grid, dt, MODE_FUSED)) return rc;
+    p->prev_valid = false;
+    if (int rc = maybe_sort(p, grid)) return rc;
+    return OPAL_OK;
+}
+
+int opal_grid_deposit(opal_grid_t *g, const opal_pop_t *pop, double dt)
+{
+    if (!g) {
+        set_error("opal_grid_deposit: null grid");
+        return OPAL_ERR_ARG;
+    }
+    if (int rc = check_pop(pop)) return rc;
+    if (pop->n_upper == 0) return OPAL_OK;  // yee.rs:557-559
+    if (!pop->prev_valid) {
+        set_error("opal_grid_deposit: prev_x is not resident; call opal_pop_advance (not the fused pass) first");
+        return OPAL_ERR_ARG;
+    }
+    return run_push(const_cast<opal_pop_t *>(pop), nullptr, g, dt, MODE_DEPOSIT);
+}
+
+int opal_pop_total_kinetic_energy(const opal_pop_t *p, double *energy)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (p->n_upper == 0) {
+        *energy = 0.0;
+        return OPAL_OK;
+    }
+    int k = p->cur;
+    int nblk = (int)std::min<size_t>((p->n_upper + BLOCK - 1) / BLOCK, p->partial_cap);
+    if (p->species == OPAL_ELECTRON)
+        k_kinetic<OPAL_ELECTRON><<<nblk, BLOCK, 0, p->stream>>>(p->d_cell[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_w[k], p->d_ctr, p->a, p->d_partial);
+    else
+        k_kinetic<OPAL_ION><<<nblk, BLOCK, 0, p->stream>>>(p->d_cell[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_w[k], p->d_ctr, p->a, p->d_partial);
+    k_fold<<<1, BLOCK, 0, p->stream>>>(p->d_partial, nblk, p->d_partial + p->partial_cap);
+    OPAL_HIP(hipGetLastError());
+    OPAL_HIP(hipMemcpyAsync(energy, p->d_partial + p->partial_cap, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    OPAL_HIP(hipStreamSynchronize(p->stream));
+    return check_pop_err(const_cast<opal_pop_t *>(p));
+}
+
+}  // extern "C"
+
+namespace opal {
+int pop_check_err(opal_pop_t *p) { return check_pop_err(p); }
+}

@@ -1,0 +1,206 @@
+// Device-side arithmetic of the PIC step for gfx950: shape functions, field
+// gather, the Vay (electron) and Boris (ion) pushers, and the deposit taps.
+// Every function cites the reference lines whose arithmetic it reproduces;
+// the operation order inside each expression follows the reference so that the
+// only differences from the CPU oracle are FMA contraction and summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace opal {
+
+// src/constants.rs:4-27 (deliberately truncated literals; C2 is NOT C*C)
+constexpr double SPEED_OF_LIGHT = 2.997925e8;
+constexpr double SPEED_OF_LIGHT_SQD = 89875517873681764.0;
+constexpr double VACUUM_PERMITTIVITY = 8.854188e-12;
+constexpr double VACUUM_PERMEABILITY = 1.256637e-6;
+constexpr double ELECTRON_CHARGE = -1.602177e-19;
+constexpr double ELEMENTARY_CHARGE = 1.602177e-19;
+constexpr double ELECTRON_MASS = 9.109383e-31;
+constexpr double PROTON_MASS = 1.672622e-27;
+constexpr double ELECTRON_MASS_MEV = 0.510999;
+constexpr double CRITICAL_FIELD = 1.323285e18;
+
+// yee.rs:239-242
+constexpr int GHOST_SIZE = 4;
+constexpr int LASER_BDY_SIZE = 4;
+constexpr int ABSORBING_BDY_SIZE = 200;
+constexpr int CONDUCTING_BDY_SIZE = 4;
+
+constexpr int DEAD_CELL = -(1 << 30);  // slot holds no particle
+
+struct V3 {
+    double x, y, z;
+};
+__host__ __device__ inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__host__ __device__ inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__host__ __device__ inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ inline V3 cross(V3 a, V3 b)
+{
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// Cell::weight, yee.rs:140-149 (branch-free: both polynomials, then select)
+__host__ __device__ inline double weight(double xi)
+{
+    double xhat = fabs(xi);
+    double inner = 0.75 - xhat * xhat;
+    double outer = 1.125 - 1.5 * xhat + 0.5 * (xhat * xhat);
+    double w = xhat < 0.5 ? inner : outer;
+    return xhat > 1.5 ? 0.0 : w;
+}
+
+// Cell::flux, yee.rs:185-204, without divergent branches.  With pa := 0 when
+// |x_i| >= 1 and pb := 0 when |x_f| >= 1 the first, second, fourth and fifth arms
+// of the reference all read |pb - pa| carrying the sign of (x_i - x_f): for a
+// boundary that moves by less than one cell (asserted by the pushers) the signs
+// the reference takes from -x_i or x_f coincide with that of x_i - x_f.
+__host__ __device__ inline double flux(double x_i, double x_f)
+{
+    double a = fabs(x_i), b = fabs(x_f);
+    bool ina = a < 1.0, inb = b < 1.0;
+    double ca = 1.0 - a, cb = 1.0 - b;
+    double pa = ina ? 0.5 * (ca * ca) : 0.0;
+    double pb = inb ? 0.5 * (cb * cb) : 0.0;
+    double same = copysign(pb - pa, x_i - x_f);
+    double diff = copysign(a * (1.0 - 0.5 * a) + b * (1.0 - 0.5 * b), x_i);
+    bool opposite = ina && inb && !(x_i * x_f >= 0.0);
+    return opposite ? diff : same;
+}
+
+// The seven gather weights of fields_at, yee.rs:504-526
+struct GatherW {
+    double c0, c1, c2;      // centred quantities (Ex, By, Bz): cells j-1, j, j+1
+    double e0, e1, e2, e3;  // edge quantities (Ey, Ez): cells j-1 .. j+2
+};
+__host__ __device__ inline GatherW gather_weights(double xi)
+{
+    GatherW g;
+    g.c0 = weight(0.5 + xi);
+    g.c1 = weight(0.5 - xi);
+    g.c2 = weight(1.5 - xi);
+    g.e0 = weight(1.0 + xi);
+    g.e1 = weight(xi);
+    g.e2 = weight(1.0 - xi);
+    g.e3 = weight(2.0 - xi);
+    return g;
+}
+
+// fields_at, yee.rs:499-529.  F is any accessor F(comp, cell_index) over the six
+// field components 0..5 = Ex Ey Ez Bx By Bz; j is the array index of the cell.
+template <class F>
+__host__ __device__ inline void gather(const F &f, int j, double xi, V3 &E, V3 &B)
+{
+    GatherW g = gather_weights(xi);
+    E.x = f(0, j - 1) * g.c0 + f(0, j) * g.c1 + f(0, j + 1) * g.c2;
+    E.y = f(1, j - 1) * g.e0 + f(1, j) * g.e1 + f(1, j + 1) * g.e2 + f(1, j + 2) * g.e3;
+    E.z = f(2, j - 1) * g.e0 + f(2, j) * g.e1 + f(2, j + 1) * g.e2 + f(2, j + 2) * g.e3;
+    B.x = f(3, j);
+    B.y = f(4, j - 1) * g.c0 + f(4, j) * g.c1 + f(4, j + 1) * g.c2;
+    B.z = f(5, j - 1) * g.c0 + f(5, j) * g.c1 + f(5, j + 1) * g.c2;
+}
+
+// Result of one push: new momentum, Lorentz factor, displacement in cells.
+struct Pushed {
+    V3 u;
+    double gamma;  // electrons: Vay gamma; ions: 1 + gamma_m1
+    double dxi;
+    // electron diagnostics (only meaningful when requested)
+    double chi, dwork;
+    V3 v_old;
+};
+
+// Electron::vay_push, electron.rs:268-330 (momentum + displacement part).
+// `gamma_old` is the Lorentz factor the reference carries in the struct; the
+// caller recomputes it as sqrt(1 + u.u) (equal to the stored value up to
+// rounding) so that gamma never travels through HBM.
+template <bool EXTRAS>
+__device__ inline Pushed vay_push(V3 u, double gamma_old, V3 E, V3 B, double alpha, double dt_over_dx, double dt)
+{
+    Pushed r;
+    double inv_g = 1.0 / gamma_old;
+    V3 v = {SPEED_OF_LIGHT * u.x * inv_g, SPEED_OF_LIGHT * u.y * inv_g, SPEED_OF_LIGHT * u.z * inv_g};
+    V3 u_half = u + alpha * (E + cross(v, B));
+    if (EXTRAS) {
+        double gh2 = 1.0 + dot(u_half, u_half);
+        double gamma_half = sqrt(gh2);
+        r.dwork = ELECTRON_CHARGE * SPEED_OF_LIGHT * dot(u_half, E) * dt / gamma_half;
+        V3 w = gamma_half * E + SPEED_OF_LIGHT * cross(u_half, B);
+        double eu = dot(E, u_half);
+        r.chi = sqrt(dot(w, w) - eu * eu) / CRITICAL_FIELD;
+        r.v_old = v;
+    }
+    V3 u_prime = u_half + alpha * E;
+    double gamma_prime_sqd = 1.0 + dot(u_prime, u_prime);
+    V3 tau = (alpha * SPEED_OF_LIGHT) * B;
+    double u_star = dot(u_prime, tau);
+    double tau2 = dot(tau, tau);
+    double sigma = gamma_prime_sqd - tau2;
+    double gamma = sqrt(0.5 * sigma + sqrt(0.25 * (sigma * sigma) + tau2 + u_star * u_star));
+    double inv_gn = 1.0 / gamma;
+    V3 t = inv_gn * tau;
+    double s = 1.0 / (1.0 + dot(t, t));
+    r.u = s * (u_prime + dot(u_prime, t) * t + cross(u_prime, t));
+    r.gamma = gamma;
+    r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx * inv_gn;
+    return r;
+}
+
+// Ion::push, ion.rs:168-214 (Boris).  alpha = q dt / (2 M c) with q = Z* e, M = A m_p.
+__device__ inline Pushed boris_push(V3 u, V3 E, V3 B, double alpha, double dt_over_dx)
+{
+    Pushed r;
+    V3 cB = SPEED_OF_LIGHT * B;
+    V3 u_minus = u + alpha * E;
+    double um2 = dot(u_minus, u_minus);
+    double gamma = 1.0 + um2 / (1.0 + sqrt(1.0 + um2));
+    double t = alpha / gamma;
+    V3 u_prime = u_minus + t * cross(u_minus, cB);
+    double t_prime = 2.0 * t / (1.0 + (t * t) * dot(cB, cB));
+    V3 u_plus = u_minus + t_prime * cross(u_prime, cB);
+    r.u = u_plus + alpha * E;
+    double un2 = dot(r.u, r.u);
+    double gamma_m1 = un2 / (1.0 + sqrt(1.0 + un2));
+    r.gamma = 1.0 + gamma_m1;
+    r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx / r.gamma;
+    return r;
+}
+
+// The deposit stencil of one particle, yee.rs:584-609, relative to its (new)
+// cell index: jx[k] -> index + k - 2 (k = 0..4); jy, jz[k] -> index + k - 1
+// (k = 0..2; the reference's fourth tap weight(2.0 + x) is identically zero);
+// rho[k] -> index + k - 2 (k = 0..3; the reference adds W(2 - x) at index - 2).
+struct Taps {
+    double jx[5];
+    double jy[3];
+    double jz[3];
+    double rho[4];
+};
+
+template <bool RHO>
+__device__ inline Taps deposit_taps(double x, double prev_x, double macrocharge, double vy, double vz,
+                                    double inv_dt, double inv_dx)
+{
+    Taps t;
+    t.jx[2] = macrocharge * flux(0.5 - prev_x, 0.5 - x) * inv_dt;
+    t.jx[1] = macrocharge * flux(-0.5 - prev_x, -0.5 - x) * inv_dt;
+    t.jx[0] = macrocharge * flux(-1.5 - prev_x, -1.5 - x) * inv_dt;
+    t.jx[3] = macrocharge * flux(1.5 - prev_x, 1.5 - x) * inv_dt;
+    t.jx[4] = macrocharge * flux(2.5 - prev_x, 2.5 - x) * inv_dt;
+    double w0 = weight(1.0 + x), w1 = weight(x), w2 = weight(1.0 - x);
+    double qy = macrocharge * vy, qz = macrocharge * vz;
+    t.jy[0] = qy * w0 * inv_dx;
+    t.jy[1] = qy * w1 * inv_dx;
+    t.jy[2] = qy * w2 * inv_dx;
+    t.jz[0] = qz * w0 * inv_dx;
+    t.jz[1] = qz * w1 * inv_dx;
+    t.jz[2] = qz * w2 * inv_dx;
+    if (RHO) {
+        t.rho[0] = macrocharge * weight(2.0 - x) * inv_dx;
+        t.rho[1] = macrocharge * w0 * inv_dx;
+        t.rho[2] = macrocharge * w1 * inv_dx;
+        t.rho[3] = macrocharge * w2 * inv_dx;
+    }
+    return t;
+}
+
+}  // namespace opal

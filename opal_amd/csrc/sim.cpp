@@ -1,0 +1,613 @@
+// The YAML-driven driver: main() of the reference (src/main.rs:48-286) for the
+// hot-path configurations (no QED), written against this library's own C ABI
+// exactly as a Rust host would call it.  Also the C-ABI wrappers of the
+// host-side pieces (GridDesign, loader, Config).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "config.hpp"
+#include "host_setup.hpp"
+#include "opal_internal.hpp"
+
+using namespace opal;
+
+namespace opal {
+int pop_check_err(opal_pop_t *p);
+}
+
+namespace {
+
+// ---- Rust-compatible float formatting (main.rs:35-38 uses {:.6e}; yee.rs:768 uses {:e} and {})
+void shortest_digits(double v, std::string &digits, int &exp10)
+{
+    // shortest decimal that round-trips; digits without dot, value = 0.d1d2... * 10^(exp10+1)
+    char buf[64];
+    for (int p = 0; p < 17; p++) {
+        snprintf(buf, sizeof buf, "%.*e", p, v);
+        if (strtod(buf, nullptr) == v) break;
+    }
+    std::string s(buf);
+    size_t epos = s.find('e');
+    std::string mant = s.substr(0, epos);
+    exp10 = atoi(s.c_str() + epos + 1);
+    digits.clear();
+    for (char c : mant)
+        if (isdigit((unsigned char)c)) digits.push_back(c);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+}
+
+std::string rust_lower_exp(double v)  // {:e}
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    std::string sign = std::signbit(v) ? "-" : "";
+    v = std::fabs(v);
+    if (v == 0.0) return sign + "0e0";
+    std::string d;
+    int e;
+    shortest_digits(v, d, e);
+    std::string out = sign + d.substr(0, 1);
+    if (d.size() > 1) out += "." + d.substr(1);
+    return out + "e" + std::to_string(e);
+}
+
+std::string rust_lower_exp_prec(double v, int prec)  // {:.6e}
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.*e", prec, v);
+    std::string s(buf);
+    size_t epos = s.find('e');
+    int e = atoi(s.c_str() + epos + 1);
+    return s.substr(0, epos) + "e" + std::to_string(e);
+}
+
+std::string rust_display(double v)  // {}
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    std::string sign = std::signbit(v) ? "-" : "";
+    v = std::fabs(v);
+    if (v == 0.0) return sign + "0";
+    std::string d;
+    int e;
+    shortest_digits(v, d, e);
+    int n = (int)d.size();
+    std::string out;
+    if (e >= n - 1) {
+        out = d + std::string((size_t)(e - (n - 1)), '0');
+    } else if (e >= 0) {
+        out = d.substr(0, (size_t)e + 1) + "." + d.substr((size_t)e + 1);
+    } else {
+        out = "0." + std::string((size_t)(-e - 1), '0') + d;
+    }
+    return sign + out;
+}
+
+// SimulationTime, setup.rs:421-438
+std::string simulation_time(double t)
+{
+    double power = 3.0 * std::floor((std::log10(std::fabs(t)) + 0.0) / 3.0);
+    power = std::max(std::min(power, 0.0), -18.0);
+    int p = std::isnan(power) ? 0 : (int)power;
+    const char *unit = " s";
+    double scale = 1.0;
+    switch (p) {
+    case -18: unit = "as"; scale = 1.0e18; break;
+    case -15: unit = "fs"; scale = 1.0e15; break;
+    case -12: unit = "ps"; scale = 1.0e12; break;
+    case -9: unit = "ns"; scale = 1.0e9; break;
+    case -6: unit = "\xce\xbcs"; scale = 1.0e6; break;
+    case -3: unit = "ms"; scale = 1.0e3; break;
+    default: break;
+    }
+    char buf[64];
+    snprintf(buf, sizeof buf, "%8.2f %s", scale * t, unit);
+    return buf;
+}
+
+int config_fail(const ConfigError &e)
+{
+    set_error("%s", e.message().c_str());
+    return OPAL_ERR_CONFIG;
+}
+
+double call_laser(double t, double x, void *user)
+{
+    auto *f = static_cast<std::function<double(const double *)> *>(user);
+    double a[2] = {t, x};
+    return (*f)(a);
+}
+
+}  // namespace
+
+struct opal_sim {
+    Config cfg;
+    int rank = 0, numtasks = 1;
+    opal_link_t *link = nullptr;
+    void *stream = nullptr;
+    std::string output_dir;
+    size_t nx = 0, n_outputs = 0;
+    double xmin = 0, dx = 0, dt = 0, tstart = 0, tend = 0;
+    bool current_deposition = false, balance = true, has_laser = false;
+    std::function<double(const double *)> laser_y, laser_z;
+    opal_grid_t *grid = nullptr;
+    opal_pop_t *electrons = nullptr, *ions = nullptr;
+    std::string ion_name;
+    double t = 0;
+    size_t total_steps = 0, steps_bt_output = 0;
+    bool fused = true;
+};
+
+namespace {
+
+struct LaserPair {
+    std::function<double(const double *)> *y, *z;
+};
+double laser_y_cb(double t, double x, void *user) { return call_laser(t, x, static_cast<LaserPair *>(user)->y); }
+double laser_z_cb(double t, double x, void *user) { return call_laser(t, x, static_cast<LaserPair *>(user)->z); }
+
+int load_species(opal_sim_t *s, const char *section, const char *density_key, int species, size_t npc, Rng &rng,
+                 opal_pop_t **out)
+{
+    ConfigError ce;
+    std::function<double(const double *)> ne, ux, uy, uz;
+    if (!s->cfg.func(section, density_key, {"x"}, ne, ce)) return config_fail(ce);
+    if (!s->cfg.func(section, "ux", {"x", "urand", "nrand"}, ux, ce)) return config_fail(ce);
+    if (!s->cfg.func(section, "uy", {"x", "urand", "nrand"}, uy, ce)) return config_fail(ce);
+    if (!s->cfg.func(section, "uz", {"x", "urand", "nrand"}, uz, ce)) return config_fail(ce);
+    HostSoA soa;
+    auto f3 = [](const std::function<double(const double *)> &f) {
+        return [f](double x, double ur, double nr) {
+            double a[3] = {x, ur, nr};
+            return f(a);
+        };
+    };
+    load_population(species, npc, [&](double x) { return ne(&x); }, f3(ux), f3(uy), f3(uz), opal_grid_xmin(s->grid),
+                    s->dx, opal_grid_size(s->grid), rng, soa);
+    // headroom for arrivals from neighbouring subdomains between two re-binnings
+    size_t cap = soa.size() + soa.size() / 8 + 65536;
+    if (int rc = opal_pop_create(out, species, cap, s->stream)) return rc;
+    return opal_pop_upload_soa(*out, soa.size(), soa.cell.data(), soa.x.data(), soa.ux.data(), soa.uy.data(),
+                               soa.uz.data(), soa.w.data(), s->dx, s->dt);
+}
+
+// main.rs:63-187
+int sim_setup(opal_sim_t *s)
+{
+    ConfigError ce;
+    Config &in = s->cfg;
+    in.with_context("constants");
+    if (!in.read_usize("control", "nx", s->nx, ce)) return config_fail(ce);
+    if (!in.read_f64("control", "xmin", s->xmin, ce)) return config_fail(ce);
+    if (!in.read_f64("control", "dx", s->dx, ce)) return config_fail(ce);
+    s->dt = 0.95 * s->dx / 2.997925e8;  // main.rs:71
+    if (!in.read_f64("control", "start", s->tstart, ce)) return config_fail(ce);
+    if (!in.read_f64("control", "end", s->tend, ce)) return config_fail(ce);
+    if (!in.read_bool("control", "current_deposition", s->current_deposition, ce)) return config_fail(ce);
+    if (!in.read_usize("control", "n_outputs", s->n_outputs, ce)) return config_fail(ce);
+    if (!in.read_bool("control", "balance", s->balance, ce)) s->balance = true;  // main.rs:76
+    bool photon_emission, photon_absorption;
+    if (!in.read_bool("qed", "photon_emission", photon_emission, ce)) return config_fail(ce);
+    if (!in.read_bool("qed", "photon_absorption", photon_absorption, ce)) return config_fail(ce);
+    if (photon_emission || photon_absorption) {
+        set_error("qed.photon_emission / photon_absorption are outside this build's hot-path scope (SURVEY.md 8f)");
+        return OPAL_ERR_CONFIG;
+    }
+    // main.rs:89-101
+    ConfigError ly_err, lz_err;
+    bool have_y = in.func("laser", "Ey", {"t", "x"}, s->laser_y, ly_err);
+    bool have_z = in.func("laser", "Ez", {"t", "x"}, s->laser_z, lz_err);
+    int left = OPAL_BDY_INTERNAL, right = OPAL_BDY_INTERNAL;
+    if (in.contains("laser")) {
+        if (!have_y) return config_fail(ly_err);
+        if (!have_z) return config_fail(lz_err);
+        left = OPAL_BDY_LASER;
+        right = OPAL_BDY_ABSORBING;
+        s->has_laser = true;
+    }
+    size_t min_size = opal_grid_min_size();
+    std::vector<size_t> nxs((size_t)s->numtasks);
+    std::vector<double> offs((size_t)s->numtasks);
+    if (s->balance) {  // main.rs:105-110
+        std::function<double(const double *)> ne;
+        if (!in.func("electrons", "ne", {"x"}, ne, ce)) return config_fail(ce);
+        if (design_balanced(s->numtasks, s->nx, s->xmin, s->dx, min_size, [&](double x) { return ne(&x); }, nxs.data(),
+                            offs.data())) {
+            set_error("balanced grid design failed: no partition point found (reference panics, grid/mod.rs:179)");
+            return OPAL_ERR_CONFIG;
+        }
+    } else {
+        design_unbalanced(s->numtasks, s->nx, s->dx, min_size, nxs.data(), offs.data());
+    }
+    if (int rc = opal_grid_build(&s->grid, s->rank, s->numtasks, left, right, s->xmin, s->dx, nxs.data(), offs.data(),
+                                 s->stream))
+        return rc;
+
+    Rng rng;
+    rng.seed((uint64_t)s->rank);  // main.rs:53
+    size_t epc;
+    std::vector<std::string> ospec;
+    if (!in.read_usize("electrons", "npc", epc, ce)) return config_fail(ce);
+    if (!in.read_strings("electrons", "output", ospec, ce)) return config_fail(ce);
+    if (epc > 0) {
+        if (int rc = load_species(s, "electrons", "ne", OPAL_ELECTRON, epc, rng, &s->electrons)) return rc;
+    }
+    size_t ipc;
+    if (!in.read_usize("ions", "npc", ipc, ce)) return config_fail(ce);
+    if (ipc > 0) {
+        double z, a;
+        if (!in.read_strings("ions", "output", ospec, ce)) return config_fail(ce);
+        if (!in.read_string("ions", "name", s->ion_name, ce)) return config_fail(ce);
+        if (!in.read_f64("ions", "Z", z, ce)) return config_fail(ce);
+        if (!in.read_f64("ions", "A", a, ce)) return config_fail(ce);
+        if (int rc = load_species(s, "ions", "ni", OPAL_ION, ipc, rng, &s->ions)) return rc;
+        if (int rc = opal_pop_set_charge_state(s->ions, z, z, a)) return rc;  // main.rs:142-147
+    }
+    s->t = s->tstart;
+    s->total_steps = (size_t)((s->tend - s->tstart) / s->dt);  // main.rs:186 (`as usize` truncates)
+    s->steps_bt_output = s->n_outputs ? s->total_steps / s->n_outputs : 0;
+    return OPAL_OK;
+}
+
+// main.rs:23-42
+int write_energies(opal_sim_t *s, size_t index)
+{
+    double f, e, i;
+    if (int rc = opal_sim_energies(s, &f, &e, &i)) return rc;
+    if (s->rank != 0) return OPAL_OK;
+    std::string fn = s->output_dir + "/" + std::to_string(index) + "_energy.dat";
+    FILE *fp = fopen(fn.c_str(), "w");
+    if (!fp) {
+        set_error("cannot write %s", fn.c_str());
+        return OPAL_ERR_IO;
+    }
+    fprintf(fp, "em_field %s\n", rust_lower_exp_prec(f, 6).c_str());
+    fprintf(fp, "electrons %s\n", rust_lower_exp_prec(e, 6).c_str());
+    fprintf(fp, "ions %s\n", rust_lower_exp_prec(i, 6).c_str());
+    fprintf(fp, "photons %s\n", rust_lower_exp_prec(0.0, 6).c_str());
+    fclose(fp);
+    return OPAL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int opal_grid_write_data(const opal_grid_t *g, const char *dir, size_t index)
+{
+    if (!g || !dir) {
+        set_error("opal_grid_write_data: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    if (opal_grid_ngrids(g) != 1) {
+        set_error("opal_grid_write_data: single-subdomain only; gather opal_grid_interpolate() rows on rank 0 otherwise");
+        return OPAL_ERR_ARG;
+    }
+    size_t n = opal_grid_size(g);
+    std::vector<double> rows(11 * n);
+    if (int rc = opal_grid_interpolate(g, rows.data())) return rc;
+    std::string fn = std::string(dir) + "/" + std::to_string(index) + "_grid.dat";
+    FILE *fp = fopen(fn.c_str(), "w");
+    if (!fp) {
+        set_error("cannot write %s", fn.c_str());
+        return OPAL_ERR_IO;
+    }
+    for (size_t k = 0; k < n; k++) {  // yee.rs:765-773
+        const double *r = &rows[11 * k];
+        std::string line;
+        for (int c = 0; c < 10; c++) line += rust_lower_exp(r[c]) + " ";
+        line += rust_display(r[10]);
+        fprintf(fp, "%s\n", line.c_str());
+    }
+    fclose(fp);
+    return OPAL_OK;
+}
+
+int opal_design_unbalanced(int numtasks, size_t size, double dx, size_t min_subsize, size_t *nx, double *offset)
+{
+    if (numtasks < 1 || !nx || !offset) {
+        set_error("opal_design_unbalanced: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    design_unbalanced(numtasks, size, dx, min_subsize, nx, offset);
+    return OPAL_OK;
+}
+
+int opal_design_balanced(int numtasks, size_t size, double xmin, double dx, size_t min_subsize, opal_fn1 ne, void *user,
+                         size_t *nx, double *offset)
+{
+    if (numtasks < 1 || !nx || !offset || !ne) {
+        set_error("opal_design_balanced: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    if (design_balanced(numtasks, size, xmin, dx, min_subsize, [&](double x) { return ne(x, user); }, nx, offset)) {
+        set_error("balanced grid design failed: no partition point found (reference panics, grid/mod.rs:179)");
+        return OPAL_ERR_CONFIG;
+    }
+    return OPAL_OK;
+}
+
+int opal_pop_new(opal_pop_t **out, int species, size_t npc, opal_fn1 number_density, opal_fn3 ux, opal_fn3 uy,
+                 opal_fn3 uz, void *user, const opal_grid_t *grid, uint64_t seed, double dt, void *hip_stream)
+{
+    if (!out || !number_density || !ux || !uy || !uz || !grid) {
+        set_error("opal_pop_new: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    Rng rng;
+    rng.seed(seed);
+    HostSoA soa;
+    load_population(species, npc, [&](double x) { return number_density(x, user); },
+                    [&](double x, double a, double b) { return ux(x, a, b, user); },
+                    [&](double x, double a, double b) { return uy(x, a, b, user); },
+                    [&](double x, double a, double b) { return uz(x, a, b, user); }, opal_grid_xmin(grid),
+                    opal_grid_dx(grid), opal_grid_size(grid), rng, soa);
+    size_t cap = soa.size() + soa.size() / 8 + 65536;
+    if (int rc = opal_pop_create(out, species, cap, hip_stream)) return rc;
+    return opal_pop_upload_soa(*out, soa.size(), soa.cell.data(), soa.x.data(), soa.ux.data(), soa.uy.data(),
+                               soa.uz.data(), soa.w.data(), opal_grid_dx(grid), dt);
+}
+
+// ----------------------------------------------------------------------- sim
+static int sim_create_common(opal_sim_t **out, std::unique_ptr<opal_sim_t> s)
+{
+    int rc = sim_setup(s.get());
+    if (rc) {
+        opal_sim_free(s.release());
+        return rc;
+    }
+    *out = s.release();
+    return OPAL_OK;
+}
+
+int opal_sim_create(opal_sim_t **out, const char *yaml_path, int rank, int numtasks, opal_link_t *link, void *hip_stream)
+{
+    if (!out || !yaml_path || numtasks < 1 || rank < 0 || rank >= numtasks) {
+        ConfigError ce{ConfigErrorKind::MissingFile, "", ""};
+        return config_fail(ce);
+    }
+    std::unique_ptr<opal_sim_t> s(new opal_sim_t());
+    ConfigError ce;
+    if (!Config::from_file(yaml_path, s->cfg, ce)) return config_fail(ce);
+    std::string p(yaml_path);
+    size_t slash = p.find_last_of('/');
+    s->output_dir = slash == std::string::npos ? "." : p.substr(0, slash);  // main.rs:60-61
+    if (s->output_dir.empty()) s->output_dir = "/";
+    s->rank = rank; s->numtasks = numtasks; s->link = link; s->stream = hip_stream;
+    return sim_create_common(out, std::move(s));
+}
+
+int opal_sim_create_from_string(opal_sim_t **out, const char *yaml_text, const char *output_dir, int rank, int numtasks,
+                                opal_link_t *link, void *hip_stream)
+{
+    if (!out || !yaml_text || numtasks < 1 || rank < 0 || rank >= numtasks) {
+        set_error("opal_sim_create_from_string: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    std::unique_ptr<opal_sim_t> s(new opal_sim_t());
+    ConfigError ce;
+    if (!Config::from_string(yaml_text, s->cfg, ce)) return config_fail(ce);
+    s->output_dir = output_dir ? output_dir : ".";
+    s->rank = rank; s->numtasks = numtasks; s->link = link; s->stream = hip_stream;
+    return sim_create_common(out, std::move(s));
+}
+
+int opal_sim_free(opal_sim_t *s)
+{
+    if (!s) return OPAL_OK;
+    opal_pop_free(s->electrons);
+    opal_pop_free(s->ions);
+    opal_grid_free(s->grid);
+    delete s;
+    return OPAL_OK;
+}
+
+// main.rs:238-267
+int opal_sim_step(opal_sim_t *s, size_t n)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    LaserPair lp{&s->laser_y, &s->laser_z};
+    for (size_t k = 0; k < n; k++) {
+        if (s->fused && s->current_deposition) {
+            // clear first, then one pass per species that pushes and deposits
+            if (int rc = opal_grid_clear(s->grid)) return rc;
+            if (s->electrons)
+                if (int rc = opal_pop_advance_deposit(s->electrons, s->link, s->grid, s->dt)) return rc;
+            if (s->ions)
+                if (int rc = opal_pop_advance_deposit(s->ions, s->link, s->grid, s->dt)) return rc;
+        } else {
+            if (s->electrons)
+                if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) return rc;
+            if (s->ions)
+                if (int rc = opal_pop_advance(s->ions, s->link, s->grid, s->dt)) return rc;
+            if (s->current_deposition) {
+                if (int rc = opal_grid_clear(s->grid)) return rc;
+                if (s->electrons)
+                    if (int rc = opal_grid_deposit(s->grid, s->electrons, s->dt)) return rc;
+                if (s->ions)
+                    if (int rc = opal_grid_deposit(s->grid, s->ions, s->dt)) return rc;
+            }
+        }
+        if (s->has_laser) {
+            if (int rc = opal_grid_synchronize(s->grid, s->link, laser_y_cb, laser_z_cb, &lp, s->t, s->dt)) return rc;
+        } else {
+            if (int rc = opal_grid_synchronize(s->grid, s->link, nullptr, nullptr, nullptr, s->t, s->dt)) return rc;
+        }
+        if (int rc = opal_grid_advance(s->grid, s->dt)) return rc;
+        s->t += s->dt;
+    }
+    return OPAL_OK;
+}
+
+int opal_sim_sync(opal_sim_t *s)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    OPAL_HIP(hipStreamSynchronize((hipStream_t)s->stream));
+    if (s->electrons)
+        if (int rc = pop_check_err(s->electrons)) return rc;
+    if (s->ions)
+        if (int rc = pop_check_err(s->ions)) return rc;
+    return OPAL_OK;
+}
+
+int opal_sim_energies(opal_sim_t *s, double *em_field, double *electrons, double *ions)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    double f = 0, e = 0, i = 0;
+    if (int rc = opal_grid_em_field_energy(s->grid, &f)) return rc;
+    if (s->electrons)
+        if (int rc = opal_pop_total_kinetic_energy(s->electrons, &e)) return rc;
+    if (s->ions)
+        if (int rc = opal_pop_total_kinetic_energy(s->ions, &i)) return rc;
+    if (em_field) *em_field = f;
+    if (electrons) *electrons = e;
+    if (ions) *ions = i;
+    return OPAL_OK;
+}
+
+// main.rs:217-283
+int opal_sim_run(opal_sim_t *s)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    if (s->numtasks != 1) {
+        set_error("opal_sim_run writes single-subdomain output; drive multi-subdomain runs with opal_sim_step");
+        return OPAL_ERR_ARG;
+    }
+    for (size_t i = 0; i < s->n_outputs; i++) {
+        if (int rc = opal_grid_write_data(s->grid, s->output_dir.c_str(), i)) return rc;
+        if (int rc = write_energies(s, i)) return rc;
+        printf("Output %4zu at t = %s...\n", i, simulation_time(s->t).c_str());
+        fflush(stdout);
+        if (int rc = opal_sim_step(s, s->steps_bt_output)) return rc;
+        if (int rc = opal_sim_sync(s)) return rc;
+    }
+    if (int rc = opal_grid_write_data(s->grid, s->output_dir.c_str(), s->n_outputs)) return rc;
+    if (int rc = write_energies(s, s->n_outputs)) return rc;
+    printf("Output %4zu at t = %s\n", s->n_outputs, simulation_time(s->t).c_str());
+    return OPAL_OK;
+}
+
+double opal_sim_time(const opal_sim_t *s) { return s ? s->t : 0.0; }
+double opal_sim_dt(const opal_sim_t *s) { return s ? s->dt : 0.0; }
+size_t opal_sim_total_steps(const opal_sim_t *s) { return s ? s->total_steps : 0; }
+size_t opal_sim_steps_between_outputs(const opal_sim_t *s) { return s ? s->steps_bt_output : 0; }
+size_t opal_sim_n_outputs(const opal_sim_t *s) { return s ? s->n_outputs : 0; }
+opal_grid_t *opal_sim_grid(opal_sim_t *s) { return s ? s->grid : nullptr; }
+opal_pop_t *opal_sim_electrons(opal_sim_t *s) { return s ? s->electrons : nullptr; }
+opal_pop_t *opal_sim_ions(opal_sim_t *s) { return s ? s->ions : nullptr; }
+int opal_sim_set_fused(opal_sim_t *s, int fused)
+{
+    if (!s) return OPAL_ERR_ARG;
+    s->fused = fused != 0;
+    return OPAL_OK;
+}
+
+// -------------------------------------------------------------------- config
+struct opal_config {
+    Config cfg;
+};
+
+int opal_config_from_file(opal_config_t **out, const char *path)
+{
+    std::unique_ptr<opal_config_t> c(new opal_config_t());
+    ConfigError ce;
+    if (!out || !path || !Config::from_file(path, c->cfg, ce)) {
+        ce.kind = ConfigErrorKind::MissingFile;
+        return config_fail(ce);
+    }
+    c->cfg.with_context("constants");
+    *out = c.release();
+    return OPAL_OK;
+}
+
+int opal_config_from_string(opal_config_t **out, const char *text)
+{
+    std::unique_ptr<opal_config_t> c(new opal_config_t());
+    ConfigError ce;
+    if (!out || !text || !Config::from_string(text, c->cfg, ce)) {
+        ce.kind = ConfigErrorKind::MissingFile;
+        return config_fail(ce);
+    }
+    c->cfg.with_context("constants");
+    *out = c.release();
+    return OPAL_OK;
+}
+
+int opal_config_free(opal_config_t *c)
+{
+    delete c;
+    return OPAL_OK;
+}
+
+int opal_config_contains(const opal_config_t *c, const char *section) { return c && c->cfg.contains(section) ? 1 : 0; }
+
+int opal_config_read_f64(const opal_config_t *c, const char *section, const char *field, double *out)
+{
+    ConfigError ce;
+    if (!c || !c->cfg.read_f64(section, field, *out, ce)) return config_fail(ce);
+    return OPAL_OK;
+}
+
+int opal_config_read_usize(const opal_config_t *c, const char *section, const char *field, size_t *out)
+{
+    ConfigError ce;
+    if (!c || !c->cfg.read_usize(section, field, *out, ce)) return config_fail(ce);
+    return OPAL_OK;
+}
+
+int opal_config_read_bool(const opal_config_t *c, const char *section, const char *field, int *out)
+{
+    ConfigError ce;
+    bool b = false;
+    if (!c || !c->cfg.read_bool(section, field, b, ce)) return config_fail(ce);
+    *out = b ? 1 : 0;
+    return OPAL_OK;
+}
+
+int opal_config_eval(const opal_config_t *c, const char *section, const char *field, int nargs,
+                     const char *const *arg_names, const double *arg_values, double *out)
+{
+    ConfigError ce;
+    std::vector<std::string> names;
+    for (int i = 0; i < nargs; i++) names.emplace_back(arg_names[i]);
+    std::function<double(const double *)> f;
+    if (!c || !c->cfg.func(section, field, names, f, ce)) return config_fail(ce);
+    *out = f(arg_values);
+    return OPAL_OK;
+}
+
+int opal_config_eval_expr(const opal_config_t *c, const char *expr, double *out)
+{
+    std::string err;
+    if (!c || !c->cfg.eval(expr, *out, err)) {
+        set_error("could not evaluate \"%s\": %s", expr ? expr : "", err.c_str());
+        return OPAL_ERR_CONFIG;
+    }
+    return OPAL_OK;
+}
+
+// ----------------------------------------------------------------------- link
+// Multi-subdomain exchange is wired in link.cpp.
+
+}  // extern "C"
