@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-updates/s of the per-timestep PIC loop on N MI355X.
+
+One "step" = one iteration of src/main.rs:238-267 (push + deposit of every charged species, halo/
+boundary synchronisation, field solve) on synthetic two-stream input already resident in HBM.
+Per GPU the workload is BASELINE.json configs[1]: 4096 cells, 2441 electrons + 2441 positrons per
+cell (2 x 9 998 336 macro-particles), periodic, current deposition on, no QED; with N GPUs the
+domain is N x 4096 cells split into N subdomains (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused push+deposit
+pass): algorithmic bytes = 80 B per particle-update x particles per launch, divided
+by the kernel's mean duration measured with HIP events around every launch in the timed region.
+`cpu_baseline` times the CPU oracle (a port of the reference's algorithm, not the opal binary) on a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CELLS_PER_GPU = 4096
+NPC = 2441
+BYTES_PER_UPDATE = 80.0   # read cell,x,u[3],w = 44 B; write cell,x,u[3] = 36 B
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+YAML = """---
+control:
+ dx: 500
+ nx: {nx}
+ xmin: 0.0
+ start: 0.0
+ end: 1.0
+ current_deposition: true
+ n_outputs: 20
+ balance: false
+
+qed:
+ photon_emission: false
+ photon_absorption: false
+
+electrons:
+ npc: {npc}
+ ne: 20.0
+ ux: drift_u * (1.0 + 0.001 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: 0.0
+ uz: 0.0
+ output: x:px
+
+ions:
+ name: positron
+ npc: {npc}
+ Z: 1.0
+ A: me/mp
+ ni: 20.0
+ ux: drift_u * (1.0 + 0.001 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: 0.0
+ uz: 0.0
+ output: x:px
+
+constants:
+ drift_u: 2.5e-24 / (me * c)
+"""
+
+
+def cpu_baseline(oa, target_seconds=12.0):
+    """Times the oracle (OpenMP over particle chunks, one subdomain) on a bounded sample of the
+    workload: same grid, same physics, 1/10 of the particles per cell, a few steps."""
+    import numpy as np
+    from oracle import oracle as o
+
+    o.build()
+    npc_s = NPC // 10
+    sim = oa.Simulation(yaml_text=YAML.format(nx=CELLS_PER_GPU, npc=npc_s))
+    dx, dt = 500.0, sim.dt
+    se, si = sim.electrons.soa(), sim.ions.soa()
+    del sim
+    threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
+    grid = o.Grid.single(CELLS_PER_GPU, 0.0, dx)
+    pe = o.Population.from_soa(o.ELECTRON, se["cell"], se["x"], se["ux"], se["uy"], se["uz"], se["w"], dx, dt)
+    pi = o.Population.from_soa(o.ION, si["cell"], si["x"], si["ux"], si["uy"], si["uz"], si["w"], dx, dt)
+    pi.set_charge_state(1.0, 1.0, 9.109383e-31 / 1.672622e-27)
+    n = len(pe) + len(pi)
+    t0 = time.perf_counter()
+    o.world_run_periodic([grid], [pe], [pi], True, 0.0, dt, 2, threads)
+    per_step = (time.perf_counter() - t0) / 2
+    steps = int(max(3, min(200, target_seconds / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    bad = o.world_run_periodic([grid], [pe], [pi], True, 2 * dt, dt, steps, threads)
+    el = time.perf_counter() - t0
+    assert bad == 0
+    return {
+        "value": n * steps / el,
+        "unit": "particle-updates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"two_stream e-+e+, {CELLS_PER_GPU} cells, npc {npc_s}+{npc_s} ({n} particles), {steps} steps, "
+                  f"C oracle with OpenMP over {threads} particle chunks (per-step counting sort, per-chunk private "
+                  f"current arrays + serial reduce, serial field solve)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--npc", type=int, default=NPC)
+    ap.add_argument("--unfused", action="store_true", help="time the reference's operator sequence instead")
+    args = ap.parse_args()
+
+    import torch
+    import opal_amd as oa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    oa.set_device(local_rank)
+    link = None
+    if world > 1:
+        import torch.distributed as dist
+        from opal_amd.exchange import TorchLink
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        link = TorchLink(rank, world, torch.device("cuda", local_rank))
+
+    stream = torch.cuda.current_stream().cuda_stream
+    nx = CELLS_PER_GPU * world
+    sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=args.npc), rank=rank, numtasks=world, link=link,
+                        stream=stream)
+    sim.set_fused(not args.unfused)
+    n_local = len(sim.electrons) + len(sim.ions)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.step(args.warmup)
+    sim.sync()
+    oa.prof_reset()
+    oa.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    sim.step(args.steps)
+    sim.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    oa.prof_enable(False)
+
+    n_total = n_local
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([n_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        n_total = int(nn.item())
+
+    kname = "fused" if not args.unfused else "advance"
+    launches, total_ms = oa.prof_get(kname)
+    sort_launches, sort_ms = oa.prof_get("sort")
+    field_launches, field_ms = oa.prof_get("field")
+    # the dominant kernel runs once per species per step; each launch covers that species' particles
+    per_launch_particles = n_local / 2.0
+    avg_ms = total_ms / max(launches, 1)
+    achieved = BYTES_PER_UPDATE * per_launch_particles / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        out = {
+            "metric": "particle-updates/sec",
+            "value": value,
+            "unit": "particle-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"two_stream, {args.npc} e- + {args.npc} e+ per cell, {CELLS_PER_GPU} cells per GPU "
+                            f"(BASELINE configs[1] per GPU), periodic, push+deposit+field, no QED",
+                "particles_total": n_total,
+                "cells_total": nx,
+                "path": "fused advance+deposit" if not args.unfused else "advance, clear, deposit (reference order)",
+                "parallelism": f"{world} subdomain(s), 1 per GPU",
+                "frac_of_hbm_roofline_whole_step": value * BYTES_PER_UPDATE / (world * HBM_PEAK_GBS * 1e9),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_push<fused>" if not args.unfused else "k_push<advance>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "launches": launches,
+                "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * per_launch_particles,
+                "other_kernels_ms_per_step": {"field": field_ms / args.steps, "sort": sort_ms / args.steps},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            del sim
+            out["cpu_baseline"] = cpu_baseline(oa)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -241,6 +241,101 @@ Context Context::builtins()
     return c;
 }
 
+// A bound expression flattened to a stack program: names are resolved once (arguments to slots,
+// context variables to constants), so evaluating it per particle costs no lookups.
+struct Program {
+    enum Op { PushConst, PushArg, Neg, Fact, Add, Sub, Mul, Div, Rem, Pow, CallN };
+    struct Ins {
+        Op op;
+        double value;
+        int arg;
+        int nargs;
+        const NativeFn *fn;
+    };
+    std::vector<Ins> code;
+    std::vector<NativeFn> fns;
+    int max_stack = 0;
+    double run(const double *args) const
+    {
+        double st[64];
+        int sp = 0;
+        for (const Ins &in : code) {
+            switch (in.op) {
+            case PushConst: st[sp++] = in.value; break;
+            case PushArg: st[sp++] = args[in.arg]; break;
+            case Neg: st[sp - 1] = -st[sp - 1]; break;
+            case Fact: st[sp - 1] = std::tgamma(st[sp - 1] + 1.0); break;
+            case Add: sp--; st[sp - 1] = st[sp - 1] + st[sp]; break;
+            case Sub: sp--; st[sp - 1] = st[sp - 1] - st[sp]; break;
+            case Mul: sp--; st[sp - 1] = st[sp - 1] * st[sp]; break;
+            case Div: sp--; st[sp - 1] = st[sp - 1] / st[sp]; break;
+            case Rem: sp--; st[sp - 1] = std::fmod(st[sp - 1], st[sp]); break;
+            case Pow: sp--; st[sp - 1] = std::pow(st[sp - 1], st[sp]); break;
+            case CallN: {
+                static thread_local std::vector<double> av;
+                av.assign(st + sp - in.nargs, st + sp);
+                sp -= in.nargs;
+                st[sp++] = fns[(size_t)in.arg](av);
+                break;
+            }
+            }
+        }
+        return st[0];
+    }
+};
+
+static bool compile_rec(const Expr &e, const Context &ctx, const std::vector<std::string> &names, Program &p, int depth,
+                        std::string &err)
+{
+    if (depth > 48) { err = "expression too deep"; return false; }
+    auto emit = [&](Program::Op op, double v = 0.0, int arg = 0, int nargs = 0) {
+        p.code.push_back({op, v, arg, nargs, nullptr});
+    };
+    auto sub = [&](size_t k, int d) { return compile_rec(*e.args[k], ctx, names, p, d, err); };
+    switch (e.kind) {
+    case Expr::Num: emit(Program::PushConst, e.value); return true;
+    case Expr::Var: {
+        for (size_t k = 0; k < names.size(); k++)
+            if (names[k] == e.name) { emit(Program::PushArg, 0.0, (int)k); return true; }
+        auto it = ctx.vars.find(e.name);
+        if (it == ctx.vars.end()) { err = "unknown variable " + e.name; return false; }
+        emit(Program::PushConst, it->second);
+        return true;
+    }
+    case Expr::Neg: if (!sub(0, depth)) return false; emit(Program::Neg); return true;
+    case Expr::Pos: return sub(0, depth);
+    case Expr::Fact: if (!sub(0, depth)) return false; emit(Program::Fact); return true;
+    case Expr::Add: case Expr::Sub: case Expr::Mul: case Expr::Div: case Expr::Rem: case Expr::Pow: {
+        if (!sub(0, depth) || !sub(1, depth + 1)) return false;
+        Program::Op op = e.kind == Expr::Add ? Program::Add : e.kind == Expr::Sub ? Program::Sub
+                         : e.kind == Expr::Mul ? Program::Mul : e.kind == Expr::Div ? Program::Div
+                         : e.kind == Expr::Rem ? Program::Rem : Program::Pow;
+        emit(op);
+        return true;
+    }
+    case Expr::Call: {
+        auto it = ctx.funcs.find(e.name);
+        if (it == ctx.funcs.end()) { err = "unknown function " + e.name; return false; }
+        int arity = it->second.first;
+        if ((arity >= 0 && (int)e.args.size() != arity) || (arity < 0 && e.args.empty())) {
+            err = "wrong number of arguments to " + e.name;
+            return false;
+        }
+        for (size_t k = 0; k < e.args.size(); k++)
+            if (!sub(k, depth + (int)k)) return false;
+        p.fns.push_back(it->second.second);
+        emit(Program::CallN, 0.0, (int)p.fns.size() - 1, (int)e.args.size());
+        return true;
+    }
+    }
+    return false;
+}
+
+static bool compile(const Expr &e, const Context &ctx, const std::vector<std::string> &names, Program &p, std::string &err)
+{
+    return compile_rec(e, ctx, names, p, 0, err);
+}
+
 // ======================================================================= YAML
 namespace {
 
@@ -705,18 +800,10 @@ bool Config::func(const std::string &section, const std::string &field, const st
     std::string perr;
     ExprPtr e = parse_expr(n->text, perr);
     if (!e) return false;
-    // bind_with_context fails on unknown names: check by evaluating once with zeros
-    std::vector<double> zeros(args.size(), 0.0);
-    double probe;
-    if (!eval_expr(*e, ctx_, args, zeros.data(), probe, perr)) return false;
-    Context ctx = ctx_;
-    std::vector<std::string> names = args;
-    out = [e, ctx, names](const double *v) {
-        double r = NAN;
-        std::string ignored;
-        eval_expr(*e, ctx, names, v, r, ignored);
-        return r;
-    };
+    // bind_with_context resolves every name once; unknown names fail here, not at call time
+    auto prog = std::make_shared<Program>();
+    if (!compile(*e, ctx_, args, *prog, perr)) return false;
+    out = [prog](const double *v) { return prog->run(v); };
     return true;
 }
 
