@@ -79,7 +79,7 @@ def cpu_baseline(oa, target_seconds=12.0):
     dx, dt = 500.0, sim.dt
     se, si = sim.electrons.soa(), sim.ions.soa()
     del sim
-    threads = max(1, min(o.max_threads(), os.cpu_count() or 1))
+    threads = max(1, min(o.max_threads(), len(os.sched_getaffinity(0)), 16))  # a 1-GPU box gets a 16-core share
     grid = o.Grid.single(CELLS_PER_GPU, 0.0, dx)
     pe = o.Population.from_soa(o.ELECTRON, se["cell"], se["x"], se["ux"], se["uy"], se["uz"], se["w"], dx, dt)
     pi = o.Population.from_soa(o.ION, si["cell"], si["x"], si["ux"], si["uy"], si["uz"], si["w"], dx, dt)

@@ -125,6 +125,10 @@ int opal_pop_free(opal_pop_t *p);
  * SplitMix64 seeding, seed = `seed`); draw order per particle as in the reference. */
 int opal_pop_new(opal_pop_t **out, int species, size_t npc, opal_fn1 number_density, opal_fn3 ux, opal_fn3 uy,
                  opal_fn3 uz, void *user, const opal_grid_t *grid, uint64_t seed, double dt, void *hip_stream);
+/* The same loader on the host only: fills caller arrays of `capacity` entries, *n_out = particle count */
+int opal_loader_generate(int species, size_t npc, opal_fn1 number_density, opal_fn3 ux, opal_fn3 uy, opal_fn3 uz,
+                         void *user, double grid_xmin, double dx, size_t ncells, uint64_t seed, size_t capacity,
+                         size_t *n_out, int32_t *cell, double *x, double *pux, double *puy, double *puz, double *w);
 /* Ion::with_charge_state applied to every ion (main.rs:142-147, ion.rs:236-241) */
 int opal_pop_set_charge_state(opal_pop_t *p, double z_star, double z, double a);
 /* T::create for n particles (electron.rs:85-103, ion.rs:81-101): prev_x is derived from u, dx, dt */
@@ -167,7 +171,17 @@ typedef int (*opal_exchange_fn)(void *user, const void *send_left, const void *s
 int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, size_t particle_capacity,
                      opal_exchange_fn exchange, void *user, void *hip_stream);
 int opal_link_free(opal_link_t *l);
+/* bytes per direction of a whole message (halo + both species' leavers) and of its halo-only prefix;
+ * the `nbytes` passed to the exchange callback is always one of the two */
 size_t opal_link_message_bytes(const opal_link_t *l);
+size_t opal_link_halo_bytes(const opal_link_t *l);
+size_t opal_link_particle_capacity(const opal_link_t *l);
+/* Replaces the four buffers the transport sees (send_left, send_right, recv_left, recv_right) by
+ * caller-owned ones of >= opal_link_message_bytes() each -- device memory if device_buffers != 0,
+ * host memory otherwise -- so that a transport can name them in its own terms (e.g. torch tensors). */
+int opal_link_set_buffers(opal_link_t *l, void *send_left, void *send_right, void *recv_left, void *recv_right);
+/* which: 0 send_left, 1 send_right, 2 recv_left, 3 recv_right */
+void *opal_link_buffer(opal_link_t *l, int which);
 
 /* ------------------------------------------------------------------ Simulation
  * main() of the reference (src/main.rs:48-286) for the hot-path configurations:
@@ -200,6 +214,10 @@ int opal_prof_enable(int on);
 int opal_prof_reset(void);
 /* kernel ids: 0 = fused advance+deposit, 1 = advance, 2 = deposit, 3 = field solve, 4 = sort */
 int opal_prof_get(int kernel, uint64_t *launches, double *total_ms);
+
+/* Text forms used by the reference's outputs: kind 0 = SimulationTime (setup.rs:421-438), 1 = Rust {:e}
+ * (yee.rs:768), 2 = {:.6e} (main.rs:35-38), 3 = {} (yee.rs:768, last column) */
+int opal_format(int kind, double v, char *buf, size_t len);
 
 /* ------------------------------------------------------------------- Config
  * src/setup.rs: typed reads of `section.field` with the `constants` context. */

@@ -53,6 +53,8 @@ SIGNATURES = {
     "opal_pop_create": (C.c_int, [pp, C.c_int, sz, vp]),
     "opal_pop_free": (C.c_int, [vp]),
     "opal_pop_new": (C.c_int, [pp, C.c_int, sz, FN1, FN3, FN3, FN3, vp, vp, C.c_uint64, dbl, vp]),
+    "opal_loader_generate": (C.c_int, [C.c_int, sz, FN1, FN3, FN3, FN3, vp, dbl, dbl, sz, C.c_uint64, sz, C.POINTER(sz), vp, vp, vp, vp, vp, vp]),
+    "opal_format": (C.c_int, [C.c_int, dbl, C.c_char_p, sz]),
     "opal_pop_set_charge_state": (C.c_int, [vp, dbl, dbl, dbl]),
     "opal_pop_upload_soa": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, dbl, dbl]),
     "opal_pop_download_soa": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -67,6 +69,10 @@ SIGNATURES = {
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),
     "opal_link_free": (C.c_int, [vp]),
     "opal_link_message_bytes": (sz, [vp]),
+    "opal_link_halo_bytes": (sz, [vp]),
+    "opal_link_particle_capacity": (sz, [vp]),
+    "opal_link_set_buffers": (C.c_int, [vp, vp, vp, vp, vp]),
+    "opal_link_buffer": (vp, [vp, C.c_int]),
     "opal_sim_create": (C.c_int, [pp, C.c_char_p, C.c_int, C.c_int, vp, vp]),
     "opal_sim_create_from_string": (C.c_int, [pp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, vp, vp]),
     "opal_sim_free": (C.c_int, [vp]),

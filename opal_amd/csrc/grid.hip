@@ -9,6 +9,7 @@
 // Roofline: HBM-bound, 9 reads + 6 writes of 8 B per cell per step (120 B/cell);
 // at the BASELINE sizes (4 K - 33 K cells) it is launch-latency bound and costs
 // < 1 % of a step.
+#include "link.hpp"
 #include "opal_internal.hpp"
 #include "pic_device.hpp"
 
@@ -25,7 +26,7 @@ constexpr int HALO_DOUBLES = HALO_CELLS * HALO_COMPS;
 
 // yee.rs:353-354: send_left = cell[0..8], send_right = cell[len-8..len]
 __global__ void k_pack_halo(const double *__restrict__ eb, const double *__restrict__ jr, size_t lenp, int len,
-                            double *__restrict__ send)
+                            double *__restrict__ send_left, double *__restrict__ send_right)
 {
     int t = threadIdx.x;
     if (t >= 2 * HALO_DOUBLES) return;
@@ -36,7 +37,7 @@ __global__ void k_pack_halo(const double *__restrict__ eb, const double *__restr
     if (comp == 0) v = jr[3 * lenp + cellidx];                 // rho
     else if (comp < 4) v = jr[(size_t)(comp - 1) * lenp + cellidx];  // j
     else v = eb[(size_t)(comp - 4) * lenp + cellidx];          // E, B
-    send[t] = v;
+    (side == 0 ? send_left : send_right)[r] = v;
 }
 
 struct SyncArgs {
@@ -246,9 +247,9 @@ int check_grid(const opal_grid_t *g)
 
 namespace opal {
 // used by particles.hip and link.cpp
-int grid_pack_halo(opal_grid_t *g)
+int grid_pack_halo(opal_grid_t *g, double *send_left, double *send_right)
 {
-    k_pack_halo<<<1, 192, 0, g->stream>>>(g->d_eb[g->cur], g->d_j, g->lenp, (int)g->len, g->d_send);
+    k_pack_halo<<<1, 192, 0, g->stream>>>(g->d_eb[g->cur], g->d_j, g->lenp, (int)g->len, send_left, send_right);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
 }
@@ -271,6 +272,23 @@ int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_
     a.damp = g->d_damp;
     k_synchronize<<<1, 256, 0, g->stream>>>(a);
     OPAL_HIP(hipGetLastError());
+    return OPAL_OK;
+}
+
+// packs this subdomain's halo into the link's messages; with `exchange` also moves the halo part now
+// (yee.rs:358-409).  Returns device pointers to the received halos.
+int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right)
+{
+    double *sl = reinterpret_cast<double *>(link_send(link, 0) + LINK_HEADER_BYTES);
+    double *sr = reinterpret_cast<double *>(link_send(link, 1) + LINK_HEADER_BYTES);
+    if (int rc = grid_pack_halo(g, sl, sr)) return rc;
+    if (exchange) {
+        if (int rc = link_exchange(link, LINK_HEAD_BYTES, g->left_bdy == OPAL_BDY_INTERNAL,
+                                   g->right_bdy == OPAL_BDY_INTERNAL, g->stream))
+            return rc;
+    }
+    *recv_left = reinterpret_cast<const double *>(link_recv(link, 0) + LINK_HEADER_BYTES);
+    *recv_right = reinterpret_cast<const double *>(link_recv(link, 1) + LINK_HEADER_BYTES);
     return OPAL_OK;
 }
 
@@ -525,21 +543,18 @@ int opal_grid_synchronize(opal_grid_t *g, opal_link_t *link, opal_fn2 laser_y, o
         lz = 2.0 * r * laser_z(t, x, user);
     }
     bool need_halo = g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL;
-    if (need_halo) {
-        if (int rc = grid_pack_halo(g)) return rc;
-    }
     const double *recv_left = nullptr, *recv_right = nullptr;
-    if (g->ngrids == 1) {
+    if (need_halo && g->ngrids == 1) {
         // yee.rs:365-370, 390-395: a lone periodic subdomain receives its own sends
+        if (int rc = grid_pack_halo(g, g->d_send, g->d_send + HALO_DOUBLES)) return rc;
         recv_left = g->d_send + HALO_DOUBLES;  // what it sent right
         recv_right = g->d_send;                // what it sent left
-    } else {
-        extern int opal_link_exchange_halo(opal_link_t *, opal_grid_t *, const double **, const double **);
+    } else if (need_halo) {
         if (!link) {
             set_error("opal_grid_synchronize: %d subdomains need a link", g->ngrids);
             return OPAL_ERR_ARG;
         }
-        if (int rc = opal_link_exchange_halo(link, g, &recv_left, &recv_right)) return rc;
+        if (int rc = grid_exchange_halo(g, link, true, &recv_left, &recv_right)) return rc;
     }
     return grid_apply_sync(g, recv_left, recv_right, ly, lz);
 }

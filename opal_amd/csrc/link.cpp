@@ -1,32 +1,68 @@
 // Neighbour exchange between subdomains (stands in for the reference's MPI
 // point-to-point traffic: yee.rs:351-409 for the halo, particle/mod.rs:303-354
-// for migrating particles).  The library packs fixed-size messages; the
-// transport (RCCL, gloo, ...) is the callback the host supplied.
+// for migrating particles).  The library packs one fixed-layout message per
+// direction; the transport (RCCL, gloo, ...) is the callback the host supplied.
+//
+// Message layout (bytes), P = particle_capacity of the link:
+//   [0, 64)            header: uint32 count[2] (species slot 0 = electrons, 1 = ions), padding
+//   [64, 704)          halo: 8 cells x (rho jx jy jz Ex Ey Ez Bx By Bz) doubles  (yee.rs:353-354)
+//   then per species slot s = 0, 1 (each block 8-byte aligned):
+//       int32  cell[P]            re-based cell index in the receiver's frame (mod.rs:291-293, 366-368)
+//       double x[P] ux[P] uy[P] uz[P] w[P] prev_x[P]
+// A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes; anything with particles moves
+// the whole message.  What a subdomain sends left arrives as its left neighbour's "recv_right".
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
 
-#include "opal_internal.hpp"
+#include "link.hpp"
 
 using namespace opal;
 
 namespace opal {
-int grid_pack_halo(opal_grid_t *g);
+
+size_t link_species_offset(const opal_link_t *l, int slot) { return LINK_HEAD_BYTES + (size_t)slot * l->species_bytes; }
+
+char *link_send(opal_link_t *l, int side) { return side == 0 ? l->d_send_left : l->d_send_right; }
+char *link_recv(opal_link_t *l, int side) { return side == 0 ? l->d_recv_left : l->d_recv_right; }
+
+int link_begin(opal_link_t *l, hipStream_t st)
+{
+    OPAL_HIP(hipMemsetAsync(l->d_send_left, 0, LINK_HEADER_BYTES, st));
+    OPAL_HIP(hipMemsetAsync(l->d_send_right, 0, LINK_HEADER_BYTES, st));
+    return OPAL_OK;
 }
 
-struct opal_link {
-    int rank, size;
-    bool device_buffers;
-    size_t particle_capacity;
-    opal_exchange_fn exchange;
-    void *user;
-    hipStream_t stream;
-    size_t nbytes;
-    char *send_left, *send_right, *recv_left, *recv_right;      // what the callback sees
-    char *d_send_left, *d_send_right, *d_recv_left, *d_recv_right;  // device staging when host buffers are used
-};
+// Moves `nbytes` of each send buffer to the neighbours and fills the recv buffers.
+int link_exchange(opal_link_t *l, size_t nbytes, bool to_left, bool to_right, hipStream_t st)
+{
+    if (nbytes > l->nbytes) {
+        set_error("link_exchange: %zu bytes exceed the link's message size %zu", nbytes, l->nbytes);
+        return OPAL_ERR_ARG;
+    }
+    if (!l->device_buffers) {
+        if (to_left) OPAL_HIP(hipMemcpyAsync(l->h_send_left, l->d_send_left, nbytes, hipMemcpyDeviceToHost, st));
+        if (to_right) OPAL_HIP(hipMemcpyAsync(l->h_send_right, l->d_send_right, nbytes, hipMemcpyDeviceToHost, st));
+        OPAL_HIP(hipStreamSynchronize(st));
+    }
+    char *sl = l->device_buffers ? l->d_send_left : l->h_send_left;
+    char *sr = l->device_buffers ? l->d_send_right : l->h_send_right;
+    char *rl = l->device_buffers ? l->d_recv_left : l->h_recv_left;
+    char *rr = l->device_buffers ? l->d_recv_right : l->h_recv_right;
+    int rc = l->exchange(l->user, to_left ? sl : nullptr, to_right ? sr : nullptr, to_left ? rl : nullptr,
+                         to_right ? rr : nullptr, nbytes);
+    if (rc) {
+        set_error("exchange callback failed with %d", rc);
+        return OPAL_ERR_LINK;
+    }
+    if (!l->device_buffers) {
+        if (to_left) OPAL_HIP(hipMemcpyAsync(l->d_recv_left, l->h_recv_left, nbytes, hipMemcpyHostToDevice, st));
+        if (to_right) OPAL_HIP(hipMemcpyAsync(l->d_recv_right, l->h_recv_right, nbytes, hipMemcpyHostToDevice, st));
+    }
+    return OPAL_OK;
+}
 
-static const size_t HALO_BYTES = 80 * sizeof(double);
+}  // namespace opal
 
 extern "C" {
 
@@ -37,27 +73,30 @@ int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, 
         set_error("opal_link_create: bad arguments");
         return OPAL_ERR_ARG;
     }
+    if (particle_capacity == 0) particle_capacity = 4096;
+    particle_capacity = (particle_capacity + 63) / 64 * 64;
     opal_link_t *l = new opal_link_t();
     memset((void *)l, 0, sizeof *l);
     l->rank = rank;
     l->size = size;
     l->device_buffers = device_buffers != 0;
-    l->particle_capacity = particle_capacity;
+    l->cap = particle_capacity;
     l->exchange = exchange;
     l->user = user;
     l->stream = (hipStream_t)hip_stream;
-    l->nbytes = HALO_BYTES;
+    l->species_bytes = particle_capacity * (sizeof(int32_t) + 6 * sizeof(double));
+    l->nbytes = LINK_HEAD_BYTES + 2 * l->species_bytes;
     char **dev[4] = {&l->d_send_left, &l->d_send_right, &l->d_recv_left, &l->d_recv_right};
     for (auto d : dev) {
         OPAL_HIP(hipMalloc((void **)d, l->nbytes));
         OPAL_HIP(hipMemset(*d, 0, l->nbytes));
     }
-    if (l->device_buffers) {
-        l->send_left = l->d_send_left; l->send_right = l->d_send_right;
-        l->recv_left = l->d_recv_left; l->recv_right = l->d_recv_right;
-    } else {
-        char **host[4] = {&l->send_left, &l->send_right, &l->recv_left, &l->recv_right};
-        for (auto h : host) OPAL_HIP(hipHostMalloc((void **)h, l->nbytes));
+    if (!l->device_buffers) {
+        char **host[4] = {&l->h_send_left, &l->h_send_right, &l->h_recv_left, &l->h_recv_right};
+        for (auto h : host) {
+            OPAL_HIP(hipHostMalloc((void **)h, l->nbytes));
+            memset(*h, 0, l->nbytes);
+        }
     }
     *out = l;
     return OPAL_OK;
@@ -66,41 +105,55 @@ int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, 
 int opal_link_free(opal_link_t *l)
 {
     if (!l) return OPAL_OK;
-    hipFree(l->d_send_left); hipFree(l->d_send_right); hipFree(l->d_recv_left); hipFree(l->d_recv_right);
-    if (!l->device_buffers) {
-        hipHostFree(l->send_left); hipHostFree(l->send_right); hipHostFree(l->recv_left); hipHostFree(l->recv_right);
+    if (!(l->external && l->device_buffers)) {
+        hipFree(l->d_send_left); hipFree(l->d_send_right); hipFree(l->d_recv_left); hipFree(l->d_recv_right);
+    }
+    if (!l->device_buffers && !l->external) {
+        hipHostFree(l->h_send_left); hipHostFree(l->h_send_right); hipHostFree(l->h_recv_left); hipHostFree(l->h_recv_right);
     }
     delete l;
     return OPAL_OK;
 }
 
 size_t opal_link_message_bytes(const opal_link_t *l) { return l ? l->nbytes : 0; }
+size_t opal_link_halo_bytes(const opal_link_t *l) { return l ? LINK_HEAD_BYTES : 0; }
+size_t opal_link_particle_capacity(const opal_link_t *l) { return l ? l->cap : 0; }
 
-// yee.rs:358-409: this subdomain's first/last 8 cells go to its neighbours; what comes back is
-// handed to the overlay kernel.  Returns device pointers to the received halos.
-int opal_link_exchange_halo(opal_link_t *l, opal_grid_t *g, const double **recv_left, const double **recv_right)
+// Replaces the buffers the transport sees by caller-owned ones of at least opal_link_message_bytes()
+// (device memory when device_buffers != 0, host memory otherwise), e.g. torch tensors, so that the
+// transport can name them in its own terms.  Order: send_left, send_right, recv_left, recv_right.
+int opal_link_set_buffers(opal_link_t *l, void *send_left, void *send_right, void *recv_left, void *recv_right)
 {
-    bool to_left = g->left_bdy == OPAL_BDY_INTERNAL, to_right = g->right_bdy == OPAL_BDY_INTERNAL;
-    OPAL_HIP(hipMemcpyAsync(l->d_send_left, g->d_send, HALO_BYTES, hipMemcpyDeviceToDevice, g->stream));
-    OPAL_HIP(hipMemcpyAsync(l->d_send_right, g->d_send + 80, HALO_BYTES, hipMemcpyDeviceToDevice, g->stream));
-    if (!l->device_buffers) {
-        OPAL_HIP(hipMemcpyAsync(l->send_left, l->d_send_left, HALO_BYTES, hipMemcpyDeviceToHost, g->stream));
-        OPAL_HIP(hipMemcpyAsync(l->send_right, l->d_send_right, HALO_BYTES, hipMemcpyDeviceToHost, g->stream));
-        OPAL_HIP(hipStreamSynchronize(g->stream));
+    if (!l || !send_left || !send_right || !recv_left || !recv_right) {
+        set_error("opal_link_set_buffers: bad arguments");
+        return OPAL_ERR_ARG;
     }
-    int rc = l->exchange(l->user, to_left ? l->send_left : nullptr, to_right ? l->send_right : nullptr,
-                         to_left ? l->recv_left : nullptr, to_right ? l->recv_right : nullptr, HALO_BYTES);
-    if (rc) {
-        set_error("exchange callback failed with %d", rc);
-        return OPAL_ERR_LINK;
+    if (l->external) {
+        set_error("opal_link_set_buffers: buffers already replaced");
+        return OPAL_ERR_ARG;
     }
-    if (!l->device_buffers) {
-        if (to_left) OPAL_HIP(hipMemcpyAsync(l->d_recv_left, l->recv_left, HALO_BYTES, hipMemcpyHostToDevice, g->stream));
-        if (to_right) OPAL_HIP(hipMemcpyAsync(l->d_recv_right, l->recv_right, HALO_BYTES, hipMemcpyHostToDevice, g->stream));
+    if (l->device_buffers) {
+        hipFree(l->d_send_left); hipFree(l->d_send_right); hipFree(l->d_recv_left); hipFree(l->d_recv_right);
+        l->d_send_left = (char *)send_left; l->d_send_right = (char *)send_right;
+        l->d_recv_left = (char *)recv_left; l->d_recv_right = (char *)recv_right;
+    } else {
+        hipHostFree(l->h_send_left); hipHostFree(l->h_send_right); hipHostFree(l->h_recv_left); hipHostFree(l->h_recv_right);
+        l->h_send_left = (char *)send_left; l->h_send_right = (char *)send_right;
+        l->h_recv_left = (char *)recv_left; l->h_recv_right = (char *)recv_right;
     }
-    *recv_left = (const double *)l->d_recv_left;
-    *recv_right = (const double *)l->d_recv_right;
+    l->external = true;
     return OPAL_OK;
+}
+
+void *opal_link_buffer(opal_link_t *l, int which)
+{
+    if (!l) return nullptr;
+    if (l->device_buffers) {
+        char *b[4] = {l->d_send_left, l->d_send_right, l->d_recv_left, l->d_recv_right};
+        return which >= 0 && which < 4 ? b[which] : nullptr;
+    }
+    char *b[4] = {l->h_send_left, l->h_send_right, l->h_recv_left, l->h_recv_right};
+    return which >= 0 && which < 4 ? b[which] : nullptr;
 }
 
 }  // extern "C"

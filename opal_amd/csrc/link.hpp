@@ -1,0 +1,30 @@
+// Internal view of opal_link_t (see link.cpp for the message layout).
+#pragma once
+#include "opal_internal.hpp"
+
+namespace opal {
+constexpr size_t LINK_HEADER_BYTES = 64;
+constexpr size_t LINK_HALO_BYTES = 80 * sizeof(double);
+constexpr size_t LINK_HEAD_BYTES = LINK_HEADER_BYTES + LINK_HALO_BYTES;  // 704
+}  // namespace opal
+
+struct opal_link {
+    int rank, size;
+    bool device_buffers;
+    bool external;  // buffers the transport sees belong to the caller
+    size_t cap;     // particles per species per direction
+    size_t species_bytes, nbytes;
+    opal_exchange_fn exchange;
+    void *user;
+    hipStream_t stream;
+    char *d_send_left, *d_send_right, *d_recv_left, *d_recv_right;  // device side (kernels pack / unpack here)
+    char *h_send_left, *h_send_right, *h_recv_left, *h_recv_right;  // host staging when device_buffers == 0
+};
+
+namespace opal {
+size_t link_species_offset(const opal_link_t *l, int slot);
+char *link_send(opal_link_t *l, int side);
+char *link_recv(opal_link_t *l, int side);
+int link_begin(opal_link_t *l, hipStream_t st);
+int link_exchange(opal_link_t *l, size_t nbytes, bool to_left, bool to_right, hipStream_t st);
+}  // namespace opal

@@ -16,6 +16,7 @@
 //   workgroup at the end.  Algorithmic traffic 80 B per particle-update; the
 //   bound is HBM (8 TB/s -> 1.0e11 updates/s), with f64 VALU issue close
 //   behind (about 4-6 flop/B).
+#include "link.hpp"
 #include "opal_internal.hpp"
 #include "pic_device.hpp"
 
@@ -54,9 +55,10 @@ struct PushArgs {
     double dt, dt_over_dx, inv_dt, inv_dx, alpha, charge;
     int left_mode, right_mode;
     PopCounters *ctr;
-    // leaver buffers (EDGE_SEND): SoA blocks of `send_cap` particles
+    // leaver buffers (EDGE_SEND) inside the link's send messages: SoA blocks of `send_cap` particles
+    unsigned *send_count[2];
     int *send_cell[2];
-    double *send_f[2];  // x ux uy uz w, 5 x send_cap
+    double *send_f[2];  // x ux uy uz w prev_x, 6 x send_cap
     unsigned send_cap;
 };
 
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
                 a.cell[i] = DEAD_CELL;
                 atomicAdd(&a.ctr->n_deleted, 1u);
             } else if (send_side >= 0) {
-                unsigned slot = atomicAdd(send_side == 0 ? &a.ctr->n_sent_left : &a.ctr->n_sent_right, 1u);
+                unsigned slot = atomicAdd(a.send_count[send_side], 1u);
                 if (slot < a.send_cap) {
                     a.send_cell[send_side][slot] = newc;
                     double *f = a.send_f[send_side];
@@ -437,6 +439,51 @@ __global__ void k_init_prev(const int *cell, const double *x, const double *ux, 
     }
 }
 
+// Arrivals from the neighbours (mod.rs:365-373): appended behind the slots in use.  Block 0 takes what
+// the left neighbour sent right (cells already re-based by the sender, mod.rs:291-293), block 1 what the
+// right neighbour sent left (cell -1 -> += this subdomain's size, mod.rs:366-368).
+struct UnpackArgs {
+    const char *recv[2];
+    size_t species_off;
+    int slot;
+    unsigned link_cap;
+    int *cell;
+    double *f[5];
+    double *prev_x;
+    PopCounters *ctr;
+    unsigned pop_cap;
+    int my_size;
+};
+
+__global__ void k_unpack(UnpackArgs a)
+{
+    __shared__ unsigned s_base;
+    int side = blockIdx.x;
+    const char *msg = a.recv[side];
+    if (!msg) return;
+    unsigned count = reinterpret_cast<const unsigned *>(msg)[a.slot];
+    if (count > a.link_cap) count = a.link_cap;  // the sender has flagged the overflow on its side
+    if (count == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&a.ctr->n_slots, count);
+    __syncthreads();
+    unsigned base = s_base;
+    if (base + count > a.pop_cap) {
+        if (threadIdx.x == 0) {
+            atomicOr(&a.ctr->err, 16);
+            atomicSub(&a.ctr->n_slots, count);
+        }
+        return;
+    }
+    const int *rc = reinterpret_cast<const int *>(msg + a.species_off);
+    const double *rf = reinterpret_cast<const double *>(msg + a.species_off + sizeof(int) * (size_t)a.link_cap);
+    for (unsigned k = threadIdx.x; k < count; k += blockDim.x) {
+        a.cell[base + k] = rc[k] + (side == 1 ? a.my_size : 0);
+#pragma unroll
+        for (int c = 0; c < 5; c++) a.f[c][base + k] = rf[(size_t)c * a.link_cap + k];
+        if (a.prev_x) a.prev_x[base + k] = rf[(size_t)5 * a.link_cap + k];
+    }
+}
+
 int check_pop(const opal_pop_t *p)
 {
     if (!p) {
@@ -461,6 +508,10 @@ int check_pop_err(opal_pop_t *p)
         OPAL_HIP(hipMemsetAsync(&p->d_ctr->err, 0, sizeof(int), p->stream));
         if (err & 8) {
             set_error("leaver buffer overflow: more particles crossed a subdomain edge in one step than the link holds");
+            return OPAL_ERR_CAPACITY;
+        }
+        if (err & 16) {
+            set_error("population capacity exceeded by arrivals from a neighbouring subdomain");
             return OPAL_ERR_CAPACITY;
         }
         set_error("particle invariant violated on device (flags 0x%x):%s%s%s", err,
@@ -519,7 +570,6 @@ void launch_push(const PushArgs &a, unsigned nblk, bool extras, hipStream_t s)
 
 int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode)
 {
-    (void)link;
     if (p->n_upper == 0) return OPAL_OK;
     PushArgs a;
     memset(&a, 0, sizeof a);
@@ -545,9 +595,20 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     a.left_mode = edge(g->left_bdy, g->rank_to_left);
     a.right_mode = edge(g->right_bdy, g->rank_to_right);
     a.ctr = p->d_ctr;
-    if (a.left_mode == EDGE_SEND || a.right_mode == EDGE_SEND) {
-        set_error("multi-subdomain particle migration needs a link (not wired in this build path)");
-        return OPAL_ERR_ARG;
+    if (mode != MODE_DEPOSIT && (a.left_mode == EDGE_SEND || a.right_mode == EDGE_SEND)) {
+        if (!link) {
+            set_error("%d subdomains: particle migration needs a link", g->ngrids);
+            return OPAL_ERR_ARG;
+        }
+        int slot = p->species == OPAL_ELECTRON ? 0 : 1;
+        for (int side = 0; side < 2; side++) {
+            char *msg = link_send(link, side);
+            char *blk = msg + link_species_offset(link, slot);
+            a.send_count[side] = reinterpret_cast<unsigned *>(msg) + slot;
+            a.send_cell[side] = reinterpret_cast<int *>(blk);
+            a.send_f[side] = reinterpret_cast<double *>(blk + sizeof(int) * link->cap);
+        }
+        a.send_cap = (unsigned)link->cap;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
     unsigned nblk = (unsigned)((p->n_upper + per_block - 1) / per_block);
@@ -566,6 +627,62 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     prof_end(kid, p->stream);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
+}
+
+int do_sort(opal_pop_t *p, const opal_grid_t *g);
+
+// appends what the neighbours sent (already in the link's recv buffers) to this population
+int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
+{
+    bool from_left = g->left_bdy == OPAL_BDY_INTERNAL, from_right = g->right_bdy == OPAL_BDY_INTERNAL;
+    if (!from_left && !from_right) return OPAL_OK;
+    size_t incoming = ((size_t)from_left + (size_t)from_right) * link->cap;
+    if (p->n_upper + incoming > p->cap) {
+        // compact first (synchronises); the true slot count replaces the running upper bound
+        if (!p->extras && p->n_upper)
+            if (int rc = do_sort(p, g)) return rc;
+        if (p->n_upper + incoming > p->cap) {
+            set_error("population capacity %zu too small for %zu slots + %zu possible arrivals", p->cap, p->n_upper, incoming);
+            return OPAL_ERR_CAPACITY;
+        }
+    }
+    UnpackArgs u;
+    int k = p->cur;
+    u.recv[0] = from_left ? link_recv(link, 0) : nullptr;
+    u.recv[1] = from_right ? link_recv(link, 1) : nullptr;
+    u.slot = p->species == OPAL_ELECTRON ? 0 : 1;
+    u.species_off = link_species_offset(link, u.slot);
+    u.link_cap = (unsigned)link->cap;
+    u.cell = p->d_cell[k];
+    u.f[0] = p->d_x[k]; u.f[1] = p->d_ux[k]; u.f[2] = p->d_uy[k]; u.f[3] = p->d_uz[k]; u.f[4] = p->d_w[k];
+    u.prev_x = p->prev_valid ? p->d_prev_x : nullptr;
+    u.ctr = p->d_ctr;
+    u.pop_cap = (unsigned)p->cap;
+    u.my_size = (int)g->size;
+    k_unpack<<<2, 256, 0, p->stream>>>(u);
+    OPAL_HIP(hipGetLastError());
+    p->n_upper += incoming;
+    return OPAL_OK;
+}
+
+bool needs_link(const opal_grid_t *g)
+{
+    return g->ngrids > 1 && (g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL);
+}
+
+// Population::advance's exchange (mod.rs:303-354) for one species on its own: push, then one
+// whole-message exchange, then append the arrivals.
+int advance_with_exchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode)
+{
+    if (!needs_link(g)) return run_push(p, link, g, dt, mode);
+    if (!link) {
+        set_error("%d subdomains: particle migration needs a link", g->ngrids);
+        return OPAL_ERR_ARG;
+    }
+    if (int rc = link_begin(link, p->stream)) return rc;
+    if (int rc = run_push(p, link, g, dt, mode)) return rc;
+    if (int rc = link_exchange(link, link->nbytes, g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL, p->stream)) return rc;
+    return unpack_arrivals(p, link, g);
 }
 
 int do_sort(opal_pop_t *p, const opal_grid_t *g)
@@ -863,8 +980,8 @@ int opal_pop_advance(opal_pop_t *p, opal_link_t *link, const opal_grid_t *grid, 
         return OPAL_ERR_ARG;
     }
     if (int rc = ensure_prev(p)) return rc;
-    if (int rc = run_push(p, link, const_cast<opal_grid_t *>(grid), dt, MODE_ADVANCE)) return rc;
     p->prev_valid = true;
+    if (int rc = advance_with_exchange(p, link, const_cast<opal_grid_t *>(grid), dt, MODE_ADVANCE)) return rc;
     if (int rc = maybe_sort(p, grid)) return rc;
     return OPAL_OK;
 }
@@ -876,8 +993,8 @@ int opal_pop_advance_deposit(opal_pop_t *p, opal_link_t *link, opal_grid_t *grid
         set_error("opal_pop_advance_deposit: null grid");
         return OPAL_ERR_ARG;
     }
-    if (int rc = run_push(p, link, grid, dt, MODE_FUSED)) return rc;
     p->prev_valid = false;
+    if (int rc = advance_with_exchange(p, link, grid, dt, MODE_FUSED)) return rc;
     if (int rc = maybe_sort(p, grid)) return rc;
     return OPAL_OK;
 }
@@ -921,4 +1038,16 @@ int opal_pop_total_kinetic_energy(const opal_pop_t *p, double *energy)
 
 namespace opal {
 int pop_check_err(opal_pop_t *p) { return check_pop_err(p); }
+// pieces of the fused multi-subdomain step (sim.cpp): push without exchanging, then unpack after the
+// single combined exchange
+int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt)
+{
+    p->prev_valid = false;
+    return run_push(p, link, g, dt, MODE_FUSED);
+}
+int pop_unpack_and_maybe_sort(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
+{
+    if (int rc = unpack_arrivals(p, link, g)) return rc;
+    return maybe_sort(p, g);
+}
 }

@@ -14,12 +14,17 @@
 
 #include "config.hpp"
 #include "host_setup.hpp"
+#include "link.hpp"
 #include "opal_internal.hpp"
 
 using namespace opal;
 
 namespace opal {
 int pop_check_err(opal_pop_t *p);
+int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
+int pop_unpack_and_maybe_sort(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g);
+int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right);
+int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz);
 }
 
 namespace {
@@ -357,6 +362,49 @@ int opal_pop_new(opal_pop_t **out, int species, size_t npc, opal_fn1 number_dens
                                soa.uz.data(), soa.w.data(), opal_grid_dx(grid), dt);
 }
 
+// Population::new on the host only: fills caller arrays (capacity entries each) and returns the count.
+int opal_loader_generate(int species, size_t npc, opal_fn1 number_density, opal_fn3 ux, opal_fn3 uy, opal_fn3 uz,
+                         void *user, double grid_xmin, double dx, size_t ncells, uint64_t seed, size_t capacity,
+                         size_t *n_out, int32_t *cell, double *x, double *pux, double *puy, double *puz, double *w)
+{
+    if (!number_density || !ux || !uy || !uz || !n_out) {
+        set_error("opal_loader_generate: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    Rng rng;
+    rng.seed(seed);
+    HostSoA soa;
+    load_population(species, npc, [&](double xx) { return number_density(xx, user); },
+                    [&](double xx, double a, double b) { return ux(xx, a, b, user); },
+                    [&](double xx, double a, double b) { return uy(xx, a, b, user); },
+                    [&](double xx, double a, double b) { return uz(xx, a, b, user); }, grid_xmin, dx, ncells, rng, soa);
+    *n_out = soa.size();
+    if (soa.size() > capacity) {
+        set_error("opal_loader_generate: %zu particles exceed the capacity %zu", soa.size(), capacity);
+        return OPAL_ERR_CAPACITY;
+    }
+    if (cell) memcpy(cell, soa.cell.data(), sizeof(int32_t) * soa.size());
+    if (x) memcpy(x, soa.x.data(), sizeof(double) * soa.size());
+    if (pux) memcpy(pux, soa.ux.data(), sizeof(double) * soa.size());
+    if (puy) memcpy(puy, soa.uy.data(), sizeof(double) * soa.size());
+    if (puz) memcpy(puz, soa.uz.data(), sizeof(double) * soa.size());
+    if (w) memcpy(w, soa.w.data(), sizeof(double) * soa.size());
+    return OPAL_OK;
+}
+
+// SimulationTime's Display (setup.rs:421-438) and the float formats of the output files
+int opal_format(int kind, double v, char *buf, size_t len)
+{
+    std::string s = kind == 0 ? simulation_time(v) : kind == 1 ? rust_lower_exp(v) : kind == 2 ? rust_lower_exp_prec(v, 6)
+                                                                                               : rust_display(v);
+    if (!buf || len <= s.size()) {
+        set_error("opal_format: buffer too small");
+        return OPAL_ERR_ARG;
+    }
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return OPAL_OK;
+}
+
 // ----------------------------------------------------------------------- sim
 static int sim_create_common(opal_sim_t **out, std::unique_ptr<opal_sim_t> s)
 {
@@ -419,7 +467,43 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         return OPAL_ERR_ARG;
     }
     LaserPair lp{&s->laser_y, &s->laser_z};
+    const bool linked = s->numtasks > 1 && (opal_grid_to_left(s->grid) >= 0 || opal_grid_to_right(s->grid) >= 0);
+    if (linked && !s->link) {
+        set_error("%d subdomains need a link", s->numtasks);
+        return OPAL_ERR_ARG;
+    }
     for (size_t k = 0; k < n; k++) {
+        if (linked && s->fused && s->current_deposition) {
+            // One exchange per step: leavers of both species and the halo travel in the same message.
+            // Leavers have already deposited into this subdomain's ghost cells, which the halo overlay
+            // hands to the neighbour (yee.rs:424-452), so migration need not precede deposition.
+            opal_grid_t *g = s->grid;
+            hipStream_t st = (hipStream_t)s->stream;
+            if (int rc = opal_grid_clear(g)) return rc;
+            if (int rc = link_begin(s->link, st)) return rc;
+            if (s->electrons)
+                if (int rc = pop_push_fused_noexchange(s->electrons, s->link, g, s->dt)) return rc;
+            if (s->ions)
+                if (int rc = pop_push_fused_noexchange(s->ions, s->link, g, s->dt)) return rc;
+            const double *rl = nullptr, *rr = nullptr;
+            if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr)) return rc;
+            if (int rc = link_exchange(s->link, s->link->nbytes, opal_grid_to_left(g) >= 0, opal_grid_to_right(g) >= 0, st)) return rc;
+            double ly = 0.0, lz = 0.0;
+            if (s->has_laser && opal_grid_rank(g) == 0) {  // yee.rs:456-462
+                double xs = g->cell_x((size_t)(g->L - 2));
+                double r = 2.997925e8 * s->dt / s->dx;
+                ly = 2.0 * r * laser_y_cb(s->t, xs, &lp);
+                lz = 2.0 * r * laser_z_cb(s->t, xs, &lp);
+            }
+            if (int rc = grid_apply_sync(g, rl, rr, ly, lz)) return rc;
+            if (s->electrons)
+                if (int rc = pop_unpack_and_maybe_sort(s->electrons, s->link, g)) return rc;
+            if (s->ions)
+                if (int rc = pop_unpack_and_maybe_sort(s->ions, s->link, g)) return rc;
+            if (int rc = opal_grid_advance(g, s->dt)) return rc;
+            s->t += s->dt;
+            continue;
+        }
         if (s->fused && s->current_deposition) {
             // clear first, then one pass per species that pushes and deposits
             if (int rc = opal_grid_clear(s->grid)) return rc;

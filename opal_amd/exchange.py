@@ -1,0 +1,96 @@
+"""Neighbour exchange over torch.distributed (RCCL on GPUs, gloo on CPUs).
+
+Replaces the reference's MPI point-to-point traffic (yee.rs:351-409 halo, particle/mod.rs:303-354
+migrating particles): every subdomain talks to its left and right neighbour only, each pair over
+its own direct xGMI link, so there is no collective on the step path.
+
+`NeighbourTransport` is the pure torch.distributed part (usable without a GPU); `TorchLink` binds
+it to the C library's opal_link_t, whose fixed-layout messages it moves.
+"""
+import ctypes as C
+import sys
+import traceback
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+TAG_LEFTWARD = 11   # a message travelling to the left neighbour (its recv_right)
+TAG_RIGHTWARD = 12  # a message travelling to the right neighbour (its recv_left)
+
+
+class NeighbourTransport:
+    """send_left -> left neighbour's recv_right, send_right -> right neighbour's recv_left.
+
+    With two subdomains and periodic boundaries both neighbours are the same peer: sends are issued
+    (left, right) and receives (right, left) so that the k-th message to a peer matches the k-th
+    receive posted there (RCCL/NCCL matches per peer in issue order; gloo also gets distinct tags).
+    """
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.left = (rank - 1 + world) % world
+        self.right = (rank + 1) % world
+
+    def exchange(self, send_left, send_right, recv_left, recv_right):
+        """Each argument is a 1-D tensor view of the bytes to move, or None to skip that direction."""
+        ops = []
+        if send_left is not None:
+            ops.append(dist.P2POp(dist.isend, send_left, self.left, self.group, TAG_LEFTWARD))
+        if send_right is not None:
+            ops.append(dist.P2POp(dist.isend, send_right, self.right, self.group, TAG_RIGHTWARD))
+        if recv_right is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_right, self.right, self.group, TAG_LEFTWARD))
+        if recv_left is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_left, self.left, self.group, TAG_RIGHTWARD))
+        if not ops:
+            return
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+class TorchLink:
+    """opal_link_t whose transport is torch.distributed.
+
+    device: torch.device("cuda", i) with the nccl (= RCCL) backend moves device buffers, stream-ordered
+    with torch's current stream (which must be the stream the simulation was created on);
+    torch.device("cpu") stages through host buffers (gloo), for rehearsals on one GPU.
+    """
+
+    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None):
+        self._lib = _lib.load()
+        self.transport = NeighbourTransport(rank, world, group)
+        self.device = torch.device(device)
+        device_buffers = 1 if self.device.type == "cuda" else 0
+        self._cb = _lib.EXCHANGE_FN(self._exchange)  # keep alive
+        h = C.c_void_p()
+        rc = self._lib.opal_link_create(C.byref(h), rank, world, device_buffers, particle_capacity, self._cb, None, stream)
+        if rc:
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        self.h = h
+        self.nbytes = self._lib.opal_link_message_bytes(h)
+        kw = {"dtype": torch.uint8, "device": self.device}
+        self.bufs = [torch.zeros(self.nbytes, **kw) for _ in range(4)]  # send_left, send_right, recv_left, recv_right
+        if self.device.type == "cpu" and torch.cuda.is_available():
+            self.bufs = [b.pin_memory() for b in self.bufs]
+        rc = self._lib.opal_link_set_buffers(h, *[C.c_void_p(b.data_ptr()) for b in self.bufs])
+        if rc:
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        self.calls = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._lib.opal_link_free(self.h)
+            self.h = None
+
+    def _exchange(self, user, send_left, send_right, recv_left, recv_right, nbytes):
+        try:
+            sl, sr, rl, rr = self.bufs
+            self.transport.exchange(sl[:nbytes] if send_left else None, sr[:nbytes] if send_right else None,
+                                    rl[:nbytes] if recv_left else None, rr[:nbytes] if recv_right else None)
+            self.calls += 1
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            traceback.print_exc(file=sys.stderr)
+            return 1

@@ -1,0 +1,114 @@
+"""One rank of a decomposed HIP run; ranks share cuda:0 and exchange through gloo (host staging).
+mode "ops": operator-level calls with a link, from a global seeded state.
+mode "sim": the YAML driver's fused step (one exchange per step)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import opal_amd as oa  # noqa: E402
+from _decomp_common import A_POSITRON, C, global_state, split  # noqa: E402
+from opal_amd.exchange import TorchLink  # noqa: E402
+
+YAML = """---
+control:
+ dx: 1.0e-8
+ nx: {nx}
+ xmin: 0.0
+ start: 0.0
+ end: 1.0e-12
+ current_deposition: true
+ n_outputs: 2
+ balance: false
+qed:
+ photon_emission: false
+ photon_absorption: false
+electrons:
+ npc: {npc}
+ ne: 1.0e27
+ ux: 0.2 * (1.0 + 0.05 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: 0.01 * nrand
+ uz: 0.01 * nrand
+ output: x:px
+ions:
+ name: positron
+ npc: {npc}
+ Z: 1.0
+ A: me/mp
+ ni: 1.0e27
+ ux: 0.2 * (1.0 + 0.05 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: 0.01 * nrand
+ uz: 0.01 * nrand
+ output: x:px
+"""
+
+
+def dump(outdir, rank, g, pe, pi, extra=None):
+    out = {k: g.raw(k) for k in ("Ex", "Ey", "Ez", "By", "Bz", "jx", "jy", "jz", "rho")}
+    for name, p in (("e", pe), ("i", pi)):
+        for k, v in p.soa().items():
+            out[f"{name}_{k}"] = v
+    out["fe"] = g.em_field_energy()
+    out["ke_e"] = pe.total_kinetic_energy()
+    out["ke_i"] = pi.total_kinetic_energy()
+    if extra:
+        out.update(extra)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+
+
+def main():
+    mode, outdir = sys.argv[1], sys.argv[2]
+    nx, npc, steps, fused = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oa.set_device(0)
+    link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=128) if world > 1 else None
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    if mode == "ops":
+        nxs, offs = oa.design_unbalanced(world, nx, dx)
+        g = oa.Grid(rank, world, oa.BDY_INTERNAL, oa.BDY_INTERNAL, 0.0, dx, nxs, offs)
+        se, si = global_state(nx, npc, dx, 5), global_state(nx, npc, dx, 6)
+        pe = oa.Population.from_soa(oa.ELECTRON, *split(se, nxs, rank), dx, dt, capacity=4 * nx * npc)
+        pi = oa.Population.from_soa(oa.ION, *split(si, nxs, rank), dx, dt, capacity=4 * nx * npc)
+        pi.set_charge_state(1.0, 1.0, A_POSITRON)
+        t = 0.0
+        for _ in range(steps):
+            if fused:
+                g.clear()
+                pe.advance_deposit(g, dt, link)
+                pi.advance_deposit(g, dt, link)
+            else:
+                pe.advance(g, dt, link)
+                pi.advance(g, dt, link)
+                g.clear()
+                g.deposit(pe, dt)
+                g.deposit(pi, dt)
+            g.synchronize(None, None, t, dt, link)
+            g.advance(dt)
+            t += dt
+        dump(outdir, rank, g, pe, pi)
+    else:
+        sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc), rank=rank, numtasks=world, link=link)
+        sim.set_fused(bool(fused))
+        init = {}
+        for name, p in (("e", sim.electrons), ("i", sim.ions)):
+            for k, v in p.soa().items():
+                init[f"init_{name}_{k}"] = v
+        sim.step(steps)
+        sim.sync()
+        dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
+        if link is not None:
+            assert link.calls == (steps if fused else 3 * steps), link.calls
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

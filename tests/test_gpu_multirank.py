@@ -1,0 +1,86 @@
+"""Decomposed HIP runs (2 and 3 ranks sharing cuda:0, gloo transport with host staging) against
+the oracle run with the same decomposition, and against the 1-subdomain HIP run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _decomp_common import A_POSITRON, C, global_state, split  # noqa: E402
+from test_exchange_gloo import _launch  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+COMPS = ("Ex", "Ey", "Ez", "By", "Bz")
+
+
+def _oracle_world(o, world, nx, dx, dt, states_e, states_i, steps):
+    nxs, offs = o.design_unbalanced(world, nx, dx)
+    grids = [o.Grid(r, world, 0, 0, 0.0, dx, nxs, offs) for r in range(world)]
+    pes = [o.Population.from_soa(o.ELECTRON, *states_e[r], dx, dt) for r in range(world)]
+    pis = [o.Population.from_soa(o.ION, *states_i[r], dx, dt) for r in range(world)]
+    for p in pis:
+        p.set_charge_state(1.0, 1.0, A_POSITRON)
+    t = 0.0
+    for _ in range(steps):
+        assert o.world_step(grids, pes, pis, True, t, dt) == 0
+        t += dt
+    return grids, pes, pis
+
+
+def _by_w(d, prefix):
+    order = np.argsort(d[f"{prefix}_w"], kind="stable")
+    return {k: d[f"{prefix}_{k}"][order] for k in ("cell", "x", "ux", "w")}
+
+
+@pytest.mark.parametrize("world,fused", [(2, 1), (2, 0), (3, 1)])
+def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused):
+    o = oracle
+    nx, npc, steps = 48, 12, 12
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    _launch("_gloo_hip_worker.py", world, ["ops", tmp_path, nx, npc, steps, fused])
+    nxs, _ = o.design_unbalanced(world, nx, dx)
+    se, si = global_state(nx, npc, dx, 5), global_state(nx, npc, dx, 6)
+    grids, pes, pis = _oracle_world(o, world, nx, dx, dt, [split(se, nxs, r) for r in range(world)],
+                                    [split(si, nxs, r) for r in range(world)], steps)
+    total = 0
+    for r in range(world):
+        got = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        for k in COMPS:
+            ref = grids[r].raw(k)
+            scale = max(np.max(np.abs(ref)), 1e-300)
+            assert np.max(np.abs(got[k] - ref)) / scale < 1e-9, (r, k)
+        for name, p in (("e", pes[r]), ("i", pis[r])):
+            ref = p.soa()
+            order = np.argsort(ref["w"], kind="stable")
+            a = _by_w(got, name)
+            assert np.array_equal(a["w"], ref["w"][order]), (r, name)  # same particles on the same rank
+            assert np.array_equal(a["cell"], ref["cell"][order].astype(np.int32))
+            assert np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
+        total += len(got["e_w"])
+    assert total == nx * npc
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world):
+    """The YAML driver's linked step (leavers of both species + halo in ONE message per neighbour)."""
+    o = oracle
+    nx, npc, steps = 64, 16, 15
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    _launch("_gloo_hip_worker.py", world, ["sim", tmp_path, nx, npc, steps, 1])
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    st_e = [tuple(g[f"init_e_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
+    st_i = [tuple(g[f"init_i_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
+    grids, pes, pis = _oracle_world(o, world, nx, dx, dt, st_e, st_i, steps)
+    for r in range(world):
+        for k in COMPS:
+            ref = grids[r].raw(k)
+            scale = max(np.max(np.abs(ref)), 1e-300)
+            assert np.max(np.abs(got[r][k] - ref)) / scale < 1e-9, (r, k)
+        assert abs(got[r]["ke_e"] - pes[r].total_kinetic_energy()) / pes[r].total_kinetic_energy() < 1e-11
+        assert len(got[r]["e_w"]) == len(pes[r]) and len(got[r]["i_w"]) == len(pis[r])
+    assert sum(len(g["e_w"]) for g in got) == nx * npc

@@ -1,0 +1,214 @@
+"""CPU-only tests of the product's host side: the C ABI exports what include/opal_amd.h declares,
+the config layer reproduces src/setup.rs (incl. its own unit tests), GridDesign and the loader match
+the oracle bit for bit, and the compute entry points fail loudly when there is no GPU."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_EXAMPLES = "/root/reference/examples"
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "opal_amd", "lib", "libopal_amd.so")):
+        ge.build()
+    import opal_amd
+    return opal_amd
+
+
+def test_abi_exports_every_declared_symbol(oa):
+    from opal_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "opal_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(opal_[a-z0-9_]+)\s*\(", header))
+    declared -= {"opal_fn1", "opal_fn2", "opal_fn3", "opal_exchange_fn"}
+    assert len(declared) > 60
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in opal_amd.h but not exported"
+    # and the Python binding knows every one of them
+    assert declared <= set(_lib.SIGNATURES), declared - set(_lib.SIGNATURES)
+
+
+def test_no_gpu_fails_loudly(oa):
+    """No silent CPU fallback: without a device the compute objects cannot even be created."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(oa.OpalError) as e:
+        oa.Grid.single(64, 0.0, 1.0)
+    assert e.value.status == 2
+    with pytest.raises(oa.OpalError):
+        oa.Population(oa.ELECTRON, 1024)
+    with pytest.raises(oa.OpalError):
+        oa.device_count()
+
+
+CONFIG_TEXT = """---
+        control:
+          dx: 0.001
+          nx: 4000
+          ne: sin(a * x)
+          ib: a * b^3
+
+        extra:
+          dx: 160
+
+        constants:
+          a: 2.0 * pi
+          b: 17.0
+        """
+
+
+def test_config_parser(oa):
+    """setup.rs:446-484 (config_parser)"""
+    c = oa.Config(text=CONFIG_TEXT)
+    assert c.read_f64("control", "dx") == 0.001
+    assert c.read_usize("control", "nx") == 4000
+    assert c.read_f64("control", "ib") == 2.0 * math.pi * 17.0 ** 3
+    assert c.read_f64("extra", "dx") == 160.0
+    ne = c.func("control", "ne", ["x"])
+    assert ne(0.6) == math.sin(2.0 * math.pi * 0.6)
+
+
+def test_time_format(oa):
+    """setup.rs:486-492 (time_format) and the float formats of the output files"""
+    lib = oa._lib.load()
+    buf = C.create_string_buffer(64)
+
+    def fmt(kind, v):
+        assert lib.opal_format(kind, v, buf, 64) == 0
+        return buf.value.decode()
+
+    assert fmt(0, 2.6e-4) == "  260.00 μs"
+    assert fmt(1, 1.0) == "1e0" and fmt(1, -2.5e-7) == "-2.5e-7" and fmt(1, 0.0) == "0e0" and fmt(1, 1234.5) == "1.2345e3"
+    assert fmt(2, 1.2345678e-3) == "1.234568e-3" and fmt(2, 0.0) == "0.000000e0"
+    assert fmt(3, 0.0) == "0" and fmt(3, 1.5) == "1.5" and fmt(3, 1e-6) == "0.000001" and fmt(3, 1e21) == "1" + "0" * 21
+
+
+def test_config_errors_and_typing(oa):
+    """ConfigError kinds (setup.rs:33-61) and the typed reads (setup.rs:287-370)."""
+    c = oa.Config(text=CONFIG_TEXT)
+    with pytest.raises(oa.OpalError) as e:
+        c.read_f64("nope", "dx")
+    assert 'Could not find section "nope"' in str(e.value)
+    with pytest.raises(oa.OpalError) as e:
+        c.read_f64("control", "nope")
+    assert 'Could not find field "nope" in section "control"' in str(e.value)
+    with pytest.raises(oa.OpalError) as e:
+        c.read_usize("control", "dx")  # a Real is not a usize
+    assert "Could not convert" in str(e.value)
+    with pytest.raises(oa.OpalError):
+        c.read_bool("control", "nx")
+    # an Integer constant is silently ignored by with_context (setup.rs:165-175)
+    c2 = oa.Config(text="control:\n a: k * 2.0\nconstants:\n k: 3\n")
+    with pytest.raises(oa.OpalError):
+        c2.read_f64("control", "a")
+    c3 = oa.Config(text="control:\n a: k * 2.0\n b: -2^2\n c: 2^-1\n d: 7 % 4\nconstants:\n k: 3.0\n")
+    assert c3.read_f64("control", "a") == 6.0
+    assert c3.read_f64("control", "b") == -4.0   # unary minus binds looser than ^ (meval)
+    assert c3.read_f64("control", "c") == 0.5
+    assert c3.read_f64("control", "d") == 3.0
+    # constants cannot depend on each other (setup.rs:160)
+    c4 = oa.Config(text="control:\n a: q\nconstants:\n p: 2.0\n q: p * 2.0\n")
+    with pytest.raises(oa.OpalError):
+        c4.read_f64("control", "a")
+    # built-ins of with_context: e is the elementary charge, gauss is un-normalised
+    assert c3.eval("e") == 1.602177e-19
+    assert c3.eval("gauss(1.0, 1.0, 3.0)") == 1.0
+    assert c3.eval("step(0.5, 0.0, 1.0) + step(1.0, 0.0, 1.0)") == 1.0
+    assert c3.eval("critical(1.0)") == 8.854188e-12 * 9.109383e-31 / 1.602177e-19 ** 2
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference examples not present")
+def test_reference_examples_parse(oa):
+    """The three shipped input files are accepted unchanged (docs/input.md)."""
+    c = oa.Config(path=os.path.join(REF_EXAMPLES, "two_stream.yaml"))
+    assert c.read_usize("control", "nx") == 1000 and c.read_f64("control", "dx") == 500.0
+    assert not c.contains("laser") and c.read_bool("control", "current_deposition")
+    ux = c.func("electrons", "ux", ["x", "urand", "nrand"])
+    ud = 2.5e-24 / (9.109383e-31 * 2.997925e8)
+    assert ux(0.0, 0.7, 0.5) == ud * (1.0 + 0.001 * 0.5) * (2.0 * math.floor(0.7 - 0.5) + 1.0)
+    assert ux(0.0, 0.2, 0.0) == -ud
+
+    c = oa.Config(path=os.path.join(REF_EXAMPLES, "hole_boring.yaml"))
+    assert c.contains("laser") and c.read_usize("control", "nx") == 20000
+    assert c.read_f64("control", "dx") == 1.0e-6 / 1000
+    omega = 2 * math.pi * 2.997925e8 / 0.8e-6
+    ne = c.func("electrons", "ne", ["x"])
+    crit = 8.854188e-12 * 9.109383e-31 * omega ** 2 / 1.602177e-19 ** 2
+    assert ne(1.0e-6) == 100.0 * crit * 1.0 and ne(-1.0e-6) == 0.0 and ne(5.0e-6) == 0.0
+    assert c.read_f64("ions", "Z") == 6.0 and c.read_f64("ions", "A") == 12.0
+    ey = c.func("laser", "Ey", ["t", "x"])
+    assert math.isfinite(ey(1e-15, 0.0)) and ey(1e-15, 0.0) != 0.0
+
+    c = oa.Config(path=os.path.join(REF_EXAMPLES, "colliding_beams.yaml"))
+    ey = c.func("laser", "Ey", ["t", "x"])  # a folded block scalar
+    a0, w = 20.0, 2 * math.pi * 2.997925e8 / 0.8e-6
+    t = 3.0e-16
+    phi = w * (t - 0.0 / 2.997925e8)
+    want = (a0 * 9.109383e-31 * 2.997925e8 * w / 1.602177e-19) * math.sin(phi) * math.exp(-math.log(2.0) * phi ** 2 / (2.0 * math.pi ** 2 * 4.0 ** 2))
+    assert abs(ey(t, 0.0) - want) <= 1e-12 * abs(want)
+    assert c.read_f64("qed", "photon_angle_max") == 50 * 1e-3
+
+
+def test_design_matches_oracle(oa, oracle):
+    """GridDesign::unbalanced / balanced (grid/mod.rs:126-206) against the oracle, bit for bit."""
+    o = oracle
+    for ntasks, size in [(1, 1000), (3, 1000), (8, 32768), (7, 50)]:
+        a, b = oa.design_unbalanced(ntasks, size, 0.25), o.design_unbalanced(ntasks, size, 0.25)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert oa.design_unbalanced(3, 1000, 1.0)[0].sum() == 999  # remainder cells are dropped (:128)
+    ne = lambda x: 100.0 if 0.0 <= x < 5.0e-6 else 0.0  # hole_boring's profile
+    for ntasks in (1, 2, 4, 8):
+        a = oa.design_balanced(ntasks, 20000, -10e-6, 1e-9, ne)
+        b = o.design_balanced(ntasks, 20000, -10e-6, 1e-9, ne)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert a[0].sum() == 20000 and a[0].min() >= 8
+    with pytest.raises(oa.OpalError):
+        oa.design_balanced(13, 100, 0.0, 1.0, lambda x: 1.0 if x < 10 else 0.0)  # reference panics (:179)
+
+
+def test_loader_matches_oracle(oa, oracle):
+    """Population::new (mod.rs:172-203): same RNG stream, draw order, weights and empty-cell rule."""
+    o = oracle
+    lib = oa._lib.load()
+    from opal_amd._lib import FN1, FN3
+    nx, npc, dx = 40, 7, 500.0
+    ud = 2.5e-24 / (9.109383e-31 * 2.997925e8)
+    dens = lambda x: 20.0 if x > 3000.0 else 0.0  # leaves the first cells empty
+    fux = lambda x, ur, nr: ud * (1.0 + 0.001 * nr) * (2.0 * math.floor(ur - 0.5) + 1.0)
+    fuy = lambda x, ur, nr: 0.1 * nr
+    fuz = lambda x, ur, nr: x * 1e-9 + ur
+    for species in (0, 1):
+        cap = nx * npc
+        cell = np.zeros(cap, np.int32)
+        arrs = [np.zeros(cap) for _ in range(5)]
+        n = C.c_size_t()
+        cbs = (FN1(lambda x, u: dens(x)), FN3(lambda x, a, b, u: fux(x, a, b)), FN3(lambda x, a, b, u: fuy(x, a, b)),
+               FN3(lambda x, a, b, u: fuz(x, a, b)))
+        rc = lib.opal_loader_generate(species, npc, *cbs, None, 0.0, dx, nx, 3, cap, C.byref(n), cell.ctypes.data,
+                                      *[a.ctypes.data for a in arrs])
+        assert rc == 0
+        g = o.Grid.single(nx, 0.0, dx)
+        op = o.Population.new(species, npc, dens, fux, fuy, fuz, g, o.RNG(3), 0.95 * dx / 2.997925e8)
+        ref = op.soa()
+        assert n.value == len(op) == (nx - 6) * npc
+        assert np.array_equal(cell[:n.value], ref["cell"].astype(np.int32))
+        for a, k in zip(arrs, ("x", "ux", "uy", "uz", "w")):
+            assert np.array_equal(a[:n.value], ref[k]), k
+
+
+def test_rng_known_answers(oracle):
+    """xoshiro256** seeded via SplitMix64: first outputs for seed 0 (public reference values of the
+    generator: splitmix64(0) state then xoshiro256starstar)."""
+    r = oracle.RNG(0)
+    # state after SplitMix64 seeding with 0
+    assert [int(v) for v in r.s.s] == [0xe220a8397b1dcdaf, 0x6e789e6aa1b965f4, 0x06c45d188009454f, 0xf88bb8a8724c81ec]
+    assert r.next_u64() == 0x99ec5f36cb75f2b4
