@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libopal_amd.so")
+LIB_PATH = os.environ.get("OPAL_AMD_LIB") or os.path.join(_HERE, "lib", "libopal_amd.so")
 
 FN1 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
 FN2 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)

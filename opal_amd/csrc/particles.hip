@@ -34,7 +34,10 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int TILE = 16;        // cells in a workgroup's LDS tile
-constexpr int REPL = 32;        // lane-private replicas per accumulator
+#ifndef OPAL_REPL
+#define OPAL_REPL 32
+#endif
+constexpr int REPL = OPAL_REPL;        // lane-private replicas per accumulator
 constexpr int TILE_LO = 3;      // a particle whose old cell sits at tile offset in [TILE_LO, TILE - 4]
 constexpr int TILE_HI = TILE - 4;  // gathers (rel-1..rel+2) and deposits (rel-3..rel+3) inside the tile
 
@@ -56,6 +59,9 @@ struct PushArgs {
     int left_mode, right_mode;
     PopCounters *ctr;
     // leaver buffers (EDGE_SEND) inside the link's send messages: SoA blocks of `send_cap` particles
+#ifdef OPAL_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: [block][8] timeline stamps
+#endif
     unsigned *send_count[2];
     int *send_cell[2];
     double *send_f[2];  // x ux uy uz w prev_x, 6 x send_cap
@@ -113,6 +119,125 @@ __device__ inline void scatter_global(double *jr, size_t lenp, int idx, const Ta
     }
 }
 
+// Per-chunk view of the particle arrays: block-uniform base pointers (scalar registers) indexed
+// with a 32-bit slot offset.
+struct ChunkPtrs {
+    int *cell;
+    double *x, *ux, *uy, *uz;
+    const double *w;
+    double *prev;
+    size_t chunk0;
+};
+
+// The per-particle body shared by the three modes.  FAST = the particle's stencil lies inside the
+// workgroup's LDS tile (fields from LDS, currents into the LDS accumulators); otherwise fields come
+// from global memory and the taps go to the grid with global atomics.
+template <int SPECIES, int MODE, bool RHO, bool EXTRAS, bool FAST>
+__device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkPtrs &cp, const double *s_field,
+                                                 double *s_acc, int base, int lane, unsigned kc, int c, double xi,
+                                                 V3 u, double wt, double prev, int &err)
+{
+    constexpr bool GATHER = MODE != MODE_DEPOSIT;
+    constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
+    int newc = c, rel, idx;
+    double xn = xi, gam;
+    if (GATHER) {
+        rel = c + a.L - base;
+        V3 E, B;
+        if (FAST) {
+            LdsFields f{s_field};
+            gather(f, rel, xi, E, B);
+        } else {
+            GlobalFields f{a.eb, a.lenp};
+            gather(f, c + a.L, xi, E, B);
+        }
+        Pushed r;
+        if (SPECIES == OPAL_ELECTRON) {
+            double gamma_old = sqrt(1.0 + dot(u, u));
+            r = vay_push<EXTRAS>(u, gamma_old, E, B, a.alpha, a.dt_over_dx, a.dt);
+            if (EXTRAS) {
+                size_t i = cp.chunk0 + kc;
+                a.chi[i] = r.chi;
+                a.work[i] += r.dwork;
+                a.y[i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
+                a.z[i] += r.v_old.z * a.dt;
+            }
+        } else {
+            r = boris_push(u, E, B, a.alpha, a.dt_over_dx);
+        }
+        if (!(r.dxi < 1.0)) err |= 1;  // electron.rs:313, ion.rs:199
+        u = r.u;
+        gam = r.gamma;
+        // electron.rs:311-329 / ion.rs:197-213
+        xn = xi + r.dxi;
+        double fl = floor(xn);
+        int s = fl < 0.0 ? -1 : (fl > 0.0 ? 1 : 0);
+        prev = xi - fl;
+        xn = xn - fl;
+        newc = c + s;
+        idx = c + a.L + s;
+        rel = rel + s;
+    } else {
+        gam = sqrt(1.0 + dot(u, u));  // electron.rs:148-151 uses the stored gamma; ion.rs:123-126: 1 + gamma_m1
+        if (SPECIES == OPAL_ION) gam = 1.0 + dot(u, u) / (1.0 + gam);
+        idx = c + a.L;
+        rel = idx - base;
+    }
+
+    // leavers: mod.rs:273-278, 291-293, 308-354; yee.rs:329-343
+    bool deleted = false;
+    int send_side = -1;
+    if (GATHER) {
+        if (newc < 0) {
+            if (a.left_mode == EDGE_WRAP) newc += a.size;
+            else if (a.left_mode == EDGE_DELETE) deleted = true;
+            else send_side = 0;
+        } else if (newc >= a.size) {
+            if (a.right_mode == EDGE_WRAP) newc -= a.size;
+            else if (a.right_mode == EDGE_DELETE) deleted = true;
+            else { send_side = 1; newc -= a.size; }  // mod.rs:291-293
+        }
+    }
+
+    if (DEPOSIT && !deleted) {
+        double macrocharge = wt * a.charge;
+        double inv_g = 1.0 / gam;
+        double vy = SPEED_OF_LIGHT * u.y * inv_g, vz = SPEED_OF_LIGHT * u.z * inv_g;
+        Taps t = deposit_taps<RHO>(xn, prev, macrocharge, vy, vz, a.inv_dt, a.inv_dx);
+        if (FAST) scatter_lds<RHO>(s_acc, rel, lane, t);
+        else scatter_global<RHO>(a.jr, a.lenp, idx, t);
+    }
+
+    if (GATHER) {
+        if (deleted) {
+            cp.cell[kc] = DEAD_CELL;
+            atomicAdd(&a.ctr->n_deleted, 1u);
+        } else if (send_side >= 0) {
+            unsigned slot = atomicAdd(a.send_count[send_side], 1u);
+            if (slot < a.send_cap) {
+                a.send_cell[send_side][slot] = newc;
+                double *f = a.send_f[send_side];
+                f[0 * (size_t)a.send_cap + slot] = xn;
+                f[1 * (size_t)a.send_cap + slot] = u.x;
+                f[2 * (size_t)a.send_cap + slot] = u.y;
+                f[3 * (size_t)a.send_cap + slot] = u.z;
+                f[4 * (size_t)a.send_cap + slot] = wt;
+                if (MODE == MODE_ADVANCE) f[5 * (size_t)a.send_cap + slot] = prev;
+            } else {
+                err |= 8;
+            }
+            cp.cell[kc] = DEAD_CELL;
+        } else {
+            cp.cell[kc] = newc;
+            cp.x[kc] = xn;
+            cp.ux[kc] = u.x;
+            cp.uy[kc] = u.y;
+            cp.uz[kc] = u.z;
+            if (MODE == MODE_ADVANCE) cp.prev[kc] = prev;
+        }
+    }
+}
+
 // One workgroup = BLOCK x ppt consecutive particle slots.
 //   MODE_ADVANCE : Population::advance's per-particle body, mod.rs:268-279 (gather, push, leaver
 //                  detection); stores prev_x for a later deposit.
@@ -125,178 +250,174 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
     __shared__ double s_field[GATHER ? 6 * TILE : 1];
     __shared__ double s_acc[DEPOSIT ? 4 * TILE * REPL : 1];
-    __shared__ int s_min[BLOCK / 64];
+    __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & (REPL - 1);
+#ifdef OPAL_STAMPS
+#define STAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    if (a.stamps && tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#else
+#define STAMP(k)
+#endif
+    STAMP(0);
     const unsigned n = a.ctr->n_slots;
     const size_t chunk0 = (size_t)blockIdx.x * BLOCK * a.ppt;
     if (chunk0 >= n) return;
 
-    // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin
+    ChunkPtrs cp;
+    cp.cell = a.cell + chunk0;
+    cp.x = a.x + chunk0; cp.ux = a.ux + chunk0; cp.uy = a.uy + chunk0; cp.uz = a.uz + chunk0;
+    cp.w = a.w + chunk0;
+    cp.prev = (MODE != MODE_FUSED) ? a.prev_x + chunk0 : nullptr;
+    cp.chunk0 = chunk0;
+    const unsigned nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
+
+    // The first slot's loads go out before anything else: its cell also decides the tile base, and the
+    // other five values are in flight while the tile is set up.
+    unsigned k = tid;
+    bool have = k < nloc;
+    int c_n = DEAD_CELL;
+    double x_n = 0.0, ux_n = 0.0, uy_n = 0.0, uz_n = 0.0, w_n = 0.0, prev_n = 0.0;
+    if (have) {
+        c_n = cp.cell[k]; x_n = cp.x[k]; ux_n = cp.ux[k]; uy_n = cp.uy[k]; uz_n = cp.uz[k]; w_n = cp.w[k];
+        if (MODE == MODE_DEPOSIT) prev_n = cp.prev[k];
+    }
+    // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin.  Slots that
+    // hold far-away cells (particles that wrapped around a periodic domain, arrivals appended from both
+    // neighbours) must not drag the tile away from the bulk: when the cells of the first slots span more
+    // than a tile, the base is taken from the more populous half of that span.
     {
-        size_t i = chunk0 + tid;
-        int c = i < n ? a.cell[i] : DEAD_CELL;
-        int m = c == DEAD_CELL ? 0x7fffffff : c;
+        const bool lv = c_n != DEAD_CELL;
+        int m = lv ? c_n : 0x7fffffff, M = lv ? c_n : (int)0x80000000;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
-        if ((tid & 63) == 0) s_min[tid >> 6] = m;
+        for (int o = 32; o > 0; o >>= 1) {
+            m = min(m, __shfl_xor(m, o));
+            M = max(M, __shfl_xor(M, o));
+        }
+        if ((tid & 63) == 0) {
+            s_min[tid >> 6] = m;
+            s_max[tid >> 6] = M;
+        }
     }
     if (DEPOSIT)
-        for (int k = tid; k < 4 * TILE * REPL; k += BLOCK) s_acc[k] = 0.0;
+        for (int q = tid; q < 4 * TILE * REPL; q += BLOCK) s_acc[q] = 0.0;
     __syncthreads();
     int cmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+    const int cmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    if (cmin != 0x7fffffff && cmax - cmin > TILE_HI - TILE_LO) {  // block-uniform
+        const int mid = cmin + (cmax - cmin) / 2;
+        const bool lv = c_n != DEAD_CELL;
+        const bool high = lv && c_n > mid;
+        int mh = high ? c_n : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mh = min(mh, __shfl_xor(mh, o));
+        int nh = __popcll(__ballot(high)), nl = __popcll(__ballot(lv && !high));
+        __syncthreads();  // everyone has read s_min / s_max
+        if ((tid & 63) == 0) {
+            s_min[tid >> 6] = mh;
+            s_max[tid >> 6] = nh - nl;
+        }
+        __syncthreads();
+        int votes = s_max[0] + s_max[1] + s_max[2] + s_max[3];
+        if (votes > 0) cmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+    }
     const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - 4;  // array index of tile cell 0
     if (GATHER) {
-        for (int k = tid; k < 6 * TILE; k += BLOCK) {
-            int comp = k / TILE, j = base + (k % TILE);
-            s_field[k] = (j >= 0 && j < a.len) ? a.eb[(size_t)comp * a.lenp + j] : 0.0;
+        for (int q = tid; q < 6 * TILE; q += BLOCK) {
+            int comp = q / TILE, j = base + (q % TILE);
+            s_field[q] = (j >= 0 && j < a.len) ? a.eb[(size_t)comp * a.lenp + j] : 0.0;
         }
         __syncthreads();
     }
-
-    unsigned slow = 0;
+    STAMP(1);
     int err = 0;
+    // A single periodic subdomain: a particle that wrapped around sits in a chunk at the other end of
+    // the array.  Its periodic image (cell -1 or `size`, i.e. a ghost cell: E and B there are copies
+    // of the interior, and synchronize folds the currents back) lies inside this chunk's tile.
+    const bool periodic = a.left_mode == EDGE_WRAP && a.right_mode == EDGE_WRAP;
+
+    // Main loop, software-pipelined: the next slot's 44 bytes are requested before the current particle
+    // is processed, so HBM latency overlaps this lane's own arithmetic instead of relying on occupancy
+    // alone.  Only particles whose stencil lies inside the LDS tile are processed here; the others are
+    // remembered in a bit mask and taken in the second loop, which keeps every global access of this
+    // loop a streaming one (precise vmcnt waits, no drain of the prefetch).
+    unsigned pending = 0;
     for (int p = 0; p < a.ppt; p++) {
-        size_t i = chunk0 + (size_t)p * BLOCK + tid;
-        if (i >= n) break;
-        int c = a.cell[i];
-        if (c == DEAD_CELL) continue;
-        double xi = a.x[i];
-        V3 u = {a.ux[i], a.uy[i], a.uz[i]};
-        double wt = a.w[i];
-
-        int newc = c, rel, idx;
-        double xn = xi, prev = 0.0, gam;
-        bool in_tile;
+        const unsigned kc = k;
+        const bool live = have && c_n != DEAD_CELL;
+        int c = c_n;
+        const double xi = x_n, wt = w_n, prev = prev_n;
+        const V3 u = {ux_n, uy_n, uz_n};
+        k += BLOCK;
+        have = (p + 1 < a.ppt) && k < nloc;
+        if (have) {
+            c_n = cp.cell[k]; x_n = cp.x[k]; ux_n = cp.ux[k]; uy_n = cp.uy[k]; uz_n = cp.uz[k]; w_n = cp.w[k];
+            if (MODE == MODE_DEPOSIT) prev_n = cp.prev[k];
+        }
+        if (!live) continue;
+        int rel = c + a.L - base;
+        bool ok, in_tile;
+        constexpr int LO = GATHER ? TILE_LO : 2, HI = GATHER ? TILE_HI : TILE - 3, REACH = GATHER ? 3 : 2;
         if (GATHER) {
-            if ((unsigned)c >= (unsigned)a.size) {  // yee.rs:501-502
-                err |= 2;
-                continue;
-            }
-            rel = c + a.L - base;
-            in_tile = rel >= TILE_LO && rel <= TILE_HI;
-            V3 E, B;
-            if (in_tile) {
-                LdsFields f{s_field};
-                gather(f, rel, xi, E, B);
-            } else {
-                GlobalFields f{a.eb, a.lenp};
-                gather(f, c + a.L, xi, E, B);
-                slow++;
-            }
-            Pushed r;
-            if (SPECIES == OPAL_ELECTRON) {
-                double gamma_old = sqrt(1.0 + dot(u, u));
-                r = vay_push<EXTRAS>(u, gamma_old, E, B, a.alpha, a.dt_over_dx, a.dt);
-                if (EXTRAS) {
-                    a.chi[i] = r.chi;
-                    a.work[i] += r.dwork;
-                    a.y[i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
-                    a.z[i] += r.v_old.z * a.dt;
-                }
-            } else {
-                r = boris_push(u, E, B, a.alpha, a.dt_over_dx);
-            }
-            if (!(r.dxi < 1.0)) err |= 1;  // electron.rs:313, ion.rs:199
-            u = r.u;
-            gam = r.gamma;
-            // electron.rs:311-329 / ion.rs:197-213
-            xn = xi + r.dxi;
-            double fl = floor(xn);
-            int s = fl < 0.0 ? -1 : (fl > 0.0 ? 1 : 0);
-            prev = xi - fl;
-            xn = xn - fl;
-            newc = c + s;
-            idx = c + a.L + s;
-            rel = rel + s;
+            ok = (unsigned)c < (unsigned)a.size;  // yee.rs:501-502
+            if (!ok) err |= 2;
         } else {
-            prev = a.prev_x[i];
-            gam = sqrt(1.0 + dot(u, u));  // electron.rs:148-151 uses the stored gamma; ion.rs:123-126: 1 + gamma_m1
-            if (SPECIES == OPAL_ION) gam = 1.0 + dot(u, u) / (1.0 + gam);
-            idx = c + a.L;
-            rel = idx - base;
-            in_tile = rel >= 2 && rel <= TILE - 3;
-            if (idx < 2 || idx >= a.len - 2) {  // yee.rs:578-579
-                err |= 4;
-                continue;
+            int idx = c + a.L;
+            ok = idx >= 2 && idx < a.len - 2;  // yee.rs:578-579
+            if (!ok) err |= 4;
+        }
+        if (!ok) continue;
+        in_tile = rel >= LO && rel <= HI;
+        if (!in_tile && periodic) {
+            int c2 = rel > HI ? c - a.size : c + a.size;
+            int rel2 = c2 + a.L - base, j2 = c2 + a.L;
+            if (rel2 >= LO && rel2 <= HI && j2 >= REACH && j2 + REACH < a.len) {
+                c = c2;
+                in_tile = true;
             }
         }
-
-        // leavers: mod.rs:273-278, 291-293, 308-354; yee.rs:329-343
-        bool deleted = false;
-        int send_side = -1;
-        if (GATHER) {
-            if (newc < 0) {
-                if (a.left_mode == EDGE_WRAP) newc += a.size;
-                else if (a.left_mode == EDGE_DELETE) deleted = true;
-                else send_side = 0;
-            } else if (newc >= a.size) {
-                if (a.right_mode == EDGE_WRAP) newc -= a.size;
-                else if (a.right_mode == EDGE_DELETE) deleted = true;
-                else { send_side = 1; newc -= a.size; }  // mod.rs:291-293
-            }
-        }
-
-        if (DEPOSIT && !deleted) {
-            double macrocharge = wt * a.charge;
-            double inv_g = 1.0 / gam;
-            double vy = SPEED_OF_LIGHT * u.y * inv_g, vz = SPEED_OF_LIGHT * u.z * inv_g;
-            Taps t = deposit_taps<RHO>(xn, prev, macrocharge, vy, vz, a.inv_dt, a.inv_dx);
-            if (in_tile) {
-                scatter_lds<RHO>(s_acc, rel, lane, t);
-            } else {
-                scatter_global<RHO>(a.jr, a.lenp, idx, t);
-                if (!GATHER) slow++;
-            }
-        }
-
-        if (GATHER) {
-            if (deleted) {
-                a.cell[i] = DEAD_CELL;
-                atomicAdd(&a.ctr->n_deleted, 1u);
-            } else if (send_side >= 0) {
-                unsigned slot = atomicAdd(a.send_count[send_side], 1u);
-                if (slot < a.send_cap) {
-                    a.send_cell[send_side][slot] = newc;
-                    double *f = a.send_f[send_side];
-                    f[0 * (size_t)a.send_cap + slot] = xn;
-                    f[1 * (size_t)a.send_cap + slot] = u.x;
-                    f[2 * (size_t)a.send_cap + slot] = u.y;
-                    f[3 * (size_t)a.send_cap + slot] = u.z;
-                    f[4 * (size_t)a.send_cap + slot] = wt;
-                    if (MODE == MODE_ADVANCE) f[5 * (size_t)a.send_cap + slot] = prev;
-                } else {
-                    err |= 8;
-                }
-                a.cell[i] = DEAD_CELL;
-            } else {
-                a.cell[i] = newc;
-                a.x[i] = xn;
-                a.ux[i] = u.x;
-                a.uy[i] = u.y;
-                a.uz[i] = u.z;
-                if (MODE == MODE_ADVANCE) a.prev_x[i] = prev;
-            }
-        }
+        if (in_tile) process_particle<SPECIES, MODE, RHO, EXTRAS, true>(a, cp, s_field, s_acc, base, lane, kc, c, xi, u, wt, prev, err);
+        else pending |= 1u << p;
     }
-    if (slow) atomicAdd(&a.ctr->n_slow, slow);
+    STAMP(2);
+    // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.
+    if (pending) {
+        unsigned slow = 0;
+        for (int p = 0; p < a.ppt; p++) {
+            if (!(pending & (1u << p))) continue;
+            unsigned kc = (unsigned)p * BLOCK + tid;
+            V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
+            double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
+            process_particle<SPECIES, MODE, RHO, EXTRAS, false>(a, cp, s_field, s_acc, base, lane, kc, cp.cell[kc], cp.x[kc], u, cp.w[kc], prev, err);
+            slow++;
+        }
+        atomicAdd(&a.ctr->n_slow, slow);
+    }
     if (err) atomicOr(&a.ctr->err, err);
 
     if (DEPOSIT) {
         __syncthreads();
+        STAMP(3);
         // fold the REPL replicas of each (component, cell) and add to the grid: one lane per accumulator,
         // rotated start so that the 64 lanes of a wave read 64 different banks.
         constexpr int NACC = (RHO ? 4 : 3) * TILE;
-        for (int k = tid; k < NACC; k += BLOCK) {
+        for (int k2 = tid; k2 < NACC; k2 += BLOCK) {
             double s = 0.0;
-            const double *row = s_acc + k * REPL;
+            const double *row = s_acc + k2 * REPL;
 #pragma unroll 8
             for (int r = 0; r < REPL; r++) s += row[(r + tid) & (REPL - 1)];
-            int comp = k / TILE, j = base + (k % TILE);
+            int comp = k2 / TILE, j = base + (k2 % TILE);
             if (s != 0.0 && j >= 0 && j < a.len) atomicAdd(a.jr + (size_t)comp * a.lenp + j, s);
         }
     }
+    STAMP(4);
 }
 
 // ------------------------------------------------------------------ re-binning
@@ -612,6 +733,19 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
     unsigned nblk = (unsigned)((p->n_upper + per_block - 1) / per_block);
+#ifdef OPAL_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    static int stamp_launch = 0;
+    a.stamps = nullptr;
+    if (getenv("OPAL_DEBUG_STAMPS") && mode == MODE_FUSED && p->species == OPAL_ELECTRON) {
+        stamp_launch++;
+        if (stamp_launch == 30) {
+            hipMalloc(&d_stamps, sizeof(unsigned long long) * 8 * nblk);
+            hipMemset(d_stamps, 0, sizeof(unsigned long long) * 8 * nblk);
+            a.stamps = d_stamps;
+        }
+    }
+#endif
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, p->stream);
     bool ex = p->extras;
@@ -626,6 +760,20 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     }
     prof_end(kid, p->stream);
     OPAL_HIP(hipGetLastError());
+#ifdef OPAL_STAMPS
+    if (a.stamps) {
+        std::vector<unsigned long long> h((size_t)8 * nblk);
+        hipStreamSynchronize(p->stream);
+        hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        FILE *fp = fopen(getenv("OPAL_DEBUG_STAMPS"), "w");
+        for (unsigned b = 0; b < nblk; b++) {
+            fprintf(fp, "%u", b);
+            for (int k = 0; k < 8; k++) fprintf(fp, " %llu", h[(size_t)b * 8 + k]);
+            fprintf(fp, "\n");
+        }
+        fclose(fp);
+    }
+#endif
     return OPAL_OK;
 }
 
@@ -777,6 +925,7 @@ int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_st
     p->z_star = p->z = p->a = 1.0;  // ion.rs:93-95
     p->sort_interval = -1;
     p->ppt = 8;
+    if (const char *e = getenv("OPAL_DEBUG_PPT")) p->ppt = std::max(1, std::min(32, atoi(e)));
     if (int rc = alloc_set(p, 0)) return rc;
     OPAL_HIP(hipMalloc(&p->d_ctr, sizeof(PopCounters)));
     OPAL_HIP(hipHostMalloc(&p->h_ctr, sizeof(PopCounters)));
