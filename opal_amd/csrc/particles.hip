@@ -90,17 +90,25 @@ __device__ inline void glb_add(double *p, double v)
 template <bool RHO>
 __device__ inline void scatter_lds(double *acc, int rel, int lane, const Taps &t)
 {
-    // acc[comp][cell][replica]
+    // acc[comp][cell][replica].  Taps that are nearly always non-zero are added unconditionally; the
+    // outer jx taps (non-zero only for a particle that crossed a cell) and the transverse currents
+    // (zero for a whole species in 1-D electrostatic problems) are skipped when no lane needs them.
     double *a = acc + lane;
+    lds_add(a + ((0 * TILE + rel - 2) * REPL), t.jx[0]);
 #pragma unroll
-    for (int k = 0; k < 5; k++) lds_add(a + ((0 * TILE + rel + k - 2) * REPL), t.jx[k]);
+    for (int k = 1; k < 4; k++) atomicAdd(a + ((0 * TILE + rel + k - 2) * REPL), t.jx[k]);
+    lds_add(a + ((0 * TILE + rel + 2) * REPL), t.jx[4]);
+    if (t.jy[1] != 0.0) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) lds_add(a + ((1 * TILE + rel + k - 1) * REPL), t.jy[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(a + ((1 * TILE + rel + k - 1) * REPL), t.jy[k]);
+    }
+    if (t.jz[1] != 0.0) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) lds_add(a + ((2 * TILE + rel + k - 1) * REPL), t.jz[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(a + ((2 * TILE + rel + k - 1) * REPL), t.jz[k]);
+    }
     if (RHO) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) lds_add(a + ((3 * TILE + rel + k - 2) * REPL), t.rho[k]);
+        for (int k = 0; k < 4; k++) atomicAdd(a + ((3 * TILE + rel + k - 2) * REPL), t.rho[k]);
     }
 }
 

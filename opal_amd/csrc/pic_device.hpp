@@ -67,7 +67,30 @@ __host__ __device__ inline double flux(double x_i, double x_f)
     return opposite ? diff : same;
 }
 
-// The seven gather weights of fields_at, yee.rs:504-526
+// The two polynomial pieces of Cell::weight (yee.rs:145,147) for callers that know the range of
+// their argument, which spares the compares and selects of the general form.
+__host__ __device__ inline double w_inner(double xhat) { return 0.75 - xhat * xhat; }                          // xhat < 0.5
+__host__ __device__ inline double w_outer(double xhat) { return 1.125 - 1.5 * xhat + 0.5 * (xhat * xhat); }    // 0.5 <= xhat <= 1.5
+
+// weight(1+x), weight(x), weight(1-x), weight(2-x) for an offset x in [0, 1] (the stored offsets:
+// electron.rs:319-329 / ion.rs:203-213 leave x - floor(x)).  Which polynomial applies follows from x
+// alone; at the break points (x = 0.5) both pieces agree, so the choice there is immaterial.
+struct EdgeW {
+    double e0, e1, e2, e3;
+};
+__host__ __device__ inline EdgeW edge_weights(double x)
+{
+    EdgeW w;
+    const bool lo = x < 0.5;
+    const double a2 = 1.0 - x;
+    w.e0 = x > 0.5 ? 0.0 : w_outer(1.0 + x);        // 1+x in [1, 2]: zero beyond 1.5
+    w.e1 = lo ? w_inner(x) : w_outer(x);            // x in [0, 1]
+    w.e2 = a2 < 0.5 ? w_inner(a2) : w_outer(a2);    // 1-x in [0, 1]
+    w.e3 = (2.0 - x) > 1.5 ? 0.0 : w_outer(2.0 - x);  // 2-x in [1, 2]
+    return w;
+}
+
+// The seven gather weights of fields_at, yee.rs:504-526, for an offset xi in [0, 1]
 struct GatherW {
     double c0, c1, c2;      // centred quantities (Ex, By, Bz): cells j-1, j, j+1
     double e0, e1, e2, e3;  // edge quantities (Ey, Ez): cells j-1 .. j+2
@@ -75,13 +98,14 @@ struct GatherW {
 __host__ __device__ inline GatherW gather_weights(double xi)
 {
     GatherW g;
-    g.c0 = weight(0.5 + xi);
-    g.c1 = weight(0.5 - xi);
-    g.c2 = weight(1.5 - xi);
-    g.e0 = weight(1.0 + xi);
-    g.e1 = weight(xi);
-    g.e2 = weight(1.0 - xi);
-    g.e3 = weight(2.0 - xi);
+    g.c0 = w_outer(0.5 + xi);        // 0.5+xi in [0.5, 1.5]
+    g.c1 = w_inner(fabs(0.5 - xi));  // |0.5-xi| <= 0.5
+    g.c2 = w_outer(1.5 - xi);        // 1.5-xi in [0.5, 1.5]
+    EdgeW e = edge_weights(xi);
+    g.e0 = e.e0;
+    g.e1 = e.e1;
+    g.e2 = e.e2;
+    g.e3 = e.e3;
     return g;
 }
 
@@ -186,7 +210,8 @@ __device__ inline Taps deposit_taps(double x, double prev_x, double macrocharge,
     t.jx[0] = macrocharge * flux(-1.5 - prev_x, -1.5 - x) * inv_dt;
     t.jx[3] = macrocharge * flux(1.5 - prev_x, 1.5 - x) * inv_dt;
     t.jx[4] = macrocharge * flux(2.5 - prev_x, 2.5 - x) * inv_dt;
-    double w0 = weight(1.0 + x), w1 = weight(x), w2 = weight(1.0 - x);
+    EdgeW ew = edge_weights(x);
+    double w0 = ew.e0, w1 = ew.e1, w2 = ew.e2;
     double qy = macrocharge * vy, qz = macrocharge * vz;
     t.jy[0] = qy * w0 * inv_dx;
     t.jy[1] = qy * w1 * inv_dx;
@@ -195,7 +220,7 @@ __device__ inline Taps deposit_taps(double x, double prev_x, double macrocharge,
     t.jz[1] = qz * w1 * inv_dx;
     t.jz[2] = qz * w2 * inv_dx;
     if (RHO) {
-        t.rho[0] = macrocharge * weight(2.0 - x) * inv_dx;
+        t.rho[0] = macrocharge * ew.e3 * inv_dx;
         t.rho[1] = macrocharge * w0 * inv_dx;
         t.rho[2] = macrocharge * w1 * inv_dx;
         t.rho[3] = macrocharge * w2 * inv_dx;
