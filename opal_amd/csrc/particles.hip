@@ -148,7 +148,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
     constexpr bool GATHER = MODE != MODE_DEPOSIT;
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
     int newc = c, rel, idx;
-    double xn = xi, gam;
+    double xn = xi, inv_g;
     if (GATHER) {
         rel = c + a.L - base;
         V3 E, B;
@@ -161,8 +161,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         }
         Pushed r;
         if (SPECIES == OPAL_ELECTRON) {
-            double gamma_old = sqrt(1.0 + dot(u, u));
-            r = vay_push<EXTRAS>(u, gamma_old, E, B, a.alpha, a.dt_over_dx, a.dt);
+            r = vay_push<EXTRAS>(u, E, B, a.alpha, a.dt_over_dx, a.dt);
             if (EXTRAS) {
                 size_t i = cp.chunk0 + kc;
                 a.chi[i] = r.chi;
@@ -175,7 +174,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         }
         if (!(r.dxi < 1.0)) err |= 1;  // electron.rs:313, ion.rs:199
         u = r.u;
-        gam = r.gamma;
+        inv_g = r.inv_gamma;
         // electron.rs:311-329 / ion.rs:197-213
         xn = xi + r.dxi;
         double fl = floor(xn);
@@ -186,8 +185,9 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         idx = c + a.L + s;
         rel = rel + s;
     } else {
-        gam = sqrt(1.0 + dot(u, u));  // electron.rs:148-151 uses the stored gamma; ion.rs:123-126: 1 + gamma_m1
+        double gam = sqrt(1.0 + dot(u, u));  // electron.rs:148-151 uses the stored gamma; ion.rs:123-126: 1 + gamma_m1
         if (SPECIES == OPAL_ION) gam = 1.0 + dot(u, u) / (1.0 + gam);
+        inv_g = 1.0 / gam;
         idx = c + a.L;
         rel = idx - base;
     }
@@ -209,7 +209,6 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
 
     if (DEPOSIT && !deleted) {
         double macrocharge = wt * a.charge;
-        double inv_g = 1.0 / gam;
         double vy = SPEED_OF_LIGHT * u.y * inv_g, vz = SPEED_OF_LIGHT * u.z * inv_g;
         Taps t = deposit_taps<RHO>(xn, prev, macrocharge, vy, vz, a.inv_dt, a.inv_dx);
         if (FAST) scatter_lds<RHO>(s_acc, rel, lane, t);

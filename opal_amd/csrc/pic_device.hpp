@@ -67,6 +67,19 @@ __host__ __device__ inline double flux(double x_i, double x_f)
     return opposite ? diff : same;
 }
 
+// Cell::flux for the two outermost taps of the deposit (boundaries at -1.5 and 2.5 cells from the
+// left edge of the particle's cell): with the final offset x in [0, 1] the boundary is at least 1.5
+// cells from the particle's final position, so |x_f| >= 1 always and only the first and last arms of
+// the reference can fire: the result is 0.5 (1 - |x_i|)^2 for |x_i| < 1, else 0, with the sign of the
+// displacement (see flux()).
+__host__ __device__ inline double flux_outer(double x_i, double displacement)
+{
+    double a = fabs(x_i);
+    double ca = 1.0 - a;
+    double pa = a < 1.0 ? 0.5 * (ca * ca) : 0.0;
+    return copysign(pa, displacement);
+}
+
 // The two polynomial pieces of Cell::weight (yee.rs:145,147) for callers that know the range of
 // their argument, which spares the compares and selects of the general form.
 __host__ __device__ inline double w_inner(double xhat) { return 0.75 - xhat * xhat; }                          // xhat < 0.5
@@ -126,22 +139,34 @@ __host__ __device__ inline void gather(const F &f, int j, double xi, V3 &E, V3 &
 // Result of one push: new momentum, Lorentz factor, displacement in cells.
 struct Pushed {
     V3 u;
-    double gamma;  // electrons: Vay gamma; ions: 1 + gamma_m1
+    double gamma;      // electrons: Vay gamma; ions: 1 + gamma_m1
+    double inv_gamma;  // 1 / gamma, shared by the displacement and the deposit's velocity
     double dxi;
     // electron diagnostics (only meaningful when requested)
     double chi, dwork;
     V3 v_old;
 };
 
+// 1/sqrt(a) to within an ulp: hardware estimate (v_rsq_f64, ~2^-26 relative) plus two Newton steps.
+// Used where the reference takes a square root only to divide by it.
+__device__ inline double rsqrt_nr(double a)
+{
+    double y = __builtin_amdgcn_rsq(a);
+    double h = 0.5 * a;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
 // Electron::vay_push, electron.rs:268-330 (momentum + displacement part).
-// `gamma_old` is the Lorentz factor the reference carries in the struct; the
-// caller recomputes it as sqrt(1 + u.u) (equal to the stored value up to
-// rounding) so that gamma never travels through HBM.
+// The reference carries gamma in the struct and divides by it; here 1/gamma_old
+// is recomputed as 1/sqrt(1 + u.u) (equal up to rounding) so that gamma never
+// travels through HBM.
 template <bool EXTRAS>
-__device__ inline Pushed vay_push(V3 u, double gamma_old, V3 E, V3 B, double alpha, double dt_over_dx, double dt)
+__device__ inline Pushed vay_push(V3 u, V3 E, V3 B, double alpha, double dt_over_dx, double dt)
 {
     Pushed r;
-    double inv_g = 1.0 / gamma_old;
+    double inv_g = rsqrt_nr(1.0 + dot(u, u));
     V3 v = {SPEED_OF_LIGHT * u.x * inv_g, SPEED_OF_LIGHT * u.y * inv_g, SPEED_OF_LIGHT * u.z * inv_g};
     V3 u_half = u + alpha * (E + cross(v, B));
     if (EXTRAS) {
@@ -159,12 +184,14 @@ __device__ inline Pushed vay_push(V3 u, double gamma_old, V3 E, V3 B, double alp
     double u_star = dot(u_prime, tau);
     double tau2 = dot(tau, tau);
     double sigma = gamma_prime_sqd - tau2;
-    double gamma = sqrt(0.5 * sigma + sqrt(0.25 * (sigma * sigma) + tau2 + u_star * u_star));
-    double inv_gn = 1.0 / gamma;
+    double g2 = 0.5 * sigma + sqrt(0.25 * (sigma * sigma) + tau2 + u_star * u_star);
+    double inv_gn = rsqrt_nr(g2);
+    double gamma = g2 * inv_gn;
     V3 t = inv_gn * tau;
     double s = 1.0 / (1.0 + dot(t, t));
     r.u = s * (u_prime + dot(u_prime, t) * t + cross(u_prime, t));
     r.gamma = gamma;
+    r.inv_gamma = inv_gn;
     r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx * inv_gn;
     return r;
 }
@@ -185,7 +212,8 @@ __device__ inline Pushed boris_push(V3 u, V3 E, V3 B, double alpha, double dt_ov
     double un2 = dot(r.u, r.u);
     double gamma_m1 = un2 / (1.0 + sqrt(1.0 + un2));
     r.gamma = 1.0 + gamma_m1;
-    r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx / r.gamma;
+    r.inv_gamma = 1.0 / r.gamma;
+    r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx * r.inv_gamma;
     return r;
 }
 
@@ -207,9 +235,9 @@ __device__ inline Taps deposit_taps(double x, double prev_x, double macrocharge,
     Taps t;
     t.jx[2] = macrocharge * flux(0.5 - prev_x, 0.5 - x) * inv_dt;
     t.jx[1] = macrocharge * flux(-0.5 - prev_x, -0.5 - x) * inv_dt;
-    t.jx[0] = macrocharge * flux(-1.5 - prev_x, -1.5 - x) * inv_dt;
+    t.jx[0] = macrocharge * flux_outer(-1.5 - prev_x, x - prev_x) * inv_dt;
     t.jx[3] = macrocharge * flux(1.5 - prev_x, 1.5 - x) * inv_dt;
-    t.jx[4] = macrocharge * flux(2.5 - prev_x, 2.5 - x) * inv_dt;
+    t.jx[4] = macrocharge * flux_outer(2.5 - prev_x, x - prev_x) * inv_dt;
     EdgeW ew = edge_weights(x);
     double w0 = ew.e0, w1 = ew.e1, w2 = ew.e2;
     double qy = macrocharge * vy, qz = macrocharge * vz;
