@@ -184,7 +184,8 @@ __device__ inline Pushed vay_push(V3 u, V3 E, V3 B, double alpha, double dt_over
     double u_star = dot(u_prime, tau);
     double tau2 = dot(tau, tau);
     double sigma = gamma_prime_sqd - tau2;
-    double g2 = 0.5 * sigma + sqrt(0.25 * (sigma * sigma) + tau2 + u_star * u_star);
+    double rad = 0.25 * (sigma * sigma) + tau2 + u_star * u_star;  // > 0: tau2 and sigma cannot both vanish
+    double g2 = 0.5 * sigma + rad * rsqrt_nr(rad);
     double inv_gn = rsqrt_nr(g2);
     double gamma = g2 * inv_gn;
     V3 t = inv_gn * tau;
@@ -203,16 +204,16 @@ __device__ inline Pushed boris_push(V3 u, V3 E, V3 B, double alpha, double dt_ov
     V3 cB = SPEED_OF_LIGHT * B;
     V3 u_minus = u + alpha * E;
     double um2 = dot(u_minus, u_minus);
-    double gamma = 1.0 + um2 / (1.0 + sqrt(1.0 + um2));
-    double t = alpha / gamma;
+    // ion.rs:183 writes gamma as 1 + u^2 / (1 + sqrt(1 + u^2)), which is sqrt(1 + u^2); t = alpha / gamma
+    double t = alpha * rsqrt_nr(1.0 + um2);
     V3 u_prime = u_minus + t * cross(u_minus, cB);
     double t_prime = 2.0 * t / (1.0 + (t * t) * dot(cB, cB));
     V3 u_plus = u_minus + t_prime * cross(u_prime, cB);
     r.u = u_plus + alpha * E;
-    double un2 = dot(r.u, r.u);
-    double gamma_m1 = un2 / (1.0 + sqrt(1.0 + un2));
-    r.gamma = 1.0 + gamma_m1;
-    r.inv_gamma = 1.0 / r.gamma;
+    double g2 = 1.0 + dot(r.u, r.u);
+    // ion.rs:194,198: 1 + gamma_m1 with gamma_m1 = u^2 / (1 + sqrt(1 + u^2)), i.e. sqrt(1 + u^2) again
+    r.inv_gamma = rsqrt_nr(g2);
+    r.gamma = g2 * r.inv_gamma;
     r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx * r.inv_gamma;
     return r;
 }
