@@ -154,6 +154,11 @@ int opal_pop_total_kinetic_energy(const opal_pop_t *p, double *energy);
 int opal_pop_sort(opal_pop_t *p, const opal_grid_t *grid);
 /* 0 = never re-bin automatically; n = every n calls of advance; <0 = adaptive (default) */
 int opal_pop_set_sort_interval(opal_pop_t *p, int interval);
+/* diagnostics: out[0] slots in use, [1] particles deleted at open edges, [2] particle-steps that missed
+ * their workgroup's LDS tile since the last re-binning, [3] steps since the last re-binning, [4] particles
+ * per thread of the push kernels, [5] live particles and [6] non-empty cells at the last re-binning,
+ * [7] host upper bound of the slots in use */
+int opal_pop_counters(const opal_pop_t *p, uint32_t *out);
 /* carry y, z, chi, work, tau for electrons (electron.rs:18-25); off by default */
 int opal_pop_track_extras(opal_pop_t *p, int on);
 int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z);

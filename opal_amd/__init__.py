@@ -238,6 +238,12 @@ class Population:
     def set_sort_interval(self, interval):
         _check(self._lib.opal_pop_set_sort_interval(self.h, interval))
 
+    def counters(self):
+        out = (C.c_uint32 * 8)()
+        _check(self._lib.opal_pop_counters(self.h, out))
+        keys = ("slots", "deleted", "tile_misses", "steps_since_sort", "ppt", "live_at_sort", "nonempty_cells", "slots_upper")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def track_extras(self, on=True):
         _check(self._lib.opal_pop_track_extras(self.h, 1 if on else 0))
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "opal_pop_total_kinetic_energy": (C.c_int, [vp, C.POINTER(dbl)]),
     "opal_pop_sort": (C.c_int, [vp, vp]),
     "opal_pop_set_sort_interval": (C.c_int, [vp, C.c_int]),
+    "opal_pop_counters": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "opal_pop_track_extras": (C.c_int, [vp, C.c_int]),
     "opal_pop_download_extras": (C.c_int, [vp, vp, vp, vp, vp]),
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),

@@ -428,13 +428,51 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
 }
 
 // ------------------------------------------------------------------ re-binning
-__global__ void k_sort_hist(const int *__restrict__ cell, const PopCounters *ctr, unsigned *__restrict__ count)
+// Counting sort by cell, tuned for nearly ordered input.  A workgroup takes SORT_PPT x 256 consecutive
+// slots, whose cells fall (almost always) in a window of SORT_W cells above the chunk's lowest cell: the
+// window is histogrammed in LDS and reaches global memory as one atomic per (workgroup, cell) instead
+// of one per particle.  Cells outside the window (wrapped or freshly arrived particles) use global
+// atomics directly.
+constexpr int SORT_PPT = 8;
+constexpr int SORT_W = 64;
+
+__device__ inline int block_min_cell(const int (&c)[SORT_PPT], int *s_red)
 {
-    unsigned n = ctr->n_slots;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int c = cell[i];
-        if (c != DEAD_CELL) atomicAdd(&count[c], 1u);
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int p = 0; p < SORT_PPT; p++) m = min(m, c[p] == DEAD_CELL ? 0x7fffffff : c[p]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(const int *__restrict__ cell, const PopCounters *ctr,
+                                                   unsigned *__restrict__ count)
+{
+    __shared__ unsigned s_cnt[SORT_W];
+    __shared__ int s_red[4];
+    const unsigned n = ctr->n_slots;
+    const size_t chunk0 = (size_t)blockIdx.x * 256 * SORT_PPT;
+    if (chunk0 >= n) return;
+    int c[SORT_PPT];
+#pragma unroll
+    for (int p = 0; p < SORT_PPT; p++) {
+        size_t i = chunk0 + (size_t)p * 256 + threadIdx.x;
+        c[p] = i < n ? cell[i] : DEAD_CELL;
     }
+    if (threadIdx.x < SORT_W) s_cnt[threadIdx.x] = 0;
+    const int wbase = block_min_cell(c, s_red);  // contains a barrier
+#pragma unroll
+    for (int p = 0; p < SORT_PPT; p++) {
+        if (c[p] == DEAD_CELL) continue;
+        unsigned rel = (unsigned)(c[p] - wbase);
+        if (rel < SORT_W) atomicAdd(&s_cnt[rel], 1u);
+        else atomicAdd(&count[c[p]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SORT_W && s_cnt[threadIdx.x]) atomicAdd(&count[wbase + threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // exclusive scan of count[0..ncells) in place, one workgroup; also the live total and non-empty cell count
@@ -482,16 +520,46 @@ struct SortArgs {
     double *oprev;
 };
 
-__global__ void k_sort_scatter(SortArgs a, const PopCounters *ctr, unsigned *__restrict__ cursor)
+__global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a, const PopCounters *ctr, unsigned *__restrict__ cursor)
 {
-    unsigned n = ctr->n_slots;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int c = a.cell[i];
-        if (c == DEAD_CELL) continue;
-        unsigned d = atomicAdd(&cursor[c], 1u);
-        a.ocell[d] = c;
+    __shared__ unsigned s_cnt[SORT_W], s_base[SORT_W];
+    __shared__ int s_red[4];
+    const unsigned n = ctr->n_slots;
+    const size_t chunk0 = (size_t)blockIdx.x * 256 * SORT_PPT;
+    if (chunk0 >= n) return;
+    int c[SORT_PPT];
+    unsigned rank[SORT_PPT];
 #pragma unroll
-        for (int k = 0; k < 5; k++) a.of[k][d] = a.f[k][i];
+    for (int p = 0; p < SORT_PPT; p++) {
+        size_t i = chunk0 + (size_t)p * 256 + threadIdx.x;
+        c[p] = i < n ? a.cell[i] : DEAD_CELL;
+    }
+    if (threadIdx.x < SORT_W) s_cnt[threadIdx.x] = 0;
+    const int wbase = block_min_cell(c, s_red);
+    // local rank of every particle inside its cell's share of this workgroup
+#pragma unroll
+    for (int p = 0; p < SORT_PPT; p++) {
+        rank[p] = 0;
+        if (c[p] == DEAD_CELL) continue;
+        unsigned rel = (unsigned)(c[p] - wbase);
+        if (rel < SORT_W) rank[p] = atomicAdd(&s_cnt[rel], 1u);
+    }
+    __syncthreads();
+    // one global reservation per (workgroup, cell)
+    if (threadIdx.x < SORT_W) {
+        unsigned k = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = k ? atomicAdd(&cursor[wbase + threadIdx.x], k) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < SORT_PPT; p++) {
+        if (c[p] == DEAD_CELL) continue;
+        size_t i = chunk0 + (size_t)p * 256 + threadIdx.x;
+        unsigned rel = (unsigned)(c[p] - wbase);
+        unsigned d = rel < SORT_W ? s_base[rel] + rank[p] : atomicAdd(&cursor[c[p]], 1u);
+        a.ocell[d] = c[p];
+#pragma unroll
+        for (int q = 0; q < 5; q++) a.of[q][d] = a.f[q][i];
         if (a.prev) a.oprev[d] = a.prev[i];
     }
 }
@@ -857,7 +925,7 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     if (p->d_prev_x && p->prev_valid) OPAL_HIP(hipMalloc(&d_prev_alt, sizeof(double) * p->cap));
     prof_begin(KERNEL_SORT, p->stream);
     OPAL_HIP(hipMemsetAsync(p->d_count, 0, sizeof(unsigned) * (ncells + 2), p->stream));
-    unsigned nblk = (unsigned)std::min<size_t>((p->n_upper + 255) / 256, 4096);
+    unsigned nblk = (unsigned)((p->n_upper + 256 * SORT_PPT - 1) / (256 * SORT_PPT));
     int k = p->cur, o = k ^ 1;
     k_sort_hist<<<nblk, 256, 0, p->stream>>>(p->d_cell[k], p->d_ctr, p->d_count);
     k_sort_scan<<<1, 1024, 0, p->stream>>>(p->d_count, (int)ncells, p->d_ctr);
@@ -896,12 +964,15 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
         if (p->steps_since_sort >= p->sort_interval) return do_sort(p, g);
         return OPAL_OK;
     }
-    // adaptive: every 8 steps look at the tile-miss counter (one small D2H copy); re-bin once more than
-    // 3 % of the particle-steps since the last sort missed their workgroup's LDS tile.
+    // adaptive ("rent or buy"): every 8 steps read the tile-miss counter (one 64-byte D2H copy).  A miss
+    // costs about MISS_NS of kernel time (slow path + straggling workgroup); once the time lost to misses
+    // since the last re-binning exceeds what a re-binning costs, re-bin.
     if (p->steps_since_sort % 8 != 0) return OPAL_OK;
     if (int rc = fetch_counters(p)) return rc;
-    double work = (double)p->h_ctr->n_slots * p->steps_since_sort;
-    if ((double)p->h_ctr->n_slow > 0.03 * work) return do_sort(p, g);
+    constexpr double MISS_NS = 10.0;
+    double lost_ms = (double)p->h_ctr->n_slow * MISS_NS * 1e-6;
+    double sort_ms = 0.06 * (double)p->h_ctr->n_slots * 1e-6 + 0.05;  // ~100 B per particle at ~2 TB/s + launches
+    if (lost_ms > sort_ms) return do_sort(p, g);
     return OPAL_OK;
 }
 
@@ -1100,6 +1171,21 @@ int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, dou
         for (size_t i = 0; i < slots; i++)
             if (hc[i] != DEAD_CELL) dst[k][o++] = tmp[i];
     }
+    return OPAL_OK;
+}
+
+int opal_pop_counters(const opal_pop_t *p, uint32_t *out)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (int rc = fetch_counters(p)) return rc;
+    out[0] = p->h_ctr->n_slots;
+    out[1] = p->h_ctr->n_deleted;
+    out[2] = p->h_ctr->n_slow;
+    out[3] = (uint32_t)p->steps_since_sort;
+    out[4] = (uint32_t)p->ppt;
+    out[5] = p->h_ctr->n_live;
+    out[6] = p->h_ctr->n_nonempty;
+    out[7] = (uint32_t)p->n_upper;
     return OPAL_OK;
 }
 
