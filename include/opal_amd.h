@@ -214,8 +214,9 @@ opal_pop_t *opal_sim_ions(opal_sim_t *s);
 int opal_sim_energies(opal_sim_t *s, double *em_field, double *electrons, double *ions);
 /* 1 = use the fused advance+deposit pass (default), 0 = the reference's operator sequence */
 int opal_sim_set_fused(opal_sim_t *s, int fused);
-/* per-kernel timing with HIP events on the library's stream */
-int opal_prof_enable(int on);
+/* per-kernel timing with HIP events on the library's stream: stride 0 = off, n = time every n-th
+ * launch of each tracked kernel (an odd n samples both species, which alternate) */
+int opal_prof_enable(int stride);
 int opal_prof_reset(void);
 /* kernel ids: 0 = fused advance+deposit, 1 = advance, 2 = deposit, 3 = field solve, 4 = sort */
 int opal_prof_get(int kernel, uint64_t *launches, double *total_ms);

@@ -370,8 +370,9 @@ class Config:
         return out.value
 
 
-def prof_enable(on=True):
-    _check(_lib.load().opal_prof_enable(1 if on else 0))
+def prof_enable(stride=1):
+    """0/False = off; n = time every n-th launch of each tracked kernel with HIP events."""
+    _check(_lib.load().opal_prof_enable(int(stride)))
 
 
 def prof_reset():

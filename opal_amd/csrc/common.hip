@@ -32,11 +32,12 @@ struct ProfSlot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     std::vector<hipEvent_t> pool;
     hipEvent_t open = nullptr;
+    uint64_t seen = 0;  // launches observed while enabled (timed or not)
     uint64_t launches = 0;
     double total_ms = 0.0;
 };
 static ProfSlot g_prof[KERNEL_COUNT];
-static bool g_prof_on = false;
+static int g_prof_stride = 0;  // 0 = off; n = time every n-th launch of each tracked kernel
 static std::mutex g_prof_mu;
 
 static hipEvent_t get_event(ProfSlot &s)
@@ -67,16 +68,17 @@ static void resolve(ProfSlot &s)
 
 void prof_begin(int kernel, hipStream_t st)
 {
-    if (!g_prof_on) return;
+    if (!g_prof_stride) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfSlot &s = g_prof[kernel];
+    if (s.seen++ % (uint64_t)g_prof_stride != 0) return;
     s.open = get_event(s);
     if (s.open) hipEventRecord(s.open, st);
 }
 
 void prof_end(int kernel, hipStream_t st)
 {
-    if (!g_prof_on) return;
+    if (!g_prof_stride) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfSlot &s = g_prof[kernel];
     if (!s.open) return;
@@ -119,7 +121,7 @@ int opal_set_device(int device)
 int opal_prof_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
+    g_prof_stride = on < 0 ? 0 : on;
     return OPAL_OK;
 }
 
@@ -128,6 +130,7 @@ int opal_prof_reset(void)
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &s : g_prof) {
         resolve(s);
+        s.seen = 0;
         s.launches = 0;
         s.total_ms = 0.0;
     }

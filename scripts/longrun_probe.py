@@ -5,7 +5,7 @@ import bench
 import opal_amd as oa
 import torch
 sim = oa.Simulation(yaml_text=bench.YAML.format(nx=4096, npc=int(os.environ.get("NPC", "2441"))), stream=torch.cuda.current_stream().cuda_stream)
-oa.prof_enable(True)
+oa.prof_enable(1)
 for blk in range(int(os.environ.get("BLOCKS", "30"))):
     oa.prof_reset()
     t0 = time.perf_counter()
