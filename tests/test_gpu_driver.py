@@ -85,3 +85,99 @@ def test_two_stream_yaml_run(oracle, tmp_path):
     # Rust float formatting of the grid dump: no "e+00", shortest round-trip digits
     first = open(tmp_path / "4_grid.dat").readline().split()
     assert first[0] == "0e0" and "e+" not in " ".join(first)
+
+
+# the physics of the reference's laser-plasma example (laser from the left, absorbing right boundary,
+# electrons + carbon ions with thermal momenta), scaled down: 3000 cells, a0 = 30, 20 particles per cell
+HOLE_BORING = """---
+control:
+ dx: micro / 200
+ nx: 3000
+ xmin: -10*micro
+ start: -11.0e-6/c
+ end: -4.0e-6/c
+ current_deposition: true
+ n_outputs: 2
+ balance: true
+
+qed:
+ photon_emission: false
+ photon_absorption: false
+
+electrons:
+ npc: 20
+ ne: density * critical(omega) * step(x,xmin,xmax)
+ ux: sqrt(kT/(m*c^2)) * nrand
+ uy: sqrt(kT/(m*c^2)) * nrand
+ uz: sqrt(kT/(m*c^2)) * nrand
+ output: [x:px, x:p_perp, py:pz]
+
+ions:
+ name: carbon
+ npc: 20
+ Z: Z
+ A: A
+ ni: density * critical(omega) * step(x,xmin,xmax) / Z
+ ux: sqrt(kT/(A*mp*c^2)) * nrand
+ uy: sqrt(kT/(A*mp*c^2)) * nrand
+ uz: sqrt(kT/(A*mp*c^2)) * nrand
+ output: [x:px, x:p_perp, py:pz]
+
+laser:
+ Ey: (a0*me*c*omega/e) * gauss_pulse_re(t,x,omega,sigma)
+ Ez: (a0*me*c*omega/e) * gauss_pulse_im(t,x,omega,sigma)
+
+constants:
+ density: 20.0
+ a0: 30.0
+ omega: 2*pi*c/0.8e-6
+ sigma: pi * 2.0 / sqrt(ln(2.0))
+ xmin: -8.0 * micro
+ xmax: -6.0 * micro
+ Z: 6.0
+ A: 12.0
+ kT: 500 * eV
+"""
+
+
+def test_laser_plasma_yaml_steps(oracle, tmp_path):
+    """Laser + absorbing boundaries, two species, relativistic motion, deletion at open edges, adaptive
+    re-binning: fields and energies against the oracle over 900 steps."""
+    import opal_amd as oa
+    o = oracle
+    yml = tmp_path / "hb.yaml"
+    yml.write_text(HOLE_BORING)
+    sim = oa.Simulation(yaml_path=yml)
+    cfg = oa.Config(path=yml)
+    ly, lz = cfg.func("laser", "Ey", ["t", "x"]), cfg.func("laser", "Ez", ["t", "x"])
+    dx, dt = 1.0e-6 / 200, sim.dt
+    g = sim.grid
+    assert (g.left_bdy_size, g.right_bdy_size, g.size) == (4, 200, 3000)
+    ne, ni = len(sim.electrons), len(sim.ions)
+    assert ne == ni == 400 * 20
+    ie, ii = sim.electrons.soa(), sim.ions.soa()
+    og = o.Grid.single(3000, -10e-6, dx, o.BDY_LASER, o.BDY_ABSORBING)
+    ope = o.Population.from_soa(o.ELECTRON, ie["cell"], ie["x"], ie["ux"], ie["uy"], ie["uz"], ie["w"], dx, dt)
+    opi = o.Population.from_soa(o.ION, ii["cell"], ii["x"], ii["ux"], ii["uy"], ii["uz"], ii["w"], dx, dt)
+    opi.set_charge_state(6.0, 6.0, 12.0)
+    t = sim.t
+    ope_ke0 = ope.total_kinetic_energy()
+    nsteps = 900  # the pulse reaches the plasma after ~630 steps
+    for k in range(nsteps):
+        assert o.world_step([og], [ope], [opi], True, t, dt, laser_y=ly, laser_z=lz) == 0
+        t += dt
+    sim.step(nsteps)
+    sim.sync()
+    assert abs(sim.t - t) <= 1e-12 * abs(t)
+    fe, ke, ki = sim.energies()
+    ofe, oke, oki = og.em_field_energy(), ope.total_kinetic_energy(), opi.total_kinetic_energy()
+    assert ofe > 0 and oke > 0
+    # north_star's tolerance: fields within 1e-6 relative of the CPU path
+    assert abs(fe - ofe) / ofe < 1e-6
+    assert abs(ke - oke) / oke < 1e-6
+    assert abs(ki - oki) / oki < 1e-6
+    assert oke > 100 * ope_ke0  # the laser has heated the electrons: the interaction really happened
+    for comp in ("Ey", "Ez", "By", "Bz", "Ex"):
+        a, b = g.raw(comp), og.raw(comp)
+        assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-6, comp
+    assert len(sim.electrons) == len(ope) and len(sim.ions) == len(opi)
