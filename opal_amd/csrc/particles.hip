@@ -93,22 +93,22 @@ __device__ inline void scatter_lds(double *acc, int rel, int lane, const Taps &t
     // acc[comp][cell][replica].  Taps that are nearly always non-zero are added unconditionally; the
     // outer jx taps (non-zero only for a particle that crossed a cell) and the transverse currents
     // (zero for a whole species in 1-D electrostatic problems) are skipped when no lane needs them.
-    double *a = acc + lane;
-    lds_add(a + ((0 * TILE + rel - 2) * REPL), t.jx[0]);
+    double *a = acc + (rel - 2) * REPL + lane;  // every tap below is this base plus a non-negative constant
+    lds_add(a, t.jx[0]);
 #pragma unroll
-    for (int k = 1; k < 4; k++) atomicAdd(a + ((0 * TILE + rel + k - 2) * REPL), t.jx[k]);
-    lds_add(a + ((0 * TILE + rel + 2) * REPL), t.jx[4]);
+    for (int k = 1; k < 4; k++) atomicAdd(a + k * REPL, t.jx[k]);
+    lds_add(a + 4 * REPL, t.jx[4]);
     if (t.jy[1] != 0.0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) atomicAdd(a + ((1 * TILE + rel + k - 1) * REPL), t.jy[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(a + (1 * TILE + k + 1) * REPL, t.jy[k]);
     }
     if (t.jz[1] != 0.0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) atomicAdd(a + ((2 * TILE + rel + k - 1) * REPL), t.jz[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(a + (2 * TILE + k + 1) * REPL, t.jz[k]);
     }
     if (RHO) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) atomicAdd(a + ((3 * TILE + rel + k - 2) * REPL), t.rho[k]);
+        for (int k = 0; k < 4; k++) atomicAdd(a + (3 * TILE + k) * REPL, t.rho[k]);
     }
 }
 
@@ -209,7 +209,8 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
 
     if (DEPOSIT && !deleted) {
         double macrocharge = wt * a.charge;
-        double vy = SPEED_OF_LIGHT * u.y * inv_g, vz = SPEED_OF_LIGHT * u.z * inv_g;
+        const double cig = SPEED_OF_LIGHT * inv_g;
+        double vy = cig * u.y, vz = cig * u.z;
         Taps t = deposit_taps<RHO>(xn, prev, macrocharge, vy, vz, a.inv_dt, a.inv_dx);
         if (FAST) scatter_lds<RHO>(s_acc, rel, lane, t);
         else scatter_global<RHO>(a.jr, a.lenp, idx, t);

@@ -67,6 +67,28 @@ __host__ __device__ inline double flux(double x_i, double x_f)
     return opposite ? diff : same;
 }
 
+// 2 x Cell::flux: the factor 0.5 of every arm of the reference (an exact power-of-two scaling) is left
+// to the caller, who folds it into the charge/dt constant.  Arms as in flux().
+__host__ __device__ inline double flux2(double x_i, double x_f)
+{
+    double a = fabs(x_i), b = fabs(x_f);
+    bool ina = a < 1.0, inb = b < 1.0;
+    double ca = 1.0 - a, cb = 1.0 - b;
+    double pa = ina ? ca * ca : 0.0;
+    double pb = inb ? cb * cb : 0.0;
+    double same = copysign(pb - pa, x_i - x_f);
+    double diff = copysign(a * (2.0 - a) + b * (2.0 - b), x_i);
+    bool opposite = ina && inb && !(x_i * x_f >= 0.0);
+    return opposite ? diff : same;
+}
+__host__ __device__ inline double flux2_outer(double x_i, double displacement)
+{
+    double a = fabs(x_i);
+    double ca = 1.0 - a;
+    double pa = a < 1.0 ? ca * ca : 0.0;
+    return copysign(pa, displacement);
+}
+
 // Cell::flux for the two outermost taps of the deposit (boundaries at -1.5 and 2.5 cells from the
 // left edge of the particle's cell): with the final offset x in [0, 1] the boundary is at least 1.5
 // cells from the particle's final position, so |x_f| >= 1 always and only the first and last arms of
@@ -167,7 +189,7 @@ __device__ inline Pushed vay_push(V3 u, V3 E, V3 B, double alpha, double dt_over
 {
     Pushed r;
     double inv_g = rsqrt_nr(1.0 + dot(u, u));
-    V3 v = {SPEED_OF_LIGHT * u.x * inv_g, SPEED_OF_LIGHT * u.y * inv_g, SPEED_OF_LIGHT * u.z * inv_g};
+    V3 v = (SPEED_OF_LIGHT * inv_g) * u;
     V3 u_half = u + alpha * (E + cross(v, B));
     if (EXTRAS) {
         double gh2 = 1.0 + dot(u_half, u_half);
@@ -234,25 +256,29 @@ __device__ inline Taps deposit_taps(double x, double prev_x, double macrocharge,
                                     double inv_dt, double inv_dx)
 {
     Taps t;
-    t.jx[2] = macrocharge * flux(0.5 - prev_x, 0.5 - x) * inv_dt;
-    t.jx[1] = macrocharge * flux(-0.5 - prev_x, -0.5 - x) * inv_dt;
-    t.jx[0] = macrocharge * flux_outer(-1.5 - prev_x, x - prev_x) * inv_dt;
-    t.jx[3] = macrocharge * flux(1.5 - prev_x, 1.5 - x) * inv_dt;
-    t.jx[4] = macrocharge * flux_outer(2.5 - prev_x, x - prev_x) * inv_dt;
+    // jx = Q flux / dt (yee.rs:584-588) with flux = 0.5 * flux2: one constant carries Q, 1/dt and the 0.5
+    const double hq = 0.5 * (macrocharge * inv_dt);
+    const double d = x - prev_x;
+    t.jx[2] = hq * flux2(0.5 - prev_x, 0.5 - x);
+    t.jx[1] = hq * flux2(-0.5 - prev_x, -0.5 - x);
+    t.jx[0] = hq * flux2_outer(-1.5 - prev_x, d);
+    t.jx[3] = hq * flux2(1.5 - prev_x, 1.5 - x);
+    t.jx[4] = hq * flux2_outer(2.5 - prev_x, d);
     EdgeW ew = edge_weights(x);
-    double w0 = ew.e0, w1 = ew.e1, w2 = ew.e2;
-    double qy = macrocharge * vy, qz = macrocharge * vz;
-    t.jy[0] = qy * w0 * inv_dx;
-    t.jy[1] = qy * w1 * inv_dx;
-    t.jy[2] = qy * w2 * inv_dx;
-    t.jz[0] = qz * w0 * inv_dx;
-    t.jz[1] = qz * w1 * inv_dx;
-    t.jz[2] = qz * w2 * inv_dx;
+    // j_perp = Q v W / dx (yee.rs:594-602), rho = Q W / dx (:606-609)
+    const double qdx = macrocharge * inv_dx;
+    const double qy = qdx * vy, qz = qdx * vz;
+    t.jy[0] = qy * ew.e0;
+    t.jy[1] = qy * ew.e1;
+    t.jy[2] = qy * ew.e2;
+    t.jz[0] = qz * ew.e0;
+    t.jz[1] = qz * ew.e1;
+    t.jz[2] = qz * ew.e2;
     if (RHO) {
-        t.rho[0] = macrocharge * ew.e3 * inv_dx;
-        t.rho[1] = macrocharge * w0 * inv_dx;
-        t.rho[2] = macrocharge * w1 * inv_dx;
-        t.rho[3] = macrocharge * w2 * inv_dx;
+        t.rho[0] = qdx * ew.e3;
+        t.rho[1] = qdx * ew.e0;
+        t.rho[2] = qdx * ew.e1;
+        t.rho[3] = qdx * ew.e2;
     }
     return t;
 }
