@@ -127,6 +127,19 @@ __device__ inline void scatter_global(double *jr, size_t lenp, int idx, const Ta
     }
 }
 
+// Element k of a block-uniform array with a 32-bit byte offset, so that the access takes the
+// scalar-base + 32-bit vector-offset form (a chunk is at most 32 x 256 slots).
+template <class T>
+__device__ __forceinline__ T ldk(const T *base, unsigned k)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + k * (unsigned)sizeof(T));
+}
+template <class T>
+__device__ __forceinline__ void stk(T *base, unsigned k, T v)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + k * (unsigned)sizeof(T)) = v;
+}
+
 // Per-chunk view of the particle arrays: block-uniform base pointers (scalar registers) indexed
 // with a 32-bit slot offset.
 struct ChunkPtrs {
@@ -236,12 +249,12 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             }
             cp.cell[kc] = DEAD_CELL;
         } else {
-            cp.cell[kc] = newc;
-            cp.x[kc] = xn;
-            cp.ux[kc] = u.x;
-            cp.uy[kc] = u.y;
-            cp.uz[kc] = u.z;
-            if (MODE == MODE_ADVANCE) cp.prev[kc] = prev;
+            stk(cp.cell, kc, newc);
+            stk(cp.x, kc, xn);
+            stk(cp.ux, kc, u.x);
+            stk(cp.uy, kc, u.y);
+            stk(cp.uz, kc, u.z);
+            if (MODE == MODE_ADVANCE) stk(cp.prev, kc, prev);
         }
     }
 }
@@ -294,8 +307,8 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
     int c_n = DEAD_CELL;
     double x_n = 0.0, ux_n = 0.0, uy_n = 0.0, uz_n = 0.0, w_n = 0.0, prev_n = 0.0;
     if (have) {
-        c_n = cp.cell[k]; x_n = cp.x[k]; ux_n = cp.ux[k]; uy_n = cp.uy[k]; uz_n = cp.uz[k]; w_n = cp.w[k];
-        if (MODE == MODE_DEPOSIT) prev_n = cp.prev[k];
+        c_n = ldk(cp.cell, k); x_n = ldk(cp.x, k); ux_n = ldk(cp.ux, k); uy_n = ldk(cp.uy, k); uz_n = ldk(cp.uz, k); w_n = ldk(cp.w, k);
+        if (MODE == MODE_DEPOSIT) prev_n = ldk(cp.prev, k);
     }
     // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin.  Slots that
     // hold far-away cells (particles that wrapped around a periodic domain, arrivals appended from both
@@ -366,8 +379,8 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
         k += BLOCK;
         have = (p + 1 < a.ppt) && k < nloc;
         if (have) {
-            c_n = cp.cell[k]; x_n = cp.x[k]; ux_n = cp.ux[k]; uy_n = cp.uy[k]; uz_n = cp.uz[k]; w_n = cp.w[k];
-            if (MODE == MODE_DEPOSIT) prev_n = cp.prev[k];
+            c_n = ldk(cp.cell, k); x_n = ldk(cp.x, k); ux_n = ldk(cp.ux, k); uy_n = ldk(cp.uy, k); uz_n = ldk(cp.uz, k); w_n = ldk(cp.w, k);
+            if (MODE == MODE_DEPOSIT) prev_n = ldk(cp.prev, k);
         }
         if (!live) continue;
         int rel = c + a.L - base;
