@@ -47,6 +47,7 @@ struct SyncArgs {
     int len, L, R;
     const double *recv_left;   // 80 doubles or null
     const double *recv_right;
+    int self_periodic;         // a lone periodic subdomain receives its own cells (yee.rs:365-370, 390-395)
     int left_bdy, right_bdy;
     double laser_y, laser_z;   // already 2 r laser(t, x), yee.rs:459-461
     const double *damp;        // (1 - sigma) for the last R-1 cells of an absorbing layer
@@ -57,19 +58,36 @@ struct SyncArgs {
 __global__ void k_synchronize(SyncArgs a)
 {
     int t = threadIdx.x;
-    // (i) ghost overlay, yee.rs:424-452 + Cell::overlay_ghost / overlay (:97-113)
+    // (i) ghost overlay, yee.rs:424-452 + Cell::overlay_ghost / overlay (:97-113).  Every lane first reads
+    // the value it received (for a self-exchange: straight from the other end of the arrays, which are
+    // both source and destination), then all lanes write.
+    int side = t / HALO_DOUBLES, r = t % HALO_DOUBLES;
+    int k = r / HALO_COMPS, comp = r % HALO_COMPS;
+    bool active = false;
+    double v = 0.0;
     if (t < 2 * HALO_DOUBLES) {
-        int side = t / HALO_DOUBLES, r = t % HALO_DOUBLES;
-        int k = r / HALO_COMPS, comp = r % HALO_COMPS;
-        const double *recv = side == 0 ? a.recv_left : a.recv_right;
-        if (recv) {
-            double v = recv[r];
-            int cellidx = side == 0 ? k : a.len - HALO_CELLS + k;
-            bool ghost = side == 0 ? (k < GHOST_SIZE) : (k >= GHOST_SIZE);
-            if (comp == 0) a.jr[3 * a.lenp + cellidx] += v;
-            else if (comp < 4) a.jr[(size_t)(comp - 1) * a.lenp + cellidx] += v;
-            else if (ghost) a.eb[(size_t)(comp - 4) * a.lenp + cellidx] = v;
+        if (a.self_periodic) {
+            // recv_left = what this subdomain sent right = cell[len-8+k]; recv_right = cell[k]
+            int src = side == 0 ? a.len - HALO_CELLS + k : k;
+            v = comp == 0 ? a.jr[3 * a.lenp + src]
+                : comp < 4 ? a.jr[(size_t)(comp - 1) * a.lenp + src]
+                           : a.eb[(size_t)(comp - 4) * a.lenp + src];
+            active = true;
+        } else {
+            const double *recv = side == 0 ? a.recv_left : a.recv_right;
+            if (recv) {
+                v = recv[r];
+                active = true;
+            }
         }
+    }
+    __syncthreads();
+    if (active) {
+        int cellidx = side == 0 ? k : a.len - HALO_CELLS + k;
+        bool ghost = side == 0 ? (k < GHOST_SIZE) : (k >= GHOST_SIZE);
+        if (comp == 0) a.jr[3 * a.lenp + cellidx] += v;
+        else if (comp < 4) a.jr[(size_t)(comp - 1) * a.lenp + cellidx] += v;
+        else if (ghost) a.eb[(size_t)(comp - 4) * a.lenp + cellidx] = v;
     }
     __syncthreads();
     // (ii) laser, yee.rs:456-462: one cell, start = left_bdy_size - 2
@@ -122,8 +140,8 @@ constexpr int FW = FT + 2 * FH;
 // the other field buffer.  The array ends follow the reference loops: B is not
 // advanced in the last cell, cell 0 gets the Silver-Mueller update.
 __global__ __launch_bounds__(FT) void k_advance(const double *__restrict__ src, double *__restrict__ dst,
-                                                const double *__restrict__ jr, size_t lenp, int len, double dt,
-                                                double dx)
+                                                const double *__restrict__ jr, double *__restrict__ jr_next,
+                                                size_t lenp, int len, double dt, double dx)
 {
     __shared__ double Ex[FW], Ey[FW], Ez[FW], By[FW], Bz[FW];
     const int t = threadIdx.x;
@@ -180,6 +198,12 @@ __global__ __launch_bounds__(FT) void k_advance(const double *__restrict__ src, 
             dst[3 * lenp + i] = src[3 * lenp + i];  // Bx: "nothing happens to Bx in 1D" (yee.rs:844)
             dst[4 * lenp + i] = by;
             dst[5 * lenp + i] = bz;
+            // YeeGrid::clear (yee.rs:543-549) for the next step, done on the spare current buffer: nobody
+            // reads it during this kernel, and the currents just used stay available to write_data
+            jr_next[0 * lenp + i] = 0.0;
+            jr_next[1 * lenp + i] = 0.0;
+            jr_next[2 * lenp + i] = 0.0;
+            jr_next[3 * lenp + i] = 0.0;
         }
     }
 }
@@ -249,7 +273,7 @@ namespace opal {
 // used by particles.hip and link.cpp
 int grid_pack_halo(opal_grid_t *g, double *send_left, double *send_right)
 {
-    k_pack_halo<<<1, 192, 0, g->stream>>>(g->d_eb[g->cur], g->d_j, g->lenp, (int)g->len, send_left, send_right);
+    k_pack_halo<<<1, 192, 0, g->stream>>>(g->d_eb[g->cur], g->j(), g->lenp, (int)g->len, send_left, send_right);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
 }
@@ -258,13 +282,14 @@ int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_
 {
     SyncArgs a;
     a.eb = g->d_eb[g->cur];
-    a.jr = g->d_j;
+    a.jr = g->j();
     a.lenp = g->lenp;
     a.len = (int)g->len;
     a.L = g->L;
     a.R = g->R;
     a.recv_left = g->left_bdy == OPAL_BDY_INTERNAL ? recv_left : nullptr;
     a.recv_right = g->right_bdy == OPAL_BDY_INTERNAL ? recv_right : nullptr;
+    a.self_periodic = g->ngrids == 1 && g->left_bdy == OPAL_BDY_INTERNAL && g->right_bdy == OPAL_BDY_INTERNAL;
     a.left_bdy = g->left_bdy;
     a.right_bdy = g->right_bdy;
     a.laser_y = ly;
@@ -348,14 +373,18 @@ int opal_grid_build(opal_grid_t **out, int id, int numtasks, int left, int right
     size_t nb = sizeof(double) * g->lenp;
     OPAL_HIP(hipMalloc(&g->d_eb[0], 6 * nb));
     OPAL_HIP(hipMalloc(&g->d_eb[1], 6 * nb));
-    OPAL_HIP(hipMalloc(&g->d_j, 4 * nb));
+    OPAL_HIP(hipMalloc(&g->d_jb[0], 4 * nb));
+    OPAL_HIP(hipMalloc(&g->d_jb[1], 4 * nb));
+    g->jcur = 0;
+    g->j_spare_zero = true;
     OPAL_HIP(hipMalloc(&g->d_send, sizeof(double) * 2 * HALO_DOUBLES));
     OPAL_HIP(hipMalloc(&g->d_scalar, sizeof(double) * 8));
     OPAL_HIP(hipMalloc(&g->d_err, sizeof(int)));
     OPAL_HIP(hipHostMalloc(&g->h_pin, sizeof(double) * 11 * g->lenp));
     OPAL_HIP(hipMemsetAsync(g->d_eb[0], 0, 6 * nb, g->stream));
     OPAL_HIP(hipMemsetAsync(g->d_eb[1], 0, 6 * nb, g->stream));
-    OPAL_HIP(hipMemsetAsync(g->d_j, 0, 4 * nb, g->stream));
+    OPAL_HIP(hipMemsetAsync(g->d_jb[0], 0, 4 * nb, g->stream));
+    OPAL_HIP(hipMemsetAsync(g->d_jb[1], 0, 4 * nb, g->stream));
     OPAL_HIP(hipMemsetAsync(g->d_err, 0, sizeof(int), g->stream));
     if (g->right_bdy == OPAL_BDY_ABSORBING) {
         // yee.rs:465-468, evaluated once on the host with the reference's arithmetic
@@ -381,7 +410,8 @@ int opal_grid_free(opal_grid_t *g)
     if (!g) return OPAL_OK;
     hipFree(g->d_eb[0]);
     hipFree(g->d_eb[1]);
-    hipFree(g->d_j);
+    hipFree(g->d_jb[0]);
+    hipFree(g->d_jb[1]);
     hipFree(g->d_send);
     hipFree(g->d_scalar);
     hipFree(g->d_err);
@@ -405,7 +435,13 @@ size_t opal_grid_right_bdy_size(const opal_grid_t *g) { return g ? (size_t)g->R 
 int opal_grid_clear(opal_grid_t *g)
 {
     if (int rc = check_grid(g)) return rc;
-    OPAL_HIP(hipMemsetAsync(g->d_j, 0, sizeof(double) * 4 * g->lenp, g->stream));
+    if (g->j_spare_zero) {
+        // the last field solve already zeroed the spare buffer: switch to it
+        g->jcur ^= 1;
+        g->j_spare_zero = false;
+    } else {
+        OPAL_HIP(hipMemsetAsync(g->j(), 0, sizeof(double) * 4 * g->lenp, g->stream));
+    }
     return OPAL_OK;
 }
 
@@ -414,7 +450,9 @@ int opal_grid_advance(opal_grid_t *g, double dt)
     if (int rc = check_grid(g)) return rc;
     int nblk = (int)((g->len + FT - 1) / FT);
     prof_begin(KERNEL_FIELD, g->stream);
-    k_advance<<<nblk, FT, 0, g->stream>>>(g->d_eb[g->cur], g->d_eb[g->cur ^ 1], g->d_j, g->lenp, (int)g->len, dt, g->dx);
+    k_advance<<<nblk, FT, 0, g->stream>>>(g->d_eb[g->cur], g->d_eb[g->cur ^ 1], g->j(), g->d_jb[g->jcur ^ 1], g->lenp,
+                                          (int)g->len, dt, g->dx);
+    g->j_spare_zero = true;
     prof_end(KERNEL_FIELD, g->stream);
     OPAL_HIP(hipGetLastError());
     g->cur ^= 1;
@@ -459,8 +497,8 @@ static int grid_fetch(const opal_grid_t *g)
     // h_pin rows: 0 rho? keep opal_comp order 1..10 (x is computed)
     double *h = g->h_pin;
     size_t nb = sizeof(double) * g->lenp;
-    OPAL_HIP(hipMemcpyAsync(h + 1 * g->lenp, g->d_j + 3 * g->lenp, nb, hipMemcpyDeviceToHost, g->stream));       // rho
-    OPAL_HIP(hipMemcpyAsync(h + 2 * g->lenp, g->d_j, 3 * nb, hipMemcpyDeviceToHost, g->stream));                  // jx jy jz
+    OPAL_HIP(hipMemcpyAsync(h + 1 * g->lenp, g->j() + 3 * g->lenp, nb, hipMemcpyDeviceToHost, g->stream));       // rho
+    OPAL_HIP(hipMemcpyAsync(h + 2 * g->lenp, g->j(), 3 * nb, hipMemcpyDeviceToHost, g->stream));                  // jx jy jz
     OPAL_HIP(hipMemcpyAsync(h + 5 * g->lenp, g->d_eb[g->cur], 6 * nb, hipMemcpyDeviceToHost, g->stream));         // E, B
     OPAL_HIP(hipStreamSynchronize(g->stream));
     for (size_t i = 0; i < g->len; i++) h[i] = g->cell_x(i);
@@ -478,8 +516,8 @@ int opal_grid_get_raw(const opal_grid_t *g, int comp, double *out)
         for (size_t i = 0; i < g->len; i++) out[i] = g->cell_x(i);
         return OPAL_OK;
     }
-    const double *src = comp == OPAL_RHO ? g->d_j + 3 * g->lenp
-                        : comp <= OPAL_JZ ? g->d_j + (size_t)(comp - OPAL_JX) * g->lenp
+    const double *src = comp == OPAL_RHO ? g->j() + 3 * g->lenp
+                        : comp <= OPAL_JZ ? g->j() + (size_t)(comp - OPAL_JX) * g->lenp
                                           : g->d_eb[g->cur] + (size_t)(comp - OPAL_EX) * g->lenp;
     OPAL_HIP(hipMemcpyAsync(out, src, sizeof(double) * g->len, hipMemcpyDeviceToHost, g->stream));
     OPAL_HIP(hipStreamSynchronize(g->stream));
@@ -493,8 +531,8 @@ int opal_grid_set_raw(opal_grid_t *g, int comp, const double *in)
         set_error("opal_grid_set_raw: bad component %d", comp);
         return OPAL_ERR_ARG;
     }
-    double *dst = comp == OPAL_RHO ? g->d_j + 3 * g->lenp
-                  : comp <= OPAL_JZ ? g->d_j + (size_t)(comp - OPAL_JX) * g->lenp
+    double *dst = comp == OPAL_RHO ? g->j() + 3 * g->lenp
+                  : comp <= OPAL_JZ ? g->j() + (size_t)(comp - OPAL_JX) * g->lenp
                                     : g->d_eb[g->cur] + (size_t)(comp - OPAL_EX) * g->lenp;
     OPAL_HIP(hipMemcpyAsync(dst, in, sizeof(double) * g->len, hipMemcpyHostToDevice, g->stream));
     OPAL_HIP(hipStreamSynchronize(g->stream));
@@ -545,10 +583,8 @@ int opal_grid_synchronize(opal_grid_t *g, opal_link_t *link, opal_fn2 laser_y, o
     bool need_halo = g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL;
     const double *recv_left = nullptr, *recv_right = nullptr;
     if (need_halo && g->ngrids == 1) {
-        // yee.rs:365-370, 390-395: a lone periodic subdomain receives its own sends
-        if (int rc = grid_pack_halo(g, g->d_send, g->d_send + HALO_DOUBLES)) return rc;
-        recv_left = g->d_send + HALO_DOUBLES;  // what it sent right
-        recv_right = g->d_send;                // what it sent left
+        // yee.rs:365-370, 390-395: a lone periodic subdomain receives its own sends; the overlay
+        // kernel reads them straight from the arrays
     } else if (need_halo) {
         if (!link) {
             set_error("opal_grid_synchronize: %d subdomains need a link", g->ngrids);

@@ -48,7 +48,10 @@ struct opal_grid {
     double dx, xmin_global, offset;
     hipStream_t stream;
     double *d_eb[2];  // ping-pong field buffers, 6 components x lenp
-    double *d_j;      // jx jy jz rho, 4 x lenp
+    double *d_jb[2];  // jx jy jz rho, 4 x lenp, twice: the field solve zeroes the spare one for the next step
+    int jcur;
+    bool j_spare_zero;
+    double *j() const { return d_jb[jcur]; }
     int cur;
     double *d_send;   // 2 x 80 doubles: what synchronize sends left / right
     double *d_damp;   // absorbing layer factors (1 - sigma), R entries (or null)
@@ -75,6 +78,10 @@ struct opal_pop {
     double z_star, z, a;
     opal::PopCounters *d_ctr;
     opal::PopCounters *h_ctr;  // pinned
+    opal::PopCounters *h_ctr_async;  // pinned target of the asynchronous copy used by the re-binning policy
+    opal::PopCounters h_ctr_seen;
+    hipEvent_t ctr_event;
+    bool ctr_pending;
     int sort_interval;         // 0 never, >0 fixed, <0 adaptive
     int steps_since_sort;
     int ppt;                   // particles per thread in the push kernels

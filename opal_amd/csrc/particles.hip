@@ -788,7 +788,7 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     a.prev_x = p->d_prev_x;
     a.chi = p->d_chi; a.work = p->d_work; a.y = p->d_y; a.z = p->d_z;
     a.eb = g->d_eb[g->cur];
-    a.jr = g->d_j;
+    a.jr = g->j();
     a.lenp = g->lenp;
     a.ppt = p->ppt;
     a.size = (int)g->size; a.L = g->L; a.len = (int)g->len;
@@ -962,6 +962,10 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     p->cur = o;
     p->n_upper = p->h_ctr->n_slots;
     p->steps_since_sort = 0;
+    if (p->ctr_pending) {
+        hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
+        p->ctr_pending = false;
+    }
     // size the per-workgroup chunk so that it spans about 4 occupied cells (TILE holds ~10 with margins)
     unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
     double per_cell = (double)p->h_ctr->n_live / ne;
@@ -978,14 +982,34 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
         if (p->steps_since_sort >= p->sort_interval) return do_sort(p, g);
         return OPAL_OK;
     }
-    // adaptive ("rent or buy"): every 8 steps read the tile-miss counter (one 64-byte D2H copy).  A miss
-    // costs about MISS_NS of kernel time (slow path + straggling workgroup); once the time lost to misses
-    // since the last re-binning exceeds what a re-binning costs, re-bin.
-    if (p->steps_since_sort % 8 != 0) return OPAL_OK;
-    if (int rc = fetch_counters(p)) return rc;
-    constexpr double MISS_NS = 10.0;
-    double lost_ms = (double)p->h_ctr->n_slow * MISS_NS * 1e-6;
-    double sort_ms = 0.06 * (double)p->h_ctr->n_slots * 1e-6 + 0.05;  // ~100 B per particle at ~2 TB/s + launches
+    // adaptive ("rent or buy"): every few steps read the tile-miss counter (one 64-byte D2H copy).  A miss
+    // costs about 100 ns of kernel time (slow path + the workgroup it delays; tuned on the two-stream
+    // bench, scripts/sustained_probe.py); once the time lost to misses since the last re-binning exceeds
+    // what a re-binning costs, re-bin.
+    static const int check_every = getenv("OPAL_DEBUG_CHECK") ? atoi(getenv("OPAL_DEBUG_CHECK")) : 4;
+    static const double miss_ns = getenv("OPAL_DEBUG_MISSNS") ? atof(getenv("OPAL_DEBUG_MISSNS")) : 100.0;
+    if (p->steps_since_sort % check_every != 0) return OPAL_OK;
+    // The counters are copied to pinned memory asynchronously and read at the NEXT check, 8 steps later:
+    // waiting for that older copy keeps the host at most ~16 steps ahead of the device (so the policy sees
+    // recent counts) while the device still has 8 queued steps to run and never idles.
+    bool fresh = false;
+    if (p->ctr_pending) {
+        OPAL_HIP(hipEventSynchronize(p->ctr_event));
+        fresh = true;
+        p->h_ctr_seen = *p->h_ctr_async;
+        p->ctr_pending = false;
+    }
+    if (!p->ctr_pending) {
+        if (!p->ctr_event) OPAL_HIP(hipEventCreateWithFlags(&p->ctr_event, hipEventDisableTiming));
+        OPAL_HIP(hipMemcpyAsync(p->h_ctr_async, p->d_ctr, sizeof(PopCounters), hipMemcpyDeviceToHost, p->stream));
+        OPAL_HIP(hipEventRecord(p->ctr_event, p->stream));
+        p->ctr_pending = true;
+        if (!fresh) return OPAL_OK;
+    }
+    if (!fresh) return OPAL_OK;
+    const PopCounters seen = p->h_ctr_seen;  // snapshot taken when the copy was found complete
+    double lost_ms = (double)seen.n_slow * miss_ns * 1e-6;
+    double sort_ms = 0.06 * (double)seen.n_slots * 1e-6 + 0.05;  // ~100 B per particle at ~2 TB/s + launches
     if (lost_ms > sort_ms) return do_sort(p, g);
     return OPAL_OK;
 }
@@ -1021,6 +1045,7 @@ int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_st
     if (int rc = alloc_set(p, 0)) return rc;
     OPAL_HIP(hipMalloc(&p->d_ctr, sizeof(PopCounters)));
     OPAL_HIP(hipHostMalloc(&p->h_ctr, sizeof(PopCounters)));
+    OPAL_HIP(hipHostMalloc(&p->h_ctr_async, sizeof(PopCounters)));
     OPAL_HIP(hipMemsetAsync(p->d_ctr, 0, sizeof(PopCounters), p->stream));
     p->partial_cap = 2048;
     OPAL_HIP(hipMalloc(&p->d_partial, sizeof(double) * (p->partial_cap + 8)));
@@ -1040,6 +1065,8 @@ int opal_pop_free(opal_pop_t *p)
     hipFree(p->d_partial);
     hipFree(p->d_ctr);
     hipHostFree(p->h_ctr);
+    hipHostFree(p->h_ctr_async);
+    if (p->ctr_event) hipEventDestroy(p->ctr_event);
     delete p;
     return OPAL_OK;
 }
