@@ -10,10 +10,12 @@
 //
 // The hot kernel (k_push<...,FUSED>) is one pass per particle per step:
 //   read 44 B, gather E,B from an LDS copy of the field tile, Vay/Boris push,
-//   charge-conserving deposit into LDS accumulators (32 lane-private replicas
-//   per (cell, component) so that ds_add_f64 never serialises on an address),
-//   write 36 B; one global f64 atomic per touched (cell, component) per
-//   workgroup at the end.  Algorithmic traffic 80 B per particle-update; the
+//   charge-conserving deposit with ds_add_f64 into LDS accumulators (a 64-cell
+//   tile x 4 components x 8 replicas selected by lane, so at most 8 lanes of a
+//   wave meet on an address; measured: 8, 16 and 32 replicas run equally fast,
+//   the LDS pipe has slack, while a wide tile keeps fast particles on the fast
+//   path for more steps between re-binnings), write 36 B; one global f64 atomic
+//   per touched (cell, component) per workgroup at the end.  Algorithmic traffic 80 B per particle-update; the
 //   bound is HBM (8 TB/s -> 1.0e11 updates/s), with f64 VALU issue close
 //   behind (about 4-6 flop/B).
 #include "link.hpp"
@@ -33,9 +35,19 @@ int grid_check_err(const opal_grid_t *g);
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int TILE = 16;        // cells in a workgroup's LDS tile
+#ifndef OPAL_TILE
+#define OPAL_TILE 64
+#endif
+#ifndef OPAL_TILE_MARGIN
+#define OPAL_TILE_MARGIN 29
+#endif
+constexpr int TILE = OPAL_TILE;        // cells in a workgroup's LDS tile
+constexpr int TILE_MARGIN = OPAL_TILE_MARGIN;  // tile cells below the chunk's lowest cell (room for leftward drift)
 #ifndef OPAL_REPL
-#define OPAL_REPL 32
+#define OPAL_REPL 8
+#endif
+#ifndef OPAL_PF_DEPTH
+#define OPAL_PF_DEPTH 1  // particle slots per lane kept in flight ahead of the one being processed
 #endif
 constexpr int REPL = OPAL_REPL;        // lane-private replicas per accumulator
 constexpr int TILE_LO = 3;      // a particle whose old cell sits at tile offset in [TILE_LO, TILE - 4]
@@ -300,16 +312,31 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
     cp.chunk0 = chunk0;
     const unsigned nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
 
-    // The first slot's loads go out before anything else: its cell also decides the tile base, and the
-    // other five values are in flight while the tile is set up.
+    // The first slots' loads go out before anything else: the first cell also decides the tile base, and
+    // the other values are in flight while the tile is set up.  PF_DEPTH slots per lane stay in flight.
+    struct Slot {
+        int c;
+        double x, ux, uy, uz, w, prev;
+        bool have;
+    };
+    auto fetch = [&](unsigned kk, bool ok) {
+        Slot sl;
+        sl.have = ok;
+        sl.c = DEAD_CELL;
+        sl.x = sl.ux = sl.uy = sl.uz = sl.w = sl.prev = 0.0;
+        if (ok) {
+            sl.c = ldk(cp.cell, kk); sl.x = ldk(cp.x, kk); sl.ux = ldk(cp.ux, kk); sl.uy = ldk(cp.uy, kk);
+            sl.uz = ldk(cp.uz, kk); sl.w = ldk(cp.w, kk);
+            if (MODE == MODE_DEPOSIT) sl.prev = ldk(cp.prev, kk);
+        }
+        return sl;
+    };
     unsigned k = tid;
-    bool have = k < nloc;
-    int c_n = DEAD_CELL;
-    double x_n = 0.0, ux_n = 0.0, uy_n = 0.0, uz_n = 0.0, w_n = 0.0, prev_n = 0.0;
-    if (have) {
-        c_n = ldk(cp.cell, k); x_n = ldk(cp.x, k); ux_n = ldk(cp.ux, k); uy_n = ldk(cp.uy, k); uz_n = ldk(cp.uz, k); w_n = ldk(cp.w, k);
-        if (MODE == MODE_DEPOSIT) prev_n = ldk(cp.prev, k);
-    }
+    Slot s_n = fetch(k, k < nloc);
+#if OPAL_PF_DEPTH == 2
+    Slot s_m = fetch(k + BLOCK, a.ppt > 1 && k + BLOCK < nloc);
+#endif
+    const int c_n = s_n.c;
     // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin.  Slots that
     // hold far-away cells (particles that wrapped around a periodic domain, arrivals appended from both
     // neighbours) must not drag the tile away from the bulk: when the cells of the first slots span more
@@ -349,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
         int votes = s_max[0] + s_max[1] + s_max[2] + s_max[3];
         if (votes > 0) cmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
     }
-    const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - 4;  // array index of tile cell 0
+    const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - TILE_MARGIN;  // array index of tile cell 0
     if (GATHER) {
         for (int q = tid; q < 6 * TILE; q += BLOCK) {
             int comp = q / TILE, j = base + (q % TILE);
@@ -372,16 +399,17 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
     unsigned pending = 0;
     for (int p = 0; p < a.ppt; p++) {
         const unsigned kc = k;
-        const bool live = have && c_n != DEAD_CELL;
-        int c = c_n;
-        const double xi = x_n, wt = w_n, prev = prev_n;
-        const V3 u = {ux_n, uy_n, uz_n};
+        const bool live = s_n.have && s_n.c != DEAD_CELL;
+        int c = s_n.c;
+        const double xi = s_n.x, wt = s_n.w, prev = s_n.prev;
+        const V3 u = {s_n.ux, s_n.uy, s_n.uz};
         k += BLOCK;
-        have = (p + 1 < a.ppt) && k < nloc;
-        if (have) {
-            c_n = ldk(cp.cell, k); x_n = ldk(cp.x, k); ux_n = ldk(cp.ux, k); uy_n = ldk(cp.uy, k); uz_n = ldk(cp.uz, k); w_n = ldk(cp.w, k);
-            if (MODE == MODE_DEPOSIT) prev_n = ldk(cp.prev, k);
-        }
+#if OPAL_PF_DEPTH == 2
+        s_n = s_m;
+        s_m = fetch(k + BLOCK, (p + 2 < a.ppt) && k + BLOCK < nloc);
+#else
+        s_n = fetch(k, (p + 1 < a.ppt) && k < nloc);
+#endif
         if (!live) continue;
         int rel = c + a.L - base;
         bool ok, in_tile;
