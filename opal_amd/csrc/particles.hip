@@ -994,10 +994,10 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
         hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
         p->ctr_pending = false;
     }
-    // size the per-workgroup chunk so that it spans about 4 occupied cells (TILE holds ~10 with margins)
+    // size the per-workgroup chunk so that it spans at most about a quarter of the tile
     unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
     double per_cell = (double)p->h_ctr->n_live / ne;
-    int ppt = (int)(4.0 * per_cell / BLOCK);
+    int ppt = (int)((TILE / 4) * per_cell / BLOCK);
     p->ppt = std::max(1, std::min(8, ppt));
     return OPAL_OK;
 }
