@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 using namespace opal;
 
@@ -780,6 +781,48 @@ void free_set(opal_pop_t *p, int k)
     p->d_cell[k] = nullptr;
 }
 
+// Enlarges the population's storage (HBM is plentiful: 288 GB): new arrays, device-to-device copy of
+// the slots in use, old arrays freed.  Synchronises the stream.
+int grow(opal_pop_t *p, size_t new_cap)
+{
+    if (new_cap >= (size_t)1 << 31) {
+        set_error("population would exceed 2^31 slots per subdomain");
+        return OPAL_ERR_CAPACITY;
+    }
+    OPAL_HIP(hipStreamSynchronize(p->stream));
+    size_t used = p->n_upper, old_cap = p->cap;
+    auto regrow = [&](auto *&ptr) -> int {
+        using T = std::remove_pointer_t<std::remove_reference_t<decltype(ptr)>>;
+        T *fresh = nullptr;
+        OPAL_HIP(hipMalloc(&fresh, sizeof(T) * new_cap));
+        if (ptr && used) OPAL_HIP(hipMemcpy(fresh, ptr, sizeof(T) * std::min(used, old_cap), hipMemcpyDeviceToDevice));
+        if (ptr) hipFree(ptr);
+        ptr = fresh;
+        return OPAL_OK;
+    };
+    int k = p->cur;
+    if (int rc = regrow(p->d_cell[k])) return rc;
+    if (int rc = regrow(p->d_x[k])) return rc;
+    if (int rc = regrow(p->d_ux[k])) return rc;
+    if (int rc = regrow(p->d_uy[k])) return rc;
+    if (int rc = regrow(p->d_uz[k])) return rc;
+    if (int rc = regrow(p->d_w[k])) return rc;
+    if (p->d_prev_x)
+        if (int rc = regrow(p->d_prev_x)) return rc;
+    if (p->have_alt) {  // the spare set holds nothing between re-binnings
+        free_set(p, k ^ 1);
+        p->have_alt = false;
+    }
+    if (p->d_chi) {
+        if (int rc = regrow(p->d_chi)) return rc;
+        if (int rc = regrow(p->d_work)) return rc;
+        if (int rc = regrow(p->d_y)) return rc;
+        if (int rc = regrow(p->d_z)) return rc;
+    }
+    p->cap = new_cap;
+    return OPAL_OK;
+}
+
 int ensure_prev(opal_pop_t *p)
 {
     if (!p->d_prev_x) OPAL_HIP(hipMalloc(&p->d_prev_x, sizeof(double) * p->cap));
@@ -907,8 +950,9 @@ int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
         if (!p->extras && p->n_upper)
             if (int rc = do_sort(p, g)) return rc;
         if (p->n_upper + incoming > p->cap) {
-            set_error("population capacity %zu too small for %zu slots + %zu possible arrivals", p->cap, p->n_upper, incoming);
-            return OPAL_ERR_CAPACITY;
+            // a subdomain that plasma is moving into: make room (1.5x what is needed now)
+            size_t want = (p->n_upper + incoming) + (p->n_upper + incoming) / 2;
+            if (int rc = grow(p, want)) return rc;
         }
     }
     UnpackArgs u;

@@ -71,7 +71,30 @@ def main():
     link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=128) if world > 1 else None
     dx = 1.0e-8
     dt = 0.95 * dx / C
-    if mode == "ops":
+    if mode == "grow":
+        # everything starts on rank 0 and streams to the right through open boundaries: rank 1 starts
+        # empty (minimum capacity) and has to enlarge its storage as the particles arrive
+        left, right = oa.BDY_LASER, oa.BDY_ABSORBING
+        nxs, offs = oa.design_unbalanced(world, nx, dx)
+        g = oa.Grid(rank, world, left, right, 0.0, dx, nxs, offs)
+        rng = np.random.default_rng(9)
+        n = nx * npc
+        cell = rng.integers(0, nx // 2, n)
+        st = (cell, rng.random(n), 0.5 + 0.05 * rng.standard_normal(n), np.zeros(n), np.zeros(n),
+              1.0e3 * (1.0 + 1e-9 * np.arange(n)))
+        pe = oa.Population.from_soa(oa.ELECTRON, *split(st, nxs, rank), dx, dt, capacity=1024 if rank else None)
+        pi = oa.Population.from_soa(oa.ION, *split(st, nxs, rank), dx, dt, capacity=1024 if rank else None)
+        t = 0.0
+        zero = lambda t_, x_: 0.0
+        for _ in range(steps):
+            g.clear()
+            pe.advance_deposit(g, dt, link)
+            pi.advance_deposit(g, dt, link)
+            g.synchronize(zero, zero, t, dt, link)
+            g.advance(dt)
+            t += dt
+        dump(outdir, rank, g, pe, pi)
+    elif mode == "ops":
         nxs, offs = oa.design_unbalanced(world, nx, dx)
         g = oa.Grid(rank, world, oa.BDY_INTERNAL, oa.BDY_INTERNAL, 0.0, dx, nxs, offs)
         se, si = global_state(nx, npc, dx, 5), global_state(nx, npc, dx, 6)

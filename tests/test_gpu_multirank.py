@@ -84,3 +84,38 @@ def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world):
         assert abs(got[r]["ke_e"] - pes[r].total_kinetic_energy()) / pes[r].total_kinetic_energy() < 1e-11
         assert len(got[r]["e_w"]) == len(pes[r]) and len(got[r]["i_w"]) == len(pis[r])
     assert sum(len(g["e_w"]) for g in got) == nx * npc
+
+
+def test_receiving_subdomain_grows_its_storage(oracle, tmp_path):
+    """All particles start on rank 0 and stream into rank 1, which starts with the minimum capacity."""
+    o = oracle
+    world, nx, npc, steps = 2, 48, 60, 70
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    _launch("_gloo_hip_worker.py", world, ["grow", tmp_path, nx, npc, steps, 1])
+    nxs, offs = o.design_unbalanced(world, nx, dx)
+    rng = np.random.default_rng(9)
+    n = nx * npc
+    cell = rng.integers(0, nx // 2, n)
+    st = (cell, rng.random(n), 0.5 + 0.05 * rng.standard_normal(n), np.zeros(n), np.zeros(n),
+          1.0e3 * (1.0 + 1e-9 * np.arange(n)))
+    grids = [o.Grid(r, world, o.BDY_LASER, o.BDY_ABSORBING, 0.0, dx, nxs, offs) for r in range(world)]
+    pes = [o.Population.from_soa(o.ELECTRON, *split(st, nxs, r), dx, dt) for r in range(world)]
+    pis = [o.Population.from_soa(o.ION, *split(st, nxs, r), dx, dt) for r in range(world)]
+    t = 0.0
+    zero = lambda t_, x_: 0.0
+    for _ in range(steps):
+        assert o.world_step(grids, pes, pis, True, t, dt, laser_y=zero, laser_z=zero) == 0
+        t += dt
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    assert len(pes[1]) > 1024  # more than rank 1's initial capacity arrived
+    for r in range(world):
+        assert len(got[r]["e_w"]) == len(pes[r]) and len(got[r]["i_w"]) == len(pis[r])
+        a = _by_w(got[r], "e")
+        ref = pes[r].soa()
+        order = np.argsort(ref["w"], kind="stable")
+        assert np.array_equal(a["w"], ref["w"][order])
+        assert np.array_equal(a["cell"], ref["cell"][order].astype(np.int32))
+        # (electrons and the unit-charge ions move together here, so the fields are pure round-off
+        # noise and not compared)
+        assert np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
