@@ -59,7 +59,7 @@ def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused
             a = _by_w(got, name)
             assert np.array_equal(a["w"], ref["w"][order]), (r, name)  # same particles on the same rank
             assert np.array_equal(a["cell"], ref["cell"][order].astype(np.int32))
-            assert np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
+            assert len(a["x"]) == 0 or np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
         total += len(got["e_w"])
     assert total == nx * npc
 
@@ -118,4 +118,4 @@ def test_receiving_subdomain_grows_its_storage(oracle, tmp_path):
         assert np.array_equal(a["cell"], ref["cell"][order].astype(np.int32))
         # (electrons and the unit-charge ions move together here, so the fields are pure round-off
         # noise and not compared)
-        assert np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
+        assert len(a["x"]) == 0 or np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
