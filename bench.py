@@ -122,14 +122,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    oa.set_device(local_rank)
+    # OPAL_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the
+    # visible GPUs and exchange through host buffers.  The driver's runs use nccl (= RCCL over xGMI).
+    backend = os.environ.get("OPAL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    oa.set_device(dev_index)
     link = None
     if world > 1:
         import torch.distributed as dist
         from opal_amd.exchange import TorchLink
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        link = TorchLink(rank, world, torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            link = TorchLink(rank, world, torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+            link = TorchLink(rank, world, torch.device("cpu"))
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     stream = torch.cuda.current_stream().cuda_stream
     nx = CELLS_PER_GPU * world
@@ -162,10 +171,10 @@ def main():
     n_total = n_local
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nn = torch.tensor([n_local], dtype=torch.float64, device="cuda")
+        nn = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         n_total = int(nn.item())
 

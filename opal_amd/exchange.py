@@ -78,6 +78,7 @@ class TorchLink:
         if rc:
             raise RuntimeError(self._lib.opal_last_error().decode())
         self.calls = 0
+        self._ops = {}
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -86,9 +87,25 @@ class TorchLink:
 
     def _exchange(self, user, send_left, send_right, recv_left, recv_right, nbytes):
         try:
-            sl, sr, rl, rr = self.bufs
-            self.transport.exchange(sl[:nbytes] if send_left else None, sr[:nbytes] if send_right else None,
-                                    rl[:nbytes] if recv_left else None, rr[:nbytes] if recv_right else None)
+            # the same few (size, directions) combinations recur every step: build the op list once
+            key = (nbytes, bool(send_left), bool(send_right), bool(recv_left), bool(recv_right))
+            ops = self._ops.get(key)
+            if ops is None:
+                sl, sr, rl, rr = self.bufs
+                tr = self.transport
+                ops = []
+                if send_left:
+                    ops.append(dist.P2POp(dist.isend, sl[:nbytes], tr.left, tr.group, TAG_LEFTWARD))
+                if send_right:
+                    ops.append(dist.P2POp(dist.isend, sr[:nbytes], tr.right, tr.group, TAG_RIGHTWARD))
+                if recv_right:
+                    ops.append(dist.P2POp(dist.irecv, rr[:nbytes], tr.right, tr.group, TAG_LEFTWARD))
+                if recv_left:
+                    ops.append(dist.P2POp(dist.irecv, rl[:nbytes], tr.left, tr.group, TAG_RIGHTWARD))
+                self._ops[key] = ops
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
             self.calls += 1
             return 0
         except Exception:  # never let an exception cross the C boundary
