@@ -8,8 +8,9 @@ cell (2 x 9 998 336 macro-particles), periodic, current deposition on, no QED; w
 domain is N x 4096 cells split into N subdomains (weak scaling).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused push+deposit
-pass): algorithmic bytes = 80 B per particle-update x particles per launch, divided
-by the kernel's mean duration measured with HIP events around every launch in the timed region.
+pass; one launch covers both species): algorithmic bytes = 80 B per particle-update x
+particles per launch, divided by the kernel's mean duration measured with HIP events around a 1-in-5
+sample of its launches in the timed region.
 `cpu_baseline` times the CPU oracle (a port of the reference's algorithm, not the opal binary) on a
 bounded sample of the same workload on this box's host cores.
 """
@@ -182,15 +183,17 @@ def main():
     launches, total_ms = oa.prof_get(kname)
     sort_launches, sort_ms = oa.prof_get("sort")
     field_launches, field_ms = oa.prof_get("field")
-    # the dominant kernel runs once per species per step; each launch covers that species' particles
-    per_launch_particles = n_local / 2.0
+    # the dominant kernel covers this rank's particles once per step, in one launch (species paired) or two
+    launches_total = oa.prof_seen(kname)
+    per_launch_particles = n_local * args.steps / max(launches_total, 1)
     avg_ms = total_ms / max(launches, 1)
     achieved = BYTES_PER_UPDATE * per_launch_particles / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            # PMC-measured HBM bytes per particle-update (profiles/r01_pmc_hbm.json) x updates per launch
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_particle_update") * per_launch_particles
         except Exception:
             traffic = None
 
@@ -227,7 +230,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "launches_timed": launches,
-                "launches_total": 2 * args.steps,
+                "launches_total": launches_total,
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * per_launch_particles,
                 "other_kernels_avg_ms": {"field_solve": field_ms / max(field_launches, 1), "rebin": sort_ms / max(sort_launches, 1)},

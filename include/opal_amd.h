@@ -218,8 +218,11 @@ int opal_sim_set_fused(opal_sim_t *s, int fused);
  * launch of each tracked kernel (an odd n samples both species, which alternate) */
 int opal_prof_enable(int stride);
 int opal_prof_reset(void);
-/* kernel ids: 0 = fused advance+deposit, 1 = advance, 2 = deposit, 3 = field solve, 4 = sort */
+/* kernel ids: 0 = fused advance+deposit (one launch covers both species when the driver pairs them),
+ * 1 = advance, 2 = deposit, 3 = field solve, 4 = re-binning; launches = launches actually timed */
 int opal_prof_get(int kernel, uint64_t *launches, double *total_ms);
+/* launches of the kernel observed since the last reset while the timers were on (timed or not) */
+int opal_prof_seen(int kernel, uint64_t *launches_seen);
 
 /* Text forms used by the reference's outputs: kind 0 = SimulationTime (setup.rs:421-438), 1 = Rust {:e}
  * (yee.rs:768), 2 = {:.6e} (main.rs:35-38), 3 = {} (yee.rs:768, last column) */

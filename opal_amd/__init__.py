@@ -379,6 +379,12 @@ def prof_reset():
     _check(_lib.load().opal_prof_reset())
 
 
+def prof_seen(kernel):
+    n = C.c_uint64()
+    _check(_lib.load().opal_prof_seen(KERNELS[kernel], C.byref(n)))
+    return n.value
+
+
 def prof_get(kernel):
     n = C.c_uint64()
     ms = C.c_double()

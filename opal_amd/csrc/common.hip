@@ -137,6 +137,17 @@ int opal_prof_reset(void)
     return OPAL_OK;
 }
 
+int opal_prof_seen(int kernel, uint64_t *launches_seen)
+{
+    if (kernel < 0 || kernel >= KERNEL_COUNT || !launches_seen) {
+        set_error("opal_prof_seen: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    *launches_seen = g_prof[kernel].seen;
+    return OPAL_OK;
+}
+
 int opal_prof_get(int kernel, uint64_t *launches, double *total_ms)
 {
     if (kernel < 0 || kernel >= KERNEL_COUNT) {

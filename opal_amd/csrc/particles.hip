@@ -72,9 +72,6 @@ struct PushArgs {
     int left_mode, right_mode;
     PopCounters *ctr;
     // leaver buffers (EDGE_SEND) inside the link's send messages: SoA blocks of `send_cap` particles
-#ifdef OPAL_STAMPS
-    unsigned long long *stamps;  // diagnostic build only: [block][8] timeline stamps
-#endif
     unsigned *send_count[2];
     int *send_cell[2];
     double *send_f[2];  // x ux uy uz w prev_x, 6 x send_cap
@@ -278,31 +275,15 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
 //   MODE_DEPOSIT : YeeGrid::deposit's per-particle body, yee.rs:573-610.
 //   MODE_FUSED   : both in one pass (prev_x stays in registers).
 template <int SPECIES, int MODE, bool RHO, bool EXTRAS>
-__global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
+__device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, double *s_field, double *s_acc, int *s_min,
+                                          int *s_max)
 {
     constexpr bool GATHER = MODE != MODE_DEPOSIT;
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
-    __shared__ double s_field[GATHER ? 6 * TILE : 1];
-    __shared__ double s_acc[DEPOSIT ? 4 * TILE * REPL : 1];
-    __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
-
     const int tid = threadIdx.x;
     const int lane = tid & (REPL - 1);
-#ifdef OPAL_STAMPS
-#define STAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    if (a.stamps && tid == 0) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        a.stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
-    }
-#else
-#define STAMP(k)
-#endif
-    STAMP(0);
     const unsigned n = a.ctr->n_slots;
-    const size_t chunk0 = (size_t)blockIdx.x * BLOCK * a.ppt;
+    const size_t chunk0 = (size_t)block * BLOCK * a.ppt;
     if (chunk0 >= n) return;
 
     ChunkPtrs cp;
@@ -385,7 +366,6 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
         }
         __syncthreads();
     }
-    STAMP(1);
     int err = 0;
     // A single periodic subdomain: a particle that wrapped around sits in a chunk at the other end of
     // the array.  Its periodic image (cell -1 or `size`, i.e. a ghost cell: E and B there are copies
@@ -436,7 +416,6 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
         if (in_tile) process_particle<SPECIES, MODE, RHO, EXTRAS, true>(a, cp, s_field, s_acc, base, lane, kc, c, xi, u, wt, prev, err);
         else pending |= 1u << p;
     }
-    STAMP(2);
     // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.
     if (pending) {
         unsigned slow = 0;
@@ -454,7 +433,6 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
 
     if (DEPOSIT) {
         __syncthreads();
-        STAMP(3);
         // fold the REPL replicas of each (component, cell) and add to the grid: one lane per accumulator,
         // rotated start so that the 64 lanes of a wave read 64 different banks.
         constexpr int NACC = (RHO ? 4 : 3) * TILE;
@@ -467,7 +445,28 @@ __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
             if (s != 0.0 && j >= 0 && j < a.len) atomicAdd(a.jr + (size_t)comp * a.lenp + j, s);
         }
     }
-    STAMP(4);
+}
+
+template <int SPECIES, int MODE, bool RHO, bool EXTRAS>
+__global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
+{
+    __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
+    __shared__ double s_acc[MODE != MODE_ADVANCE ? 4 * TILE * REPL : 1];
+    __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
+    push_body<SPECIES, MODE, RHO, EXTRAS>(a, blockIdx.x, s_field, s_acc, s_min, s_max);
+}
+
+// Both charged species of a step in one launch: the first `nblk_e` workgroups take electrons, the rest
+// ions.  One launch instead of two means one ragged tail of finishing workgroups per step instead of two
+// (the species are independent: both read the fields and add into the same current arrays atomically).
+template <int MODE, bool RHO>
+__global__ __launch_bounds__(BLOCK) void k_push_pair(PushArgs ae, PushArgs ai, unsigned nblk_e)
+{
+    __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
+    __shared__ double s_acc[MODE != MODE_ADVANCE ? 4 * TILE * REPL : 1];
+    __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
+    if (blockIdx.x < nblk_e) push_body<OPAL_ELECTRON, MODE, RHO, false>(ae, blockIdx.x, s_field, s_acc, s_min, s_max);
+    else push_body<OPAL_ION, MODE, RHO, false>(ai, blockIdx.x - nblk_e, s_field, s_acc, s_min, s_max);
 }
 
 // ------------------------------------------------------------------ re-binning
@@ -849,10 +848,8 @@ void launch_push(const PushArgs &a, unsigned nblk, bool extras, hipStream_t s)
         k_push<SPECIES, MODE, true, false><<<nblk, BLOCK, 0, s>>>(a);
 }
 
-int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode)
+int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode, PushArgs &a, unsigned &nblk)
 {
-    if (p->n_upper == 0) return OPAL_OK;
-    PushArgs a;
     memset(&a, 0, sizeof a);
     int k = p->cur;
     a.cell = p->d_cell[k]; a.x = p->d_x[k]; a.ux = p->d_ux[k]; a.uy = p->d_uy[k]; a.uz = p->d_uz[k]; a.w = p->d_w[k];
@@ -892,20 +889,16 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
         a.send_cap = (unsigned)link->cap;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
-    unsigned nblk = (unsigned)((p->n_upper + per_block - 1) / per_block);
-#ifdef OPAL_STAMPS
-    static unsigned long long *d_stamps = nullptr;
-    static int stamp_launch = 0;
-    a.stamps = nullptr;
-    if (getenv("OPAL_DEBUG_STAMPS") && mode == MODE_FUSED && p->species == OPAL_ELECTRON) {
-        stamp_launch++;
-        if (stamp_launch == 30) {
-            hipMalloc(&d_stamps, sizeof(unsigned long long) * 8 * nblk);
-            hipMemset(d_stamps, 0, sizeof(unsigned long long) * 8 * nblk);
-            a.stamps = d_stamps;
-        }
-    }
-#endif
+    nblk = (unsigned)((p->n_upper + per_block - 1) / per_block);
+    return OPAL_OK;
+}
+
+int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode)
+{
+    if (p->n_upper == 0) return OPAL_OK;
+    PushArgs a;
+    unsigned nblk;
+    if (int rc = build_args(p, link, g, dt, mode, a, nblk)) return rc;
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, p->stream);
     bool ex = p->extras;
@@ -920,20 +913,24 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     }
     prof_end(kid, p->stream);
     OPAL_HIP(hipGetLastError());
-#ifdef OPAL_STAMPS
-    if (a.stamps) {
-        std::vector<unsigned long long> h((size_t)8 * nblk);
-        hipStreamSynchronize(p->stream);
-        hipMemcpy(h.data(), d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
-        FILE *fp = fopen(getenv("OPAL_DEBUG_STAMPS"), "w");
-        for (unsigned b = 0; b < nblk; b++) {
-            fprintf(fp, "%u", b);
-            for (int k = 0; k < 8; k++) fprintf(fp, " %llu", h[(size_t)b * 8 + k]);
-            fprintf(fp, "\n");
-        }
-        fclose(fp);
+    return OPAL_OK;
+}
+
+// electrons and ions of one step in a single launch (fused pass only)
+int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt)
+{
+    if (pe->n_upper == 0 || pi->n_upper == 0 || pe->extras || pe->stream != pi->stream) {
+        if (int rc = run_push(pe, link, g, dt, MODE_FUSED)) return rc;
+        return run_push(pi, link, g, dt, MODE_FUSED);
     }
-#endif
+    PushArgs ae, ai;
+    unsigned ne, ni;
+    if (int rc = build_args(pe, link, g, dt, MODE_FUSED, ae, ne)) return rc;
+    if (int rc = build_args(pi, link, g, dt, MODE_FUSED, ai, ni)) return rc;
+    prof_begin(KERNEL_FUSED, pe->stream);
+    k_push_pair<MODE_FUSED, true><<<ne + ni, BLOCK, 0, pe->stream>>>(ae, ai, ne);
+    prof_end(KERNEL_FUSED, pe->stream);
+    OPAL_HIP(hipGetLastError());
     return OPAL_OK;
 }
 
@@ -1400,6 +1397,14 @@ int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, 
     p->prev_valid = false;
     return run_push(p, link, g, dt, MODE_FUSED);
 }
+// both species of a fused step in one launch; no exchange, no re-binning bookkeeping
+int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt)
+{
+    pe->prev_valid = false;
+    pi->prev_valid = false;
+    return run_push_pair(pe, pi, link, g, dt);
+}
+int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
 int pop_unpack_and_maybe_sort(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
 {
     if (int rc = unpack_arrivals(p, link, g)) return rc;

@@ -23,6 +23,8 @@ namespace opal {
 int pop_check_err(opal_pop_t *p);
 int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_unpack_and_maybe_sort(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g);
+int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
+int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
 int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right);
 int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz);
 }
@@ -481,10 +483,14 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             hipStream_t st = (hipStream_t)s->stream;
             if (int rc = opal_grid_clear(g)) return rc;
             if (int rc = link_begin(s->link, st)) return rc;
-            if (s->electrons)
-                if (int rc = pop_push_fused_noexchange(s->electrons, s->link, g, s->dt)) return rc;
-            if (s->ions)
-                if (int rc = pop_push_fused_noexchange(s->ions, s->link, g, s->dt)) return rc;
+            if (s->electrons && s->ions) {
+                if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, s->link, g, s->dt)) return rc;
+            } else {
+                if (s->electrons)
+                    if (int rc = pop_push_fused_noexchange(s->electrons, s->link, g, s->dt)) return rc;
+                if (s->ions)
+                    if (int rc = pop_push_fused_noexchange(s->ions, s->link, g, s->dt)) return rc;
+            }
             const double *rl = nullptr, *rr = nullptr;
             if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr)) return rc;
             if (int rc = link_exchange(s->link, s->link->nbytes, opal_grid_to_left(g) >= 0, opal_grid_to_right(g) >= 0, st)) return rc;
@@ -507,10 +513,17 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         if (s->fused && s->current_deposition) {
             // clear first, then one pass per species that pushes and deposits
             if (int rc = opal_grid_clear(s->grid)) return rc;
-            if (s->electrons)
-                if (int rc = opal_pop_advance_deposit(s->electrons, s->link, s->grid, s->dt)) return rc;
-            if (s->ions)
-                if (int rc = opal_pop_advance_deposit(s->ions, s->link, s->grid, s->dt)) return rc;
+            if (s->electrons && s->ions && !linked) {
+                // both species in one launch, then the re-binning bookkeeping of each
+                if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, nullptr, s->grid, s->dt)) return rc;
+                if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
+                if (int rc = pop_maybe_sort(s->ions, s->grid)) return rc;
+            } else {
+                if (s->electrons)
+                    if (int rc = opal_pop_advance_deposit(s->electrons, s->link, s->grid, s->dt)) return rc;
+                if (s->ions)
+                    if (int rc = opal_pop_advance_deposit(s->ions, s->link, s->grid, s->dt)) return rc;
+            }
         } else {
             if (s->electrons)
                 if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) return rc;
