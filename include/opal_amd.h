@@ -38,6 +38,7 @@ typedef struct opal_grid opal_grid_t; /* YeeGrid, src/grid/yee.rs:255-269 */
 typedef struct opal_pop opal_pop_t;   /* Population<Electron|Ion>, src/particle/mod.rs:141-145 */
 typedef struct opal_link opal_link_t; /* neighbour exchange; stands in for `impl Communicator` */
 typedef struct opal_sim opal_sim_t;   /* main()'s state, src/main.rs:48-215 */
+typedef struct opal_hist opal_hist_t; /* Histogram, src/particle/hgram.rs:71-84 */
 
 /* enum Boundary, src/grid/mod.rs:22-28 */
 enum opal_boundary { OPAL_BDY_INTERNAL = 0, OPAL_BDY_LASER = 1, OPAL_BDY_ABSORBING = 2, OPAL_BDY_CONDUCTING = 3 };
@@ -162,6 +163,30 @@ int opal_pop_counters(const opal_pop_t *p, uint32_t *out);
 /* carry y, z, chi, work, tau for electrons (electron.rs:18-25); off by default */
 int opal_pop_track_extras(opal_pop_t *p, int on);
 int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z);
+
+/* ------------------------------------------------------------------ Distribution functions
+ * Population::write_data (mod.rs:383-568) and Histogram (hgram.rs:168-425).  `spec` is one entry of the
+ * input file's `output:` list: "x", "x:px", "energy:(log;energy)", ...  The accessors, the min/max
+ * pass and the weighted binning run on the GPU.  The reference's MPI all-reductions (hgram.rs:190-192,
+ * 249, 260) are the caller's: range -> reduce min/max/count -> fill -> sum counts and totals -> finish
+ * -> write.  Specs the reference silently skips (unknown quantity or weight) return OPAL_ERR_CONFIG. */
+int opal_pop_hist_range(const opal_pop_t *p, const opal_grid_t *g, const char *spec, int *dim, double *min, double *max,
+                        size_t *count);
+int opal_pop_hist_fill(const opal_pop_t *p, const opal_grid_t *g, const char *spec, const double *gmin, const double *gmax,
+                       size_t gnum, opal_hist_t **out);
+size_t opal_hist_len(const opal_hist_t *h);
+double *opal_hist_counts(opal_hist_t *h);          /* host array of opal_hist_len doubles (raw until finish) */
+double opal_hist_total(const opal_hist_t *h);      /* total weight, hgram.rs:224 */
+int opal_hist_set_total(opal_hist_t *h, double global_total);
+int opal_hist_dims(const opal_hist_t *h, int *dim, size_t *nbins, double *min, double *bin_size);
+int opal_hist_finish(opal_hist_t *h);              /* density normalisation, hgram.rs:255-259; once */
+int opal_hist_write_fits(const opal_hist_t *h, const char *path);  /* hgram.rs:394-425 */
+int opal_hist_free(opal_hist_t *h);
+/* file name of mod.rs:527-559 (without CFITSIO's leading '!') */
+int opal_hist_filename(const char *dir, size_t index, const char *pop_name, const char *spec, char *out, size_t len);
+/* write_data for one subdomain: one FITS file per mappable spec */
+int opal_pop_write_data(const opal_pop_t *p, const opal_grid_t *g, const char *dir, size_t index, const char *pop_name,
+                        const char *const *specs, size_t nspecs);
 
 /* ------------------------------------------------------------------------ Link
  * Neighbour exchange for one subdomain of `size`.  The library fills fixed-size

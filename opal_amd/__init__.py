@@ -244,6 +244,36 @@ class Population:
         keys = ("slots", "deleted", "tile_misses", "steps_since_sort", "ppt", "live_at_sort", "nonempty_cells", "slots_upper")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def histogram(self, grid, spec):
+        """One `output:` spec -> dict(cts, nbins, min, bin_sz, total) for this subdomain
+        (Histogram::generate_1d/2d with HeightSpec::Density, hgram.rs:168-392)."""
+        dim = C.c_int()
+        mn = (C.c_double * 2)()
+        mx = (C.c_double * 2)()
+        n = C.c_size_t()
+        _check(self._lib.opal_pop_hist_range(self.h, grid.h, spec.encode(), C.byref(dim), mn, mx, C.byref(n)))
+        if n.value == 0:
+            return None
+        h = C.c_void_p()
+        _check(self._lib.opal_pop_hist_fill(self.h, grid.h, spec.encode(), mn, mx, n.value, C.byref(h)))
+        try:
+            _check(self._lib.opal_hist_finish(h))
+            nb = (C.c_size_t * 2)(1, 1)
+            hmin = (C.c_double * 2)()
+            bsz = (C.c_double * 2)()
+            _check(self._lib.opal_hist_dims(h, C.byref(dim), nb, hmin, bsz))
+            ln = self._lib.opal_hist_len(h)
+            cts = np.ctypeslib.as_array(self._lib.opal_hist_counts(h), shape=(ln,)).copy()
+            return {"cts": cts, "nbins": [int(nb[0]), int(nb[1])], "min": np.array(hmin), "max": np.array(mx),
+                    "bin_sz": np.array(bsz), "total": self._lib.opal_hist_total(h), "dim": dim.value}
+        finally:
+            self._lib.opal_hist_free(h)
+
+    def write_data(self, grid, directory, index, name, specs):
+        """Population::write_data (mod.rs:383-568) for one subdomain."""
+        arr = (C.c_char_p * len(specs))(*[s.encode() for s in specs])
+        _check(self._lib.opal_pop_write_data(self.h, grid.h, directory.encode(), index, name.encode(), arr, len(specs)))
+
     def track_extras(self, on=True):
         _check(self._lib.opal_pop_track_extras(self.h, 1 if on else 0))
 

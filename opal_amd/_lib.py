@@ -67,6 +67,18 @@ SIGNATURES = {
     "opal_pop_counters": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "opal_pop_track_extras": (C.c_int, [vp, C.c_int]),
     "opal_pop_download_extras": (C.c_int, [vp, vp, vp, vp, vp]),
+    "opal_pop_hist_range": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(C.c_int), vp, vp, C.POINTER(sz)]),
+    "opal_pop_hist_fill": (C.c_int, [vp, vp, C.c_char_p, vp, vp, sz, pp]),
+    "opal_hist_len": (sz, [vp]),
+    "opal_hist_counts": (C.POINTER(dbl), [vp]),
+    "opal_hist_total": (dbl, [vp]),
+    "opal_hist_set_total": (C.c_int, [vp, dbl]),
+    "opal_hist_dims": (C.c_int, [vp, C.POINTER(C.c_int), vp, vp, vp]),
+    "opal_hist_finish": (C.c_int, [vp]),
+    "opal_hist_write_fits": (C.c_int, [vp, C.c_char_p]),
+    "opal_hist_free": (C.c_int, [vp]),
+    "opal_hist_filename": (C.c_int, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.c_char_p, sz]),
+    "opal_pop_write_data": (C.c_int, [vp, vp, C.c_char_p, sz, C.c_char_p, C.POINTER(C.c_char_p), sz]),
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),
     "opal_link_free": (C.c_int, [vp]),
     "opal_link_message_bytes": (sz, [vp]),

@@ -149,6 +149,7 @@ struct opal_sim {
     opal_grid_t *grid = nullptr;
     opal_pop_t *electrons = nullptr, *ions = nullptr;
     std::string ion_name;
+    std::vector<std::string> electron_output, ion_output;  // the `output:` lists (main.rs:117,134)
     double t = 0;
     size_t total_steps = 0, steps_bt_output = 0;
     bool fused = true;
@@ -242,9 +243,9 @@ int sim_setup(opal_sim_t *s)
     Rng rng;
     rng.seed((uint64_t)s->rank);  // main.rs:53
     size_t epc;
-    std::vector<std::string> ospec;
+    std::vector<std::string> &ospec = s->ion_output;
     if (!in.read_usize("electrons", "npc", epc, ce)) return config_fail(ce);
-    if (!in.read_strings("electrons", "output", ospec, ce)) return config_fail(ce);
+    if (!in.read_strings("electrons", "output", s->electron_output, ce)) return config_fail(ce);
     if (epc > 0) {
         if (int rc = load_species(s, "electrons", "ne", OPAL_ELECTRON, epc, rng, &s->electrons)) return rc;
     }
@@ -591,8 +592,19 @@ int opal_sim_run(opal_sim_t *s)
         set_error("opal_sim_run writes single-subdomain output; drive multi-subdomain runs with opal_sim_step");
         return OPAL_ERR_ARG;
     }
+    auto write_pops = [&](size_t i) -> int {  // main.rs:219-221
+        auto one = [&](opal_pop_t *p, const std::string &name, const std::vector<std::string> &specs) -> int {
+            if (!p || specs.empty()) return OPAL_OK;
+            std::vector<const char *> cs;
+            for (auto &sp : specs) cs.push_back(sp.c_str());
+            return opal_pop_write_data(p, s->grid, s->output_dir.c_str(), i, name.c_str(), cs.data(), cs.size());
+        };
+        if (int rc = one(s->electrons, "electron", s->electron_output)) return rc;
+        return one(s->ions, s->ion_name, s->ion_output);
+    };
     for (size_t i = 0; i < s->n_outputs; i++) {
         if (int rc = opal_grid_write_data(s->grid, s->output_dir.c_str(), i)) return rc;
+        if (int rc = write_pops(i)) return rc;
         if (int rc = write_energies(s, i)) return rc;
         printf("Output %4zu at t = %s...\n", i, simulation_time(s->t).c_str());
         fflush(stdout);
@@ -600,6 +612,7 @@ int opal_sim_run(opal_sim_t *s)
         if (int rc = opal_sim_sync(s)) return rc;
     }
     if (int rc = opal_grid_write_data(s->grid, s->output_dir.c_str(), s->n_outputs)) return rc;
+    if (int rc = write_pops(s->n_outputs)) return rc;
     if (int rc = write_energies(s, s->n_outputs)) return rc;
     printf("Output %4zu at t = %s\n", s->n_outputs, simulation_time(s->t).c_str());
     return OPAL_OK;

@@ -1043,3 +1043,137 @@ int oracle_max_threads(void)
     return 1;
 #endif
 }
+
+/* ----------------------------------------------------- distribution functions
+ * Population::write_data's accessors (particle/mod.rs:388-449) and
+ * Histogram::generate_1d / generate_2d (particle/hgram.rs:168-392) for one
+ * subdomain (the MPI all-reductions are identities).  HeightSpec is always
+ * Density (mod.rs:459-466).  acc ids: 0 x, 1 r, 2 energy, 3 px, 4 py, 5 pz,
+ * 6 p_perp, 7 theta, 8 phi, 9 longitude, 10 latitude, 11 work, 12 chi.
+ * bkind: 0 auto, 1 log, 2 fixed number, 3 fixed size.  weight_kind: 0 weight,
+ * 1 energy * weight.  Not pinned by any reference test (its histogram tests are
+ * #[ignore]d smoke tests). */
+static void p_momentum(const Population *p, size_t i, double *mom)
+{
+    if (p->species == SPECIES_ELECTRON) {  /* electron.rs:157-160 */
+        const Electron *e = &((const Electron *)p->store)[i];
+        for (int k = 0; k < 3; k++) mom[k] = e->u[k] * ELECTRON_MASS_MEV;
+    } else {  /* ion.rs:140-143 */
+        const Ion *e = &((const Ion *)p->store)[i];
+        for (int k = 0; k < 3; k++) mom[k] = e->u[k] * (e->A * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV;
+    }
+}
+static double p_energy(const Population *p, size_t i)
+{
+    if (p->species == SPECIES_ELECTRON) return ((const Electron *)p->store)[i].gamma * ELECTRON_MASS_MEV; /* electron.rs:118 */
+    const Ion *e = &((const Ion *)p->store)[i];
+    return e->gamma_m1 * (e->A * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV; /* ion.rs:128 */
+}
+static double p_weight(const Population *p, size_t i)
+{
+    return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].weight : ((const Ion *)p->store)[i].weight;
+}
+static double p_access(const Population *p, const YeeGrid *g, int id, size_t i)
+{
+    double m[3];
+    p_momentum(p, i, m);
+    switch (id) {
+    case 0: {
+        long c = pcell(p, i);
+        double x = p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].x : ((const Ion *)p->store)[i].x;
+        return oracle_grid_xmin(g) + (((double)c) + x) * g->dx;
+    }
+    case 1: return p->species == SPECIES_ELECTRON ? hypot(((const Electron *)p->store)[i].y, ((const Electron *)p->store)[i].z) : 0.0;
+    case 2: return p_energy(p, i);
+    case 3: return m[0];
+    case 4: return m[1];
+    case 5: return m[2];
+    case 6: return hypot(m[1], m[2]);
+    case 7: return acos(m[0] / sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]));
+    case 8: return atan2(m[2], m[1]);
+    case 9: return atan2(m[1], -m[0]);
+    case 10: return asin(m[2] / sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]));
+    case 11: return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].work : ((const Ion *)p->store)[i].work;
+    case 12: return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].chi : 0.0;
+    default: return 0.0;
+    }
+}
+static size_t f64_as_usize(double v) { return v != v ? 0 : (v < 0.0 ? 0 : (v > 1.8e19 ? (size_t)-1 : (size_t)v)); }
+static double lin_bin_vol(double mn, double bin_sz, size_t bin) { return exp(mn + ((double)bin) * bin_sz) * expm1(bin_sz); } /* hgram.rs:129 */
+static size_t n_bins(double mn, double mx, size_t n, int bkind, size_t fixed_n, double fixed_dx)
+{
+    if (mn == mx) return 1;
+    if (bkind == 2) return fixed_n;
+    if (bkind == 3) return f64_as_usize(ceil((mx - mn) / fixed_dx));
+    return f64_as_usize(ceil(2.0 * cbrt((double)n)));
+}
+
+/* Returns the number of bins written to cts (capacity cap), or 0 for an empty population.
+ * out: meta[0..1] gmin, [2..3] gmax, [4..5] bin_sz, [6] bin_vol, [7] total; nbins[0..1]. */
+size_t oracle_histogram(const Population *p, const YeeGrid *g, int dim, const int *acc, int bkind, size_t fixed_n,
+                        double fixed_dx, int weight_kind, double *cts, size_t cap, double *meta, size_t *nbins)
+{
+    size_t n = p->n;
+    if (n == 0) return 0;
+    int lg = bkind == 1;
+    double mn[2] = {0.0, 0.0}, mx[2] = {0.0, 0.0};
+    for (int d = 0; d < dim; d++) { /* min_max_by, hgram.rs:105-127 */
+        double v0 = p_access(p, g, acc[d], 0);
+        if (lg) v0 = log(v0);
+        mn[d] = mx[d] = v0;
+        for (size_t i = 0; i < n; i++) {
+            double v = p_access(p, g, acc[d], i);
+            if (lg) v = log(v);
+            if (isfinite(v)) { mn[d] = fmin(mn[d], v); mx[d] = fmax(mx[d], v); }
+        }
+    }
+    double bin_sz[2] = {0.0, 0.0}, bin_vol;
+    for (int d = 0; d < dim; d++) nbins[d] = n_bins(mn[d], mx[d], n, bkind, fixed_n, fixed_dx);
+    if (dim == 1) { /* hgram.rs:202-211 */
+        bin_vol = mn[0] == mx[0] ? 1.0 : (bkind == 3 ? fixed_dx : (mx[0] - mn[0]) / ((double)nbins[0]));
+        bin_sz[0] = nbins[0] <= 1 ? 0.0 : bin_vol;
+        nbins[1] = 1;
+    } else { /* hgram.rs:148-166 */
+        bin_vol = 1.0;
+        for (int d = 0; d < 2; d++) {
+            if (mn[d] == mx[d]) bin_sz[d] = 0.0;
+            else { bin_sz[d] = bkind == 3 ? fixed_dx : (mx[d] - mn[d]) / ((double)nbins[d]); bin_vol *= bin_sz[d]; }
+        }
+    }
+    size_t len = dim == 1 ? nbins[0] : nbins[0] * nbins[1];
+    if (len > cap) return 0;
+    for (size_t k = 0; k < len; k++) cts[k] = 0.0;
+    double total = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        double w = p_weight(p, i);
+        if (weight_kind == 1) w = p_energy(p, i) * w;
+        total = total + w;
+        double v[2] = {0.0, 0.0};
+        int fin = 1;
+        for (int d = 0; d < dim; d++) {
+            v[d] = p_access(p, g, acc[d], i);
+            if (lg) v[d] = log(v[d]);
+            if (!isfinite(v[d])) fin = 0;
+        }
+        if (!fin) continue;
+        size_t fbin;
+        if (dim == 1) { /* hgram.rs:218-247 */
+            size_t bin = f64_as_usize(floor((v[0] - mn[0]) / bin_vol));
+            if (lg) w = w * bin_vol / lin_bin_vol(mn[0], bin_vol, bin);
+            fbin = bin;
+        } else { /* hgram.rs:312-345 */
+            size_t b0 = bin_sz[0] == 0.0 ? 0 : f64_as_usize(floor((v[0] - mn[0]) / bin_sz[0]));
+            size_t b1 = bin_sz[1] == 0.0 ? 0 : f64_as_usize(floor((v[1] - mn[1]) / bin_sz[1]));
+            if (lg) w *= bin_sz[0] == 0.0 ? 1.0 : bin_sz[0] / lin_bin_vol(mn[0], bin_sz[0], b0);
+            if (lg) w *= bin_sz[1] == 0.0 ? 1.0 : bin_sz[1] / lin_bin_vol(mn[1], bin_sz[1], b1);
+            fbin = b1 * nbins[1] + b0; /* sic, :342 */
+        }
+        if (fbin < len) cts[fbin] = cts[fbin] + w;
+    }
+    for (size_t k = 0; k < len; k++) cts[k] = cts[k] / bin_vol; /* HeightSpec::Density */
+    meta[0] = mn[0]; meta[1] = dim == 2 ? mn[1] : 0.0;
+    meta[2] = mx[0]; meta[3] = dim == 2 ? mx[1] : 0.0;
+    meta[4] = bin_sz[0]; meta[5] = bin_sz[1];
+    meta[6] = bin_vol; meta[7] = total;
+    return len;
+}

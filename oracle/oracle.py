@@ -130,6 +130,7 @@ def lib():
             "oracle_world_step": (C.c_size_t, [vp, vp, vp, C.c_int, C.c_int, FN2, FN2, vp, C.c_double, C.c_double, C.c_int]),
             "oracle_world_run_periodic": (C.c_size_t, [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t, C.c_int]),
             "oracle_max_threads": (C.c_int, []),
+            "oracle_histogram": (C.c_size_t, [vp, vp, C.c_int, vp, C.c_int, C.c_size_t, C.c_double, C.c_int, vp, C.c_size_t, vp, vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -398,6 +399,31 @@ class Population:
         bl = C.create_string_buffer(recv_left, len(recv_left)) if recv_left else None
         br = C.create_string_buffer(recv_right, len(recv_right)) if recv_right else None
         lib().oracle_pop_splice(self.h, grid.h, bl, len(recv_left) // sz, br, len(recv_right) // sz)
+
+
+ACCESSORS = {"x": 0, "r": 1, "energy": 2, "px": 3, "py": 4, "pz": 5, "p_perp": 6, "theta": 7, "phi": 8,
+             "longitude": 9, "latitude": 10, "work": 11, "chi": 12}
+
+
+def histogram(pop, grid, names, bspec="auto", weight="weight"):
+    """Histogram::generate_1d / generate_2d (hgram.rs:168-392) with HeightSpec::Density for one subdomain.
+    names: one or two accessor names; bspec: "auto", "log", an int (bin count) or a float (bin size)."""
+    acc = np.array([ACCESSORS[n] for n in names], dtype=np.int32)
+    bkind, fn, fdx = 0, 0, 0.0
+    if bspec == "log":
+        bkind = 1
+    elif isinstance(bspec, int):
+        bkind, fn = 2, bspec
+    elif isinstance(bspec, float):
+        bkind, fdx = 3, bspec
+    cap = 1 << 22
+    cts = np.zeros(cap)
+    meta = np.zeros(8)
+    nb = np.zeros(2, dtype=np.uint64)
+    n = lib().oracle_histogram(pop.h, grid.h, len(names), _ptr(acc), bkind, fn, fdx, 1 if weight == "energy" else 0,
+                               _ptr(cts), cap, _ptr(meta), _ptr(nb))
+    return {"cts": cts[:n].copy(), "min": meta[0:2].copy(), "max": meta[2:4].copy(), "bin_sz": meta[4:6].copy(),
+            "bin_vol": meta[6], "total": meta[7], "nbins": [int(nb[0]), int(nb[1])]}
 
 
 def electron_create(cell, x, u, weight, dx, dt):

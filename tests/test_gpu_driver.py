@@ -82,6 +82,9 @@ def test_two_stream_yaml_run(oracle, tmp_path):
                 assert o.world_step([og], [op], None, True, t, dt) == 0
                 t += dt
     assert abs(sim.t - t) < 1e-12 * t
+    # the `output: x:px` spec of the input file became one FITS image per output (mod.rs:383-568)
+    for i in range(5):
+        assert (tmp_path / f"{i}_electron_x-px.fits").stat().st_size % 2880 == 0
     # Rust float formatting of the grid dump: no "e+00", shortest round-trip digits
     first = open(tmp_path / "4_grid.dat").readline().split()
     assert first[0] == "0e0" and "e+" not in " ".join(first)

@@ -212,3 +212,23 @@ def test_rng_known_answers(oracle):
     # state after SplitMix64 seeding with 0
     assert [int(v) for v in r.s.s] == [0xe220a8397b1dcdaf, 0x6e789e6aa1b965f4, 0x06c45d188009454f, 0xf88bb8a8724c81ec]
     assert r.next_u64() == 0x99ec5f36cb75f2b4
+
+
+def test_output_spec_file_names(oa):
+    """File names of Population::write_data (mod.rs:527-559) and which specs the reference skips."""
+    lib = oa._lib.load()
+    buf = C.create_string_buffer(512)
+
+    def name(spec, pop="electron", index=7):
+        rc = lib.opal_hist_filename(b"out", index, pop.encode(), spec.encode(), buf, 512)
+        return buf.value.decode() if rc == 0 else None
+
+    assert name("x") == "out/7_electron_x.fits"
+    assert name("x:px") == "out/7_electron_x-px.fits"
+    assert name("energy:(log;energy)") == "out/7_electron_energy_energy_log.fits"
+    assert name("x:energy:(energy)", "carbon") == "out/7_carbon_x-energy_energy.fits"
+    assert name("longitude:latitude:(energy)", "photon") == "out/7_photon_longitude-latitude_energy.fits"
+    assert name("x:(auto)") == "out/7_electron_x_auto.fits"          # weight "auto" is accepted, and named
+    assert name("px:(32;weight)") == "out/7_electron_px.fits"
+    assert name("x:px:pz") is None and name("bogus") is None and name("x:(volume)") is None
+    assert name("x:(a;b;c)") == "out/7_electron_x.fits"               # three fields: defaults (mod.rs:463)
