@@ -560,6 +560,8 @@ struct SortArgs {
     double *of[5];
     const double *prev;
     double *oprev;
+    const double *ex[4];  // chi work y z (electron extras) or null
+    double *oex[4];
 };
 
 __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a, const PopCounters *ctr, unsigned *__restrict__ cursor)
@@ -603,6 +605,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a, const PopCount
 #pragma unroll
         for (int q = 0; q < 5; q++) a.of[q][d] = a.f[q][i];
         if (a.prev) a.oprev[d] = a.prev[i];
+        if (a.ex[0]) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) a.oex[q][d] = a.ex[q][i];
+        }
     }
 }
 
@@ -688,6 +694,7 @@ struct UnpackArgs {
     int *cell;
     double *f[5];
     double *prev_x;
+    double *ex[4];  // electron extras (chi work y z) or null: arrivals restart them from zero
     PopCounters *ctr;
     unsigned pop_cap;
     int my_size;
@@ -719,6 +726,12 @@ __global__ void k_unpack(UnpackArgs a)
 #pragma unroll
         for (int c = 0; c < 5; c++) a.f[c][base + k] = rf[(size_t)c * a.link_cap + k];
         if (a.prev_x) a.prev_x[base + k] = rf[(size_t)5 * a.link_cap + k];
+        if (a.ex[0]) {
+            // the link message does not carry chi / work / y / z (diagnostics only): a particle that
+            // changes subdomain restarts them
+#pragma unroll
+            for (int q = 0; q < 4; q++) a.ex[q][base + k] = 0.0;
+        }
     }
 }
 
@@ -944,7 +957,7 @@ int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
     size_t incoming = ((size_t)from_left + (size_t)from_right) * link->cap;
     if (p->n_upper + incoming > p->cap) {
         // compact first (synchronises); the true slot count replaces the running upper bound
-        if (!p->extras && p->n_upper)
+        if (p->n_upper)
             if (int rc = do_sort(p, g)) return rc;
         if (p->n_upper + incoming > p->cap) {
             // a subdomain that plasma is moving into: make room (1.5x what is needed now)
@@ -962,6 +975,10 @@ int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
     u.cell = p->d_cell[k];
     u.f[0] = p->d_x[k]; u.f[1] = p->d_ux[k]; u.f[2] = p->d_uy[k]; u.f[3] = p->d_uz[k]; u.f[4] = p->d_w[k];
     u.prev_x = p->prev_valid ? p->d_prev_x : nullptr;
+    u.ex[0] = p->extras ? p->d_chi : nullptr;
+    u.ex[1] = p->d_work;
+    u.ex[2] = p->d_y;
+    u.ex[3] = p->d_z;
     u.ctr = p->d_ctr;
     u.pop_cap = (unsigned)p->cap;
     u.my_size = (int)g->size;
@@ -1019,6 +1036,19 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     sa.of[0] = p->d_x[o]; sa.of[1] = p->d_ux[o]; sa.of[2] = p->d_uy[o]; sa.of[3] = p->d_uz[o]; sa.of[4] = p->d_w[o];
     sa.prev = d_prev_alt ? p->d_prev_x : nullptr;
     sa.oprev = d_prev_alt;
+    double *ex_alt[4] = {nullptr, nullptr, nullptr, nullptr};
+    double **ex_cur[4] = {&p->d_chi, &p->d_work, &p->d_y, &p->d_z};
+    for (int q = 0; q < 4; q++) {
+        sa.ex[q] = nullptr;
+        sa.oex[q] = nullptr;
+    }
+    if (p->extras && p->d_chi) {
+        for (int q = 0; q < 4; q++) {
+            OPAL_HIP(hipMalloc(&ex_alt[q], sizeof(double) * p->cap));
+            sa.ex[q] = *ex_cur[q];
+            sa.oex[q] = ex_alt[q];
+        }
+    }
     k_sort_scatter<<<nblk, 256, 0, p->stream>>>(sa, p->d_ctr, p->d_count);
     k_sort_finish<<<1, 1, 0, p->stream>>>(p->d_ctr);
     prof_end(KERNEL_SORT, p->stream);
@@ -1027,6 +1057,12 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     if (d_prev_alt) {
         hipFree(p->d_prev_x);
         p->d_prev_x = d_prev_alt;
+    }
+    if (ex_alt[0]) {
+        for (int q = 0; q < 4; q++) {
+            hipFree(*ex_cur[q]);
+            *ex_cur[q] = ex_alt[q];
+        }
     }
     p->cur = o;
     p->n_upper = p->h_ctr->n_slots;
@@ -1256,7 +1292,6 @@ int opal_pop_track_extras(opal_pop_t *p, int on)
         OPAL_HIP(hipMemsetAsync(p->d_z, 0, sizeof(double) * p->cap, p->stream));
     }
     p->extras = on != 0;
-    if (p->extras) p->sort_interval = 0;  // extras are not carried through re-binning
     return OPAL_OK;
 }
 
@@ -1302,10 +1337,6 @@ int opal_pop_counters(const opal_pop_t *p, uint32_t *out)
 int opal_pop_set_sort_interval(opal_pop_t *p, int interval)
 {
     if (int rc = check_pop(p)) return rc;
-    if (p->extras && interval != 0) {
-        set_error("opal_pop_set_sort_interval: re-binning is disabled while electron extras are tracked");
-        return OPAL_ERR_ARG;
-    }
     p->sort_interval = interval;
     return OPAL_OK;
 }
@@ -1315,10 +1346,6 @@ int opal_pop_sort(opal_pop_t *p, const opal_grid_t *grid)
     if (int rc = check_pop(p)) return rc;
     if (!grid) {
         set_error("opal_pop_sort: null grid");
-        return OPAL_ERR_ARG;
-    }
-    if (p->extras) {
-        set_error("opal_pop_sort: re-binning is disabled while electron extras are tracked");
         return OPAL_ERR_ARG;
     }
     return do_sort(p, grid);

@@ -439,3 +439,30 @@ def test_full_size_properties(oa, npc):
     assert np.max(np.abs(g2.raw("rho") - rho_f)) < 1e-11 * abs(q) * npc / dx
     ke, ke2 = p.total_kinetic_energy(), p2.total_kinetic_energy()
     assert abs(ke - ke2) / ke < 1e-13
+
+
+def test_extras_survive_rebinning(oa, oracle):
+    """chi, work, y, z (electron.rs:18-25) follow their particle through the counting sort."""
+    o = oracle
+    nx, npc, dx = 48, 30, 1.0e-8
+    dt = 0.95 * dx / C
+    g, og = _random_grid_pair(oa, o, nx, dx, 81, amp_e=1e12, amp_b=3e3)
+    cell, x, ux, uy, uz, w = _random_particles(nx, npc, dx, 82, 1.0)
+    p = oa.Population(oa.ELECTRON, 4 * nx * npc)
+    p.track_extras(True)
+    p.upload(cell, x, ux, uy, uz, w, dx, dt)
+    p.set_sort_interval(2)
+    op = o.Population.from_soa(o.ELECTRON, cell, x, ux, uy, uz, w, dx, dt)
+    for _ in range(5):
+        p.advance(g, dt)
+        op.advance(og, dt)
+    a = p.soa()
+    ex = p.extras()
+    order = np.argsort(a["w"], kind="stable")
+    ref = op.soa()
+    rex = op.electron_extras()
+    rorder = np.argsort(ref["w"], kind="stable")
+    assert p.counters()["steps_since_sort"] < 2  # it did re-bin
+    for k in ("chi", "work", "y", "z"):
+        scale = np.max(np.abs(rex[k]))
+        assert np.max(np.abs(ex[k][order] - rex[k][rorder])) <= 1e-10 * scale, k
