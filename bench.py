@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--npc", type=int, default=NPC)
+    ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU,
+                    help="other BASELINE configs, e.g. configs[2] on one GPU: --cells-per-gpu 32768 --npc 1526")
     ap.add_argument("--unfused", action="store_true", help="time the reference's operator sequence instead")
     args = ap.parse_args()
 
@@ -142,7 +144,8 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     stream = torch.cuda.current_stream().cuda_stream
-    nx = CELLS_PER_GPU * world
+    cells_per_gpu = args.cells_per_gpu
+    nx = cells_per_gpu * world
     sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=args.npc), rank=rank, numtasks=world, link=link,
                         stream=stream)
     sim.set_fused(not args.unfused)
@@ -213,8 +216,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"two_stream, {args.npc} e- + {args.npc} e+ per cell, {CELLS_PER_GPU} cells per GPU "
-                            f"(BASELINE configs[1] per GPU), periodic, push+deposit+field, no QED",
+                "workload": f"two_stream, {args.npc} e- + {args.npc} e+ per cell, {cells_per_gpu} cells per GPU "
+                            + ("(BASELINE configs[1] per GPU)" if (cells_per_gpu, args.npc) == (CELLS_PER_GPU, NPC) else "")
+                            + ", periodic, push+deposit+field, no QED",
                 "particles_total": n_total,
                 "cells_total": nx,
                 "path": "fused advance+deposit" if not args.unfused else "advance, clear, deposit (reference order)",
