@@ -60,7 +60,7 @@ enum { BDY_INTERNAL = 0, BDY_LASER = 1, BDY_ABSORBING = 2, BDY_CONDUCTING = 3 };
 #define ABSORBING_BDY_SIZE 200
 #define CONDUCTING_BDY_SIZE 4
 
-enum { SPECIES_ELECTRON = 0, SPECIES_ION = 1 };
+enum { SPECIES_ELECTRON = 0, SPECIES_ION = 1, SPECIES_PHOTON = 2 };
 
 /* yee.rs:84-92 */
 typedef struct {
@@ -83,6 +83,7 @@ typedef struct {
     long cell;
     double prev_x, x, y, z, weight, gamma, u[3], chi, tau, work;
     int flag;
+    unsigned long id; /* not in the reference: keys the counter-based RNG of the emission test harness */
 } Electron;
 
 /* ion.rs:14-26 */
@@ -91,6 +92,14 @@ typedef struct {
     double prev_x, x, weight, Z_star, Z, A, gamma_m1, u[3], work;
     int flag;
 } Ion;
+
+/* photon.rs:16-32 without the polarisation / absorption members (only used by `absorb`) */
+typedef struct {
+    long cell;
+    double prev_x, x, y, z, weight, k[3], chi, birth_time;
+    int flag;
+    unsigned long id; /* id of the parent electron (test harness) */
+} Photon;
 
 /* particle/mod.rs:141-145 */
 typedef struct {
@@ -507,7 +516,7 @@ static Electron electron_create(long cell, double x, const double *u, double wei
     e.x = x; e.y = 0.0; e.z = 0.0;
     e.weight = weight; e.gamma = gamma;
     e.u[0] = u[0]; e.u[1] = u[1]; e.u[2] = u[2];
-    e.chi = 0.0; e.tau = INFINITY; e.work = 0.0; e.flag = 0;
+    e.chi = 0.0; e.tau = INFINITY; e.work = 0.0; e.flag = 0; e.id = 0;
     return e;
 }
 
@@ -615,6 +624,337 @@ static double ion_ke(const Ion *p)
     return p->weight * energy * 1.0e6 * ELEMENTARY_CHARGE;
 }
 
+/* ----------------------------------------------------------------- Photon */
+/* photon.rs:95-119 (the members kept here) */
+static Photon photon_create(long cell, double x, const double *u, double weight, double dx, double dt)
+{
+    Photon p;
+    Vec3 k = v3(u[0], u[1], u[2]);
+    double k0 = sqrt(vdot(k, k));
+    p.cell = cell;
+    p.prev_x = x - SPEED_OF_LIGHT * k.x * dt / (k0 * dx);
+    p.x = x; p.y = 0.0; p.z = 0.0; p.weight = weight;
+    p.k[0] = u[0]; p.k[1] = u[1]; p.k[2] = u[2];
+    p.chi = 0.0; p.birth_time = -INFINITY; p.flag = 0; p.id = 0;
+    return p;
+}
+
+/* photon.rs:150-183 */
+static int photon_push(Photon *p, const double *Ea, const double *Ba, double dx, double dt)
+{
+    Vec3 E = v3(Ea[0], Ea[1], Ea[2]), B = v3(Ba[0], Ba[1], Ba[2]);
+    Vec3 k = v3(p->k[0], p->k[1], p->k[2]);
+    double k0 = sqrt(vdot(k, k));
+    Vec3 v = vdivs(smul(SPEED_OF_LIGHT, k), k0);
+    {
+        Vec3 w = vadd(smul(k0, E), smul(SPEED_OF_LIGHT, vcross(k, B)));
+        double ek = vdot(E, k);
+        p->chi = sqrt(vdot(w, w) - ek * ek) / CRITICAL_FIELD;
+    }
+    p->prev_x = p->x;
+    double dxi = v.x * dt / dx;
+    int bad = !(dxi < 1.0);
+    p->x = p->x + dxi;
+    p->y = p->y + v.y * dt;
+    p->z = p->z + v.z * dt;
+    double fl = floor(p->x);
+    if (fl < 0.0) p->cell = p->cell - 1;
+    else if (fl > 0.0) p->cell = p->cell + 1;
+    p->prev_x -= fl;
+    p->x -= fl;
+    return bad;
+}
+
+/* photon.rs:225-231 */
+static double photon_ke(const Photon *p)
+{
+    double energy = sqrt(p->k[0] * p->k[0] + p->k[1] * p->k[1] + p->k[2] * p->k[2]) * ELECTRON_MASS_MEV;
+    return p->weight * energy * 1.0e6 * ELEMENTARY_CHARGE;
+}
+
+/* ------------------------------------------------------- photon emission */
+/* Sampling tables: generated from the emission rate by tools/make_qed_tables.py (the reference's
+ * photon_emission_tables.rs plays this role; its numbers are not used). */
+typedef struct { double coeff, power; double table[31][2]; } QedCdf;
+#define QED_TABLE_QUAL const
+#include "qed_tables.inc"
+
+#define PWMCI_RECURSION_LIMIT 32
+#define PWMCI_PRECISION_LIMIT 1.0e-6
+
+typedef struct { double x[2], f[2], m[2]; } FitParameters;
+
+/* pwmci.rs:14-69.  The reference indexes table[i-1] and so cannot be called with i == 0; its callers
+ * never do (they handle f <= table[0][1] separately), and neither do ours. */
+static FitParameters fit_construct(size_t i, const double (*table)[2], size_t len)
+{
+    double secant[3];
+    if (i == 1) {
+        secant[0] = (table[i][1] - table[i - 1][1]) / (table[i][0] - table[i - 1][0]);
+        secant[1] = (table[i][1] - table[i - 1][1]) / (table[i][0] - table[i - 1][0]);
+        secant[2] = (table[i + 1][1] - table[i][1]) / (table[i + 1][0] - table[i][0]);
+    } else if (i == len - 1) {
+        secant[0] = (table[i - 1][1] - table[i - 2][1]) / (table[i - 1][0] - table[i - 2][0]);
+        secant[1] = (table[i][1] - table[i - 1][1]) / (table[i][0] - table[i - 1][0]);
+        secant[2] = (table[i][1] - table[i - 1][1]) / (table[i][0] - table[i - 1][0]);
+    } else {
+        secant[0] = (table[i - 1][1] - table[i - 2][1]) / (table[i - 1][0] - table[i - 2][0]);
+        secant[1] = (table[i][1] - table[i - 1][1]) / (table[i][0] - table[i - 1][0]);
+        secant[2] = (table[i + 1][1] - table[i][1]) / (table[i + 1][0] - table[i][0]);
+    }
+    double tangent[2];
+    tangent[0] = secant[0] * secant[1] > 0.0 ? 0.5 * (secant[0] + secant[1]) : 0.0;
+    tangent[1] = secant[1] * secant[2] > 0.0 ? 0.5 * (secant[1] + secant[2]) : 0.0;
+    if (secant[1] != 0.0) {
+        double alpha = tangent[0] / secant[1];
+        if (alpha > 3.0) tangent[0] = 3.0 * secant[1];
+    }
+    if (secant[2] != 0.0) {
+        double beta = tangent[1] / secant[2];
+        if (beta > 3.0) tangent[1] = 3.0 * secant[2];
+    }
+    FitParameters fp;
+    fp.x[0] = table[i - 1][0]; fp.x[1] = table[i][0];
+    fp.f[0] = table[i - 1][1]; fp.f[1] = table[i][1];
+    fp.m[0] = tangent[0]; fp.m[1] = tangent[1];
+    return fp;
+}
+
+/* pwmci.rs:71-78 */
+static double fit_evaluate(const FitParameters *fp, double x)
+{
+    double t = (x - fp->x[0]) / (fp->x[1] - fp->x[0]);
+    double omt2 = (1.0 - t) * (1.0 - t), t2 = t * t;
+    double h00 = (1.0 + 2.0 * t) * omt2;
+    double h10 = t * omt2;
+    double h01 = t2 * (3.0 - 2.0 * t);
+    double h11 = t2 * (t - 1.0);
+    return fp->f[0] * h00 + fp->f[1] * h01 + (fp->x[1] - fp->x[0]) * (fp->m[0] * h10 + fp->m[1] * h11);
+}
+
+/* pwmci.rs:86-94 */
+static int is_between(double x, double min, double max)
+{
+    if (min < max) return x > min && x < max;
+    if (max < min) return x > max && x < min;
+    return 1;
+}
+
+/* pwmci.rs:96-111; returns 0 for None */
+int oracle_pwmci_evaluate(double x, const double *tab, size_t len, double *out)
+{
+    const double (*table)[2] = (const double (*)[2])tab;
+    size_t i = 0;
+    while (i < len && x > table[i][0]) i++;
+    if (i >= len - 1 && x > table[len - 1][0]) return 0;
+    if (i == 0) i = 1; /* x == table[0][0] exactly: the reference would index table[-1] */
+    FitParameters fp = fit_construct(i, table, len);
+    *out = fit_evaluate(&fp, x);
+    return 1;
+}
+
+/* pwmci.rs:113-228; returns 0 for None */
+int oracle_pwmci_invert(double f, const double *tab, size_t len, double *out, int *nevals)
+{
+    const double (*table)[2] = (const double (*)[2])tab;
+    size_t i = 0;
+    while (i < len && f > table[i][1]) i++;
+    if (i >= len - 1 && f > table[len - 1][1]) return 0;
+    if (i == 0) i = 1;
+    FitParameters fp = fit_construct(i, table, len);
+    struct { double x, f; } root[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, tmp;
+    root[0].x = table[i - 1][0]; root[0].f = table[i - 1][1] - f;
+    root[1].x = table[i][0];     root[1].f = table[i][1] - f;
+    if (fabs(root[1].f) < fabs(root[0].f)) { tmp = root[0]; root[0] = root[1]; root[1] = tmp; }
+    root[2] = root[1];
+    int prev_bisect = 0, counter = 0;
+    for (int it = 0; it < PWMCI_RECURSION_LIMIT; it++) {
+        counter++;
+        double s;
+        if (root[0].f != root[2].f && root[1].f != root[2].f) {
+            double r = root[0].f / root[2].f;
+            double ss = root[0].f / root[1].f;
+            double t = root[1].f / root[2].f;
+            double pp = ss * (t * (r - t) * (root[2].x - root[0].x) - (1.0 - r) * (root[0].x - root[1].x));
+            double q = (t - 1.0) * (r - 1.0) * (ss - 1.0);
+            s = root[0].x + pp / q;
+        } else {
+            s = root[0].x - (root[0].f * (root[0].x - root[1].x) / (root[0].f - root[1].f));
+        }
+        if (!is_between(s, 0.25 * (3.0 * root[1].x + root[0].x), root[0].x)
+            || (prev_bisect && fabs(s - root[0].x) >= 0.5 * fabs(root[0].x - root[2].x))
+            || (!prev_bisect && fabs(s - root[0].x) >= 0.5 * fabs(root[2].x - root[3].x))) {
+            prev_bisect = 1;
+            s = 0.5 * (root[0].x + root[1].x);
+        } else {
+            prev_bisect = 0;
+        }
+        root[3] = root[2];
+        root[2] = root[0];
+        root[0].x = s;
+        root[0].f = fit_evaluate(&fp, s) - f;
+        if (root[1].f * root[0].f >= 0.0) {
+            root[1] = root[0];
+            root[0] = root[2];
+        }
+        if (fabs(root[1].f) < fabs(root[0].f)) { tmp = root[0]; root[0] = root[1]; root[1] = tmp; }
+        double error = fabs(root[1].x - root[0].x) / fabs(root[0].x);
+        if (error < PWMCI_PRECISION_LIMIT || root[0].f == 0.0) break;
+    }
+    *out = root[0].x;
+    if (nevals) *nevals = counter;
+    return 1;
+}
+
+/* photon_emission.rs:87-121 */
+static double from_linear_cdf_table(double global_zero, double local_zero, double rnd, const QedCdf *cdf)
+{
+    double r_zero;
+    if (local_zero < cdf->table[0][0]) {
+        r_zero = cdf->coeff * pow(local_zero - global_zero, cdf->power);
+    } else if (!oracle_pwmci_evaluate(local_zero, &cdf->table[0][0], 31, &r_zero)) {
+        return local_zero;
+    }
+    double r = r_zero + (1.0 - r_zero) * rnd;
+    double y;
+    if (r <= cdf->table[0][1]) {
+        double tmp = (log(r) - log(cdf->coeff)) / cdf->power;
+        y = exp(tmp) + global_zero;
+    } else if (!oracle_pwmci_invert(r, &cdf->table[0][0], 31, &y, NULL)) {
+        y = local_zero;
+    }
+    /* the reference asserts y >= local_zero (:119); interpolation error can undershoot by rounding */
+    return y >= local_zero ? y : local_zero;
+}
+
+/* the small-x limit of the classical cdf, (3/pi) int_0^x t K_{1/3}(t) dt -> A x^(5/3) with
+ * A = (9 / (5 pi)) Gamma(1/3) 2^(-2/3); photon_emission.rs:275 carries its inverse as a literal */
+#define CLASSICAL_SMALL_X_COEFF 1.0203772548972 /* A^(-3/5) */
+
+/* photon_emission.rs:264-292; out = omega/mc^2, theta, phi */
+void oracle_qed_classical_sample(double chi, double gamma, double rand1, double rand2, double rand3, double *out)
+{
+    double delta = acos((-9.0 + 50.0 * rand2 - 25.0 * (rand2 * rand2)) / 16.0);
+    double zc = (2.0 + 4.0 * cos(delta / 3.0)) / (5.0 * (1.0 - rand2));
+    double z = zc * zc * zc;
+    double ln_rand = log(rand1);
+    double x;
+    if (ln_rand < QED_CLASSICAL_SPECTRUM[0][1]) {
+        x = CLASSICAL_SMALL_X_COEFF * pow(rand1, 0.6);
+    } else {
+        double ln_x;
+        if (!oracle_pwmci_invert(ln_rand, &QED_CLASSICAL_SPECTRUM[0][0], 41, &ln_x, NULL)) ln_x = QED_CLASSICAL_SPECTRUM[40][0];
+        x = exp(ln_x);
+    }
+    double u = 3.0 * chi * x / (2.0 * z);
+    double omega_mc2 = u * gamma;
+    double cos_theta = (gamma - pow(z, 2.0 / 3.0) / (2.0 * gamma)) / sqrt(gamma * gamma - 1.0);
+    double theta = acos(fmax(fmin(cos_theta, 1.0), -1.0));
+    out[0] = omega_mc2; out[1] = theta; out[2] = 2.0 * PI * rand3;
+}
+
+static double quantum_ln_u(const QedCdf *c, double ln_rand)
+{
+    double r;
+    if (ln_rand <= c->table[0][1]) return (ln_rand - log(c->coeff)) / c->power;
+    if (oracle_pwmci_invert(ln_rand, &c->table[0][0], 31, &r, NULL)) return r;
+    return c->table[30][0];
+}
+
+/* photon_emission.rs:129-203; returns 1 where the reference reaches unimplemented!() (chi >= 100) */
+int oracle_qed_sample(double chi, double gamma, double rand1, double rand2, double rand3, double *out)
+{
+    double index = (log(chi) - QED_LN_CHI_MIN) / QED_LN_CHI_STEP;
+    if (log(chi) <= QED_LN_CHI_MIN) {
+        oracle_qed_classical_sample(chi, gamma, rand1, rand2, rand3, out);
+        out[0] = out[0] * gamma / (gamma + out[0]);
+        return 0;
+    }
+    double weight = index - trunc(index);
+    size_t idx = (size_t)floor(index);
+    if (idx >= 41 - 1) return 1;
+    double ln_u_lower = quantum_ln_u(&QED_QUANTUM_CDF[idx], log(rand1));
+    double ln_u_upper = quantum_ln_u(&QED_QUANTUM_CDF[idx + 1], log(rand1));
+    double u = exp((1.0 - weight) * ln_u_lower + weight * ln_u_upper);
+
+    double beta = 2.0 * u / (3.0 * chi);
+    double delta = (1.0 + (1.0 + u) * (1.0 + u)) * pow(beta, -2.0 / 3.0) / (1.0 + u);
+    index = (log(delta) - QED_LN_DELTA_MIN) / QED_LN_DELTA_STEP;
+    weight = index - trunc(index);
+    idx = (size_t)floor(index);
+    double y;
+    if (idx >= 31 - 1) {
+        y = from_linear_cdf_table(0.0, beta, rand2, &QED_Y_INFINITE_DELTA_CDF[0]);
+    } else {
+        double y0 = pow(delta, -1.5);
+        double y_lower = from_linear_cdf_table(y0, beta, rand2, &QED_Y_CDF[idx]);
+        double y_upper = from_linear_cdf_table(y0, beta, rand2, &QED_Y_CDF[idx + 1]);
+        y = (1.0 - weight) * y_lower + weight * y_upper;
+    }
+    double z = fmax(y / beta, 1.0);
+    double cos_theta = (gamma - pow(z, 2.0 / 3.0) / (2.0 * gamma)) / sqrt(gamma * gamma - 1.0);
+    double theta = acos(fmax(fmin(cos_theta, 1.0), -1.0));
+    out[0] = gamma * u / (1.0 + u); out[1] = theta; out[2] = 2.0 * PI * rand3;
+    return 0;
+}
+
+/* Random numbers for emission.  The reference clones one Xoshiro256** per rayon chunk and jumps it
+ * (interactions.rs:58-67), so its stream already depends on the thread count; the build keys a
+ * counter-based generator (Philox4x32-10, Salmon et al. 2011) by (seed, particle id, step), which the
+ * GPU kernel can reproduce exactly.  Draw order per emitting electron follows electron.rs:209-218:
+ * new optical depth, rand1, rand2, rand3.  (The four optical depths the reference then draws for the
+ * photon, photon.rs:126-133, only matter to absorption and are not drawn.) */
+void oracle_philox(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4])
+{
+    uint32_t c[4] = {ctr_in[0], ctr_in[1], ctr_in[2], ctr_in[3]}, k[2] = {key_in[0], key_in[1]};
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+static double u53(uint32_t hi, uint32_t lo) { return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0); }
+
+/* out = uniform draws in [0,1): optical-depth draw, rand1, rand2, rand3 */
+void oracle_emission_randoms(uint64_t seed, uint64_t id, uint32_t step, double *out)
+{
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, ctr[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 0}, r[4];
+    oracle_philox(ctr, key, r);
+    out[0] = u53(r[0], r[1]); out[1] = u53(r[2], r[3]);
+    ctr[3] = 1;
+    oracle_philox(ctr, key, r);
+    out[2] = u53(r[0], r[1]); out[3] = u53(r[2], r[3]);
+}
+
+/* vec3.rs:115-122 */
+static Vec3 vnormalize(Vec3 a) { return vdivs(a, sqrt(vdot(a, a))); }
+static Vec3 vorthogonal(Vec3 a)
+{
+    Vec3 perp = fabs(a.x) > fabs(a.z) ? v3(-a.y, a.x, 0.0) : v3(0.0, -a.z, a.y);
+    return vnormalize(perp);
+}
+/* vec3.rs:124-138 */
+static Vec3 vrotate_around(Vec3 v, Vec3 axis, double theta)
+{
+    double s = sin(theta), c = cos(theta);
+    return v3((c + axis.x * axis.x * (1.0 - c)) * v.x + (axis.x * axis.y * (1.0 - c) - axis.z * s) * v.y
+                  + (axis.x * axis.z * (1.0 - c) + axis.y * s) * v.z,
+              (axis.y * axis.x * (1.0 - c) + axis.z * s) * v.x + (c + axis.y * axis.y * (1.0 - c)) * v.y
+                  + (axis.y * axis.z * (1.0 - c) - axis.x * s) * v.z,
+              (axis.z * axis.x * (1.0 - c) - axis.y * s) * v.x + (axis.z * axis.y * (1.0 - c) + axis.x * s) * v.y
+                  + (c + axis.z * axis.z * (1.0 - c)) * v.z);
+}
+void oracle_vec3_orthogonal(const double *a, double *out) { Vec3 r = vorthogonal(v3(a[0], a[1], a[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void oracle_vec3_rotate_around(const double *v, const double *axis, double theta, double *out)
+{
+    Vec3 r = vrotate_around(v3(v[0], v[1], v[2]), v3(axis[0], axis[1], axis[2]), theta);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
 /* single-particle entry points for the tests (electron.rs:401-436 KATs) */
 void oracle_electron_create(long cell, double x, const double *u, double weight, double dx, double dt, Electron *out)
 {
@@ -660,7 +1000,10 @@ double oracle_rng_normal(Rng *r)
 double oracle_rng_exp1(Rng *r) { return -log(1.0 - oracle_rng_f64(r)); }
 
 /* ------------------------------------------------------------ Population */
-static size_t psize(int species) { return species == SPECIES_ELECTRON ? sizeof(Electron) : sizeof(Ion); }
+static size_t psize(int species)
+{
+    return species == SPECIES_ELECTRON ? sizeof(Electron) : species == SPECIES_ION ? sizeof(Ion) : sizeof(Photon);
+}
 
 Population *oracle_pop_new_empty(int species)
 {
@@ -683,7 +1026,7 @@ static void pop_reserve(Population *p, size_t n)
 
 /* particle/mod.rs:172-203.  RNG draw order per particle: x, then (urand,
  * nrand) for ux, uy, uz, then the species' optical depths (electron: one Exp1,
- * electron.rs:168-172; ion: none, ion.rs:157-159). */
+ * electron.rs:168-172; ion: none, ion.rs:157-159; photon: four, photon.rs:126-133). */
 Population *oracle_pop_new(int species, size_t npc, fn1_t number_density, fn3_t ux, fn3_t uy, fn3_t uz,
                            void *user, const YeeGrid *grid, Rng *rng, double dt)
 {
@@ -708,9 +1051,14 @@ Population *oracle_pop_new(int species, size_t npc, fn1_t number_density, fn3_t 
             if (species == SPECIES_ELECTRON) {
                 Electron e = electron_create(c, xf, u, weight, dx, dt);
                 e.tau = oracle_rng_exp1(rng);
+                e.id = p->n;
                 ((Electron *)p->store)[p->n++] = e;
-            } else {
+            } else if (species == SPECIES_ION) {
                 ((Ion *)p->store)[p->n++] = ion_create(c, xf, u, weight, dx, dt);
+            } else {
+                /* photon.rs:126-133: four optical depths, used by absorption only */
+                for (int k = 0; k < 4; k++) (void)oracle_rng_exp1(rng);
+                ((Photon *)p->store)[p->n++] = photon_create(c, xf, u, weight, dx, dt);
             }
         }
     }
@@ -734,6 +1082,10 @@ void oracle_pop_get_soa(const Population *p, long *cell, double *x, double *prev
             const Electron *e = &((const Electron *)p->store)[i];
             cell[i] = e->cell; x[i] = e->x; prev_x[i] = e->prev_x;
             ux[i] = e->u[0]; uy[i] = e->u[1]; uz[i] = e->u[2]; w[i] = e->weight; aux[i] = e->gamma;
+        } else if (p->species == SPECIES_PHOTON) {
+            const Photon *e = &((const Photon *)p->store)[i];
+            cell[i] = e->cell; x[i] = e->x; prev_x[i] = e->prev_x;
+            ux[i] = e->k[0]; uy[i] = e->k[1]; uz[i] = e->k[2]; w[i] = e->weight; aux[i] = (double)e->id;
         } else {
             const Ion *e = &((const Ion *)p->store)[i];
             cell[i] = e->cell; x[i] = e->x; prev_x[i] = e->prev_x;
@@ -760,8 +1112,11 @@ Population *oracle_pop_from_soa(int species, size_t n, const long *cell, const d
     pop_reserve(p, n);
     for (size_t i = 0; i < n; i++) {
         double u[3] = {ux[i], uy[i], uz[i]};
-        if (species == SPECIES_ELECTRON) ((Electron *)p->store)[i] = electron_create(cell[i], x[i], u, w[i], dx, dt);
-        else ((Ion *)p->store)[i] = ion_create(cell[i], x[i], u, w[i], dx, dt);
+        if (species == SPECIES_ELECTRON) {
+            ((Electron *)p->store)[i] = electron_create(cell[i], x[i], u, w[i], dx, dt);
+            ((Electron *)p->store)[i].id = i;
+        } else if (species == SPECIES_ION) ((Ion *)p->store)[i] = ion_create(cell[i], x[i], u, w[i], dx, dt);
+        else ((Photon *)p->store)[i] = photon_create(cell[i], x[i], u, w[i], dx, dt);
     }
     p->n = n;
     return p;
@@ -774,6 +1129,8 @@ void oracle_pop_set_prev_aux(Population *p, const double *prev_x, const double *
             Electron *e = &((Electron *)p->store)[i];
             if (prev_x) e->prev_x = prev_x[i];
             if (aux) e->gamma = aux[i];
+        } else if (p->species == SPECIES_PHOTON) {
+            if (prev_x) ((Photon *)p->store)[i].prev_x = prev_x[i];
         } else {
             Ion *e = &((Ion *)p->store)[i];
             if (prev_x) e->prev_x = prev_x[i];
@@ -788,18 +1145,22 @@ double oracle_pop_total_kinetic_energy(const Population *p)
     double sum = 0.0;
     for (size_t i = 0; i < p->n; i++)
         sum += p->species == SPECIES_ELECTRON ? electron_ke(&((const Electron *)p->store)[i])
-                                              : ion_ke(&((const Ion *)p->store)[i]);
+               : p->species == SPECIES_ION    ? ion_ke(&((const Ion *)p->store)[i])
+                                              : photon_ke(&((const Photon *)p->store)[i]);
     return sum;
 }
 
 static inline long pcell(const Population *p, size_t i)
 {
-    return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].cell : ((const Ion *)p->store)[i].cell;
+    return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].cell
+           : p->species == SPECIES_ION    ? ((const Ion *)p->store)[i].cell
+                                          : ((const Photon *)p->store)[i].cell;
 }
 static inline void pshift(Population *p, void *store, size_t i, long delta)
 {
     if (p->species == SPECIES_ELECTRON) ((Electron *)store)[i].cell += delta;
-    else ((Ion *)store)[i].cell += delta;
+    else if (p->species == SPECIES_ION) ((Ion *)store)[i].cell += delta;
+    else ((Photon *)store)[i].cell += delta;
 }
 
 /* particle/mod.rs:247-293: gather + push every particle, count leavers, sort
@@ -823,10 +1184,16 @@ size_t oracle_pop_push_and_sort(Population *p, const YeeGrid *grid, double dt, i
             bad += (size_t)electron_vay_push(e, E, B, dx, dt);
             e->flag = 0;
             c = e->cell;
-        } else {
+        } else if (p->species == SPECIES_ION) {
             Ion *e = &((Ion *)p->store)[i];
             if (oracle_grid_fields_at(grid, e->cell, e->x, E, B)) { bad++; continue; }
             bad += (size_t)ion_push(e, E, B, dx, dt);
+            e->flag = 0;
+            c = e->cell;
+        } else {
+            Photon *e = &((Photon *)p->store)[i];
+            if (oracle_grid_fields_at(grid, e->cell, e->x, E, B)) { bad++; continue; }
+            bad += (size_t)photon_push(e, E, B, dx, dt);
             e->flag = 0;
             c = e->cell;
         }
@@ -927,7 +1294,7 @@ size_t oracle_grid_deposit(YeeGrid *g, const Population *p, double dt, int nthre
     double dx = g->dx;
     size_t size = g->len, bad = 0;
     long left_bdy_size = g->left_bdy_size;
-    if (p->n == 0) return 0;
+    if (p->n == 0 || p->species == SPECIES_PHOTON) return 0; /* photons carry no charge and are never deposited (main.rs:254-258) */
     if (nthreads < 1) nthreads = 1;
     size_t chunk_len = p->n > (size_t)nthreads ? p->n / (size_t)nthreads : p->n;
     size_t nchunks = (p->n + chunk_len - 1) / chunk_len;
@@ -1058,6 +1425,9 @@ static void p_momentum(const Population *p, size_t i, double *mom)
     if (p->species == SPECIES_ELECTRON) {  /* electron.rs:157-160 */
         const Electron *e = &((const Electron *)p->store)[i];
         for (int k = 0; k < 3; k++) mom[k] = e->u[k] * ELECTRON_MASS_MEV;
+    } else if (p->species == SPECIES_PHOTON) {  /* photon.rs:211-214 */
+        const Photon *e = &((const Photon *)p->store)[i];
+        for (int k = 0; k < 3; k++) mom[k] = e->k[k] * ELECTRON_MASS_MEV;
     } else {  /* ion.rs:140-143 */
         const Ion *e = &((const Ion *)p->store)[i];
         for (int k = 0; k < 3; k++) mom[k] = e->u[k] * (e->A * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV;
@@ -1066,12 +1436,18 @@ static void p_momentum(const Population *p, size_t i, double *mom)
 static double p_energy(const Population *p, size_t i)
 {
     if (p->species == SPECIES_ELECTRON) return ((const Electron *)p->store)[i].gamma * ELECTRON_MASS_MEV; /* electron.rs:118 */
+    if (p->species == SPECIES_PHOTON) {  /* photon.rs:222-224 */
+        const Photon *ph = &((const Photon *)p->store)[i];
+        return sqrt(ph->k[0] * ph->k[0] + ph->k[1] * ph->k[1] + ph->k[2] * ph->k[2]) * ELECTRON_MASS_MEV;
+    }
     const Ion *e = &((const Ion *)p->store)[i];
     return e->gamma_m1 * (e->A * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV; /* ion.rs:128 */
 }
 static double p_weight(const Population *p, size_t i)
 {
-    return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].weight : ((const Ion *)p->store)[i].weight;
+    return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].weight
+           : p->species == SPECIES_ION    ? ((const Ion *)p->store)[i].weight
+                                          : ((const Photon *)p->store)[i].weight;
 }
 static double p_access(const Population *p, const YeeGrid *g, int id, size_t i)
 {
@@ -1080,10 +1456,14 @@ static double p_access(const Population *p, const YeeGrid *g, int id, size_t i)
     switch (id) {
     case 0: {
         long c = pcell(p, i);
-        double x = p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].x : ((const Ion *)p->store)[i].x;
+        double x = p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].x
+                   : p->species == SPECIES_ION    ? ((const Ion *)p->store)[i].x
+                                                  : ((const Photon *)p->store)[i].x;
         return oracle_grid_xmin(g) + (((double)c) + x) * g->dx;
     }
-    case 1: return p->species == SPECIES_ELECTRON ? hypot(((const Electron *)p->store)[i].y, ((const Electron *)p->store)[i].z) : 0.0;
+    case 1:
+        if (p->species == SPECIES_PHOTON) return hypot(((const Photon *)p->store)[i].y, ((const Photon *)p->store)[i].z);
+        return p->species == SPECIES_ELECTRON ? hypot(((const Electron *)p->store)[i].y, ((const Electron *)p->store)[i].z) : 0.0;
     case 2: return p_energy(p, i);
     case 3: return m[0];
     case 4: return m[1];
@@ -1093,8 +1473,12 @@ static double p_access(const Population *p, const YeeGrid *g, int id, size_t i)
     case 8: return atan2(m[2], m[1]);
     case 9: return atan2(m[1], -m[0]);
     case 10: return asin(m[2] / sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]));
-    case 11: return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].work : ((const Ion *)p->store)[i].work;
-    case 12: return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].chi : 0.0;
+    case 11:
+        if (p->species == SPECIES_PHOTON) return 0.0;  /* photon.rs:207-209 */
+        return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].work : ((const Ion *)p->store)[i].work;
+    case 12:
+        if (p->species == SPECIES_PHOTON) return ((const Photon *)p->store)[i].chi;
+        return p->species == SPECIES_ELECTRON ? ((const Electron *)p->store)[i].chi : 0.0;
     default: return 0.0;
     }
 }
@@ -1176,4 +1560,86 @@ size_t oracle_histogram(const Population *p, const YeeGrid *g, int dim, const in
     meta[4] = bin_sz[0]; meta[5] = bin_sz[1];
     meta[6] = bin_vol; meta[7] = total;
     return len;
+}
+
+/* ------------------------------------------------- emit_radiation */
+/* electron.rs:208-251 (default features).  Returns 1 and fills photon / formation_length on emission,
+ * -1 where the reference panics (chi >= 100). */
+static int electron_radiate(Electron *e, uint64_t seed, uint32_t step, double t, Photon *photon, double *formation_length)
+{
+    if (!(e->tau < 0.0)) return 0;
+    double rnd[4], smp[3];
+    oracle_emission_randoms(seed, e->id, step, rnd);
+    e->tau = -log(1.0 - rnd[0]);
+    if (oracle_qed_sample(e->chi, e->gamma, rnd[1], rnd[2], rnd[3], smp)) return -1;
+    double omega_mc2 = smp[0], theta = smp[1], cphi = smp[2];
+    Vec3 eu = v3(e->u[0], e->u[1], e->u[2]);
+    Vec3 parallel = vnormalize(eu);
+    Vec3 perp = vrotate_around(vorthogonal(parallel), parallel, cphi);
+    Vec3 k = smul(omega_mc2, vadd(smul(cos(theta), parallel), smul(sin(theta), perp)));
+    *formation_length = 2.0 * (e->gamma * e->gamma) * theta * SPEED_OF_LIGHT * COMPTON_TIME / e->chi;
+    eu = vadd(eu, smul(-1.0, k));
+    double new_gamma = sqrt(1.0 + vdot(eu, eu));
+    e->chi = e->chi * new_gamma / e->gamma;
+    e->gamma = new_gamma;
+    e->u[0] = eu.x; e->u[1] = eu.y; e->u[2] = eu.z;
+    double kk[3] = {k.x, k.y, k.z};
+    /* Photon::create(cell, x, u, weight, 0.0, 0.0): dt/dx = 0/0, so prev_x starts as NaN in the
+     * reference too; it is overwritten by the first push and photons are never deposited */
+    *photon = photon_create(e->cell, e->x, kk, e->weight, 0.0, 0.0);
+    photon->birth_time = t;
+    photon->id = e->id;
+    return 1;
+}
+
+/* interactions.rs:45-107.  Limits < 0 mean None.  Photons are appended in electron order (the
+ * reference's order for one thread).  Returns the number appended, or -1 on a reference panic. */
+long oracle_emit_radiation(Population *e, Population *ph, uint64_t seed, uint32_t step, double t, double min_energy,
+                           double max_angle, double max_formation_length)
+{
+    long appended = 0;
+    for (size_t i = 0; i < e->n; i++) {
+        Photon photon;
+        double fl;
+        int rc = electron_radiate(&((Electron *)e->store)[i], seed, step, t, &photon, &fl);
+        if (rc < 0) return -1;
+        if (rc == 0) continue;
+        int energy_ok = 1, angle_ok = 1, fl_ok = 1;
+        double p[3] = {photon.k[0] * ELECTRON_MASS_MEV, photon.k[1] * ELECTRON_MASS_MEV, photon.k[2] * ELECTRON_MASS_MEV};
+        if (min_energy >= 0.0) {
+            double energy = sqrt(photon.k[0] * photon.k[0] + photon.k[1] * photon.k[1] + photon.k[2] * photon.k[2]) * ELECTRON_MASS_MEV;
+            energy_ok = energy >= min_energy;
+        }
+        if (max_angle >= 0.0) {
+            double magnitude = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+            angle_ok = acos(-p[0] / magnitude) <= max_angle;
+        }
+        if (max_formation_length >= 0.0) fl_ok = fl < max_formation_length;
+        if (energy_ok && angle_ok && fl_ok) {
+            pop_reserve(ph, ph->n + 1);
+            ((Photon *)ph->store)[ph->n++] = photon;
+            appended++;
+        }
+    }
+    return appended;
+}
+
+void oracle_pop_set_electron_state(Population *p, const double *tau, const uint64_t *id)
+{
+    for (size_t i = 0; i < p->n; i++) {
+        Electron *e = &((Electron *)p->store)[i];
+        if (tau) e->tau = tau[i];
+        if (id) e->id = id[i];
+    }
+}
+void oracle_pop_get_electron_ids(const Population *p, uint64_t *id)
+{
+    for (size_t i = 0; i < p->n; i++) id[i] = ((const Electron *)p->store)[i].id;
+}
+void oracle_pop_get_photon_extras(const Population *p, double *chi, double *y, double *z, double *birth_time, uint64_t *id)
+{
+    for (size_t i = 0; i < p->n; i++) {
+        const Photon *e = &((const Photon *)p->store)[i];
+        chi[i] = e->chi; y[i] = e->y; z[i] = e->z; birth_time[i] = e->birth_time; id[i] = e->id;
+    }
 }

@@ -39,7 +39,8 @@ class Cell(C.Structure):
 class Electron(C.Structure):
     _fields_ = [("cell", C.c_long), ("prev_x", C.c_double), ("x", C.c_double), ("y", C.c_double),
                 ("z", C.c_double), ("weight", C.c_double), ("gamma", C.c_double), ("u", C.c_double * 3),
-                ("chi", C.c_double), ("tau", C.c_double), ("work", C.c_double), ("flag", C.c_int)]
+                ("chi", C.c_double), ("tau", C.c_double), ("work", C.c_double), ("flag", C.c_int),
+                ("id", C.c_ulong)]
 
 
 class Ion(C.Structure):
@@ -130,6 +131,18 @@ def lib():
             "oracle_world_step": (C.c_size_t, [vp, vp, vp, C.c_int, C.c_int, FN2, FN2, vp, C.c_double, C.c_double, C.c_int]),
             "oracle_world_run_periodic": (C.c_size_t, [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t, C.c_int]),
             "oracle_max_threads": (C.c_int, []),
+            "oracle_pwmci_evaluate": (C.c_int, [C.c_double, vp, C.c_size_t, dp]),
+            "oracle_pwmci_invert": (C.c_int, [C.c_double, vp, C.c_size_t, dp, C.POINTER(C.c_int)]),
+            "oracle_qed_sample": (C.c_int, [C.c_double] * 5 + [vp]),
+            "oracle_qed_classical_sample": (None, [C.c_double] * 5 + [vp]),
+            "oracle_philox": (None, [vp, vp, vp]),
+            "oracle_emission_randoms": (None, [C.c_uint64, C.c_uint64, C.c_uint32, vp]),
+            "oracle_vec3_orthogonal": (None, [vp, vp]),
+            "oracle_vec3_rotate_around": (None, [vp, vp, C.c_double, vp]),
+            "oracle_emit_radiation": (C.c_long, [vp, vp, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double]),
+            "oracle_pop_set_electron_state": (None, [vp, vp, vp]),
+            "oracle_pop_get_electron_ids": (None, [vp, vp]),
+            "oracle_pop_get_photon_extras": (None, [vp] + [vp] * 5),
             "oracle_histogram": (C.c_size_t, [vp, vp, C.c_int, vp, C.c_int, C.c_size_t, C.c_double, C.c_int, vp, C.c_size_t, vp, vp]),
         }
         for name, (res, args) in sig.items():
@@ -376,6 +389,25 @@ class Population:
         lib().oracle_pop_get_electron_extras(self.h, *[_ptr(out[k]) for k in ("chi", "tau", "work", "y", "z")])
         return out
 
+    def set_electron_state(self, tau=None, ids=None):
+        """Overwrite the optical depths and/or the ids that key the emission random numbers."""
+        t = np.ascontiguousarray(tau, dtype=np.float64) if tau is not None else None
+        i = np.ascontiguousarray(ids, dtype=np.uint64) if ids is not None else None
+        lib().oracle_pop_set_electron_state(self.h, _ptr(t) if t is not None else None, _ptr(i) if i is not None else None)
+
+    def electron_ids(self):
+        out = np.empty(len(self), dtype=np.uint64)
+        lib().oracle_pop_get_electron_ids(self.h, _ptr(out))
+        return out
+
+    def photon_extras(self):
+        n = len(self)
+        out = {k: np.empty(n, dtype=np.float64) for k in ("chi", "y", "z", "birth_time")}
+        ids = np.empty(n, dtype=np.uint64)
+        lib().oracle_pop_get_photon_extras(self.h, *[_ptr(out[k]) for k in ("chi", "y", "z", "birth_time")], _ptr(ids))
+        out["id"] = ids
+        return out
+
     def total_kinetic_energy(self):
         return lib().oracle_pop_total_kinetic_energy(self.h)
 
@@ -399,6 +431,55 @@ class Population:
         bl = C.create_string_buffer(recv_left, len(recv_left)) if recv_left else None
         br = C.create_string_buffer(recv_right, len(recv_right)) if recv_right else None
         lib().oracle_pop_splice(self.h, grid.h, bl, len(recv_left) // sz, br, len(recv_right) // sz)
+
+
+def pwmci_invert(f, table):
+    """pwmci::invert (pwmci.rs:113-228): (x, evaluations) or None."""
+    t = np.ascontiguousarray(table, dtype=np.float64)
+    x, n = C.c_double(), C.c_int()
+    ok = lib().oracle_pwmci_invert(f, _ptr(t), len(t), C.byref(x), C.byref(n))
+    return (x.value, n.value) if ok else None
+
+
+def pwmci_evaluate(x, table):
+    t = np.ascontiguousarray(table, dtype=np.float64)
+    f = C.c_double()
+    return f.value if lib().oracle_pwmci_evaluate(x, _ptr(t), len(t), C.byref(f)) else None
+
+
+def qed_sample(chi, gamma, r1, r2, r3):
+    """photon_emission::sample (photon_emission.rs:129-203): (omega/mc^2, theta, phi)."""
+    out = np.empty(3)
+    if lib().oracle_qed_sample(chi, gamma, r1, r2, r3, _ptr(out)):
+        raise NotImplementedError("chi >= 100 (photon_emission.rs:146 unimplemented!())")
+    return tuple(out)
+
+
+def qed_classical_sample(chi, gamma, r1, r2, r3):
+    out = np.empty(3)
+    lib().oracle_qed_classical_sample(chi, gamma, r1, r2, r3, _ptr(out))
+    return tuple(out)
+
+
+def philox(ctr, key):
+    c, k, o = np.asarray(ctr, dtype=np.uint32), np.asarray(key, dtype=np.uint32), np.empty(4, dtype=np.uint32)
+    lib().oracle_philox(_ptr(c), _ptr(k), _ptr(o))
+    return o
+
+
+def emission_randoms(seed, pid, step):
+    out = np.empty(4)
+    lib().oracle_emission_randoms(seed, pid, step, _ptr(out))
+    return out
+
+
+def emit_radiation(electrons, photons, seed, step, t, min_energy=None, max_angle=None, max_formation_length=None):
+    """emit_radiation (interactions.rs:45-107) for one subdomain; returns the number of photons appended."""
+    f = lambda v: -1.0 if v is None else float(v)
+    n = lib().oracle_emit_radiation(electrons.h, photons.h, seed, step, t, f(min_energy), f(max_angle), f(max_formation_length))
+    if n < 0:
+        raise NotImplementedError("chi >= 100 (photon_emission.rs:146 unimplemented!())")
+    return n
 
 
 ACCESSORS = {"x": 0, "r": 1, "energy": 2, "px": 3, "py": 4, "pz": 5, "p_perp": 6, "theta": 7, "phi": 8,
