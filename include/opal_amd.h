@@ -43,7 +43,7 @@ typedef struct opal_hist opal_hist_t; /* Histogram, src/particle/hgram.rs:71-84 
 /* enum Boundary, src/grid/mod.rs:22-28 */
 enum opal_boundary { OPAL_BDY_INTERNAL = 0, OPAL_BDY_LASER = 1, OPAL_BDY_ABSORBING = 2, OPAL_BDY_CONDUCTING = 3 };
 /* Electron = Vay push (electron.rs:268-330); Ion = Boris push with Z*, A (ion.rs:168-214) */
-enum opal_species { OPAL_ELECTRON = 0, OPAL_ION = 1 };
+enum opal_species { OPAL_ELECTRON = 0, OPAL_ION = 1, OPAL_PHOTON = 2 };
 
 enum opal_status {
     OPAL_OK = 0,
@@ -160,9 +160,30 @@ int opal_pop_set_sort_interval(opal_pop_t *p, int interval);
  * per thread of the push kernels, [5] live particles and [6] non-empty cells at the last re-binning,
  * [7] host upper bound of the slots in use */
 int opal_pop_counters(const opal_pop_t *p, uint32_t *out);
-/* carry y, z, chi, work, tau for electrons (electron.rs:18-25); off by default */
+/* level 1: carry chi, work, y, z for electrons (electron.rs:18-25) / chi, y, z, parent id for photons;
+ * level 2 (electrons): also the optical depth and id that photon emission needs; 0 = off (default) */
 int opal_pop_track_extras(opal_pop_t *p, int on);
 int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z);
+/* Optical depth against emission (electron.rs:24) and the id that keys the emission random numbers, for
+ * electrons tracked at level 2; for photons (level >= 1) `id` is the parent electron's.  Slot order. */
+int opal_pop_download_emission_state(const opal_pop_t *p, double *tau, uint64_t *id);
+int opal_pop_upload_emission_state(opal_pop_t *p, size_t n, const double *tau, const uint64_t *id);
+
+/* ------------------------------------------------------------------ Photon emission
+ * emit_radiation (particle/interactions.rs:45-107): every electron whose optical depth has fallen below
+ * zero emits a photon sampled from the quantum synchrotron spectrum (qed/photon_emission.rs:129-203),
+ * recoils and draws a new optical depth (electron.rs:208-251); photons passing the filters are appended
+ * to `photons`.  min_energy [MeV], max_angle [rad, to the negative x axis], max_formation_length [m]:
+ * negative = no limit.  Random numbers: Philox4x32-10 keyed by (seed, electron id, step).
+ * n_emitted (optional) receives the number of electrons that emitted. */
+int opal_emit_radiation(opal_pop_t *electrons, opal_pop_t *photons, uint64_t seed, uint32_t step, double t,
+                        double min_energy, double max_angle, double max_formation_length, size_t *n_emitted);
+/* photon_emission::sample / classical_sample, the emission random numbers and photon_emission::rate
+ * evaluated on the device for n inputs in host memory (out: 3n / 4n / n doubles). */
+int opal_qed_sample_batch(size_t n, const double *chi, const double *gamma, const double *r1, const double *r2,
+                          const double *r3, int classical, double *out);
+int opal_qed_randoms_batch(size_t n, uint64_t seed, const uint64_t *id, uint32_t step, double *out);
+int opal_qed_rate_batch(size_t n, const double *chi, const double *gamma, double *out);
 
 /* ------------------------------------------------------------------ Distribution functions
  * Population::write_data (mod.rs:383-568) and Histogram (hgram.rs:168-425).  `spec` is one entry of the
@@ -200,6 +221,12 @@ typedef int (*opal_exchange_fn)(void *user, const void *send_left, const void *s
                                 void *recv_right, size_t nbytes);
 int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, size_t particle_capacity,
                      opal_exchange_fn exchange, void *user, void *hip_stream);
+/* The same with room for `species_slots` species (2: electrons, ions; 3: + photons) and
+ * `fields_per_particle` doubles per particle (6: x ux uy uz w prev_x; 12: + chi work y z tau id, needed
+ * when photon emission is on: the reference ships whole structs, mod.rs:308-354). */
+int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_buffers, size_t particle_capacity,
+                            int species_slots, int fields_per_particle, opal_exchange_fn exchange, void *user,
+                            void *hip_stream);
 int opal_link_free(opal_link_t *l);
 /* bytes per direction of a whole message (halo + both species' leavers) and of its halo-only prefix;
  * the `nbytes` passed to the exchange callback is always one of the two */
@@ -235,6 +262,7 @@ size_t opal_sim_n_outputs(const opal_sim_t *s);
 opal_grid_t *opal_sim_grid(opal_sim_t *s);
 opal_pop_t *opal_sim_electrons(opal_sim_t *s);
 opal_pop_t *opal_sim_ions(opal_sim_t *s);
+opal_pop_t *opal_sim_photons(opal_sim_t *s); /* null unless qed.photon_emission is on */
 /* write_energies, main.rs:23-42: em_field, electrons, ions (this subdomain's parts) */
 int opal_sim_energies(opal_sim_t *s, double *em_field, double *electrons, double *ions);
 /* 1 = use the fused advance+deposit pass (default), 0 = the reference's operator sequence */

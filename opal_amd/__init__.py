@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import FN1, FN2, FN3
 
 BDY_INTERNAL, BDY_LASER, BDY_ABSORBING, BDY_CONDUCTING = 0, 1, 2, 3
-ELECTRON, ION = 0, 1
+ELECTRON, ION, PHOTON = 0, 1, 2
 COMP = {"x": 0, "rho": 1, "jx": 2, "jy": 3, "jz": 4, "Ex": 5, "Ey": 6, "Ez": 7, "Bx": 8, "By": 9, "Bz": 10}
 KERNELS = {"fused": 0, "advance": 1, "deposit": 2, "field": 3, "sort": 4}
 
@@ -157,7 +157,7 @@ class Grid:
 
 
 class Population:
-    """Population<Electron> / Population<Ion> on the GPU (SoA in HBM)."""
+    """Population<Electron> / Population<Ion> / Population<Photon> on the GPU (SoA in HBM)."""
 
     def __init__(self, species, capacity=0, stream=None, _handle=None):
         self._lib = _lib.load()
@@ -275,13 +275,63 @@ class Population:
         _check(self._lib.opal_pop_write_data(self.h, grid.h, directory.encode(), index, name.encode(), arr, len(specs)))
 
     def track_extras(self, on=True):
-        _check(self._lib.opal_pop_track_extras(self.h, 1 if on else 0))
+        """on: False/0 off, True/1 chi work y z (photons: chi y z parent id), 2 also the optical depth and id
+        photon emission needs (electrons)."""
+        _check(self._lib.opal_pop_track_extras(self.h, int(on)))
+
+    def emission_state(self):
+        """(tau, id) of every electron in slot order; for photons (None, parent id)."""
+        n = len(self)
+        tau = np.empty(n) if self.species == ELECTRON else None
+        ids = np.empty(n, dtype=np.uint64)
+        _check(self._lib.opal_pop_download_emission_state(self.h, _ptr(tau) if tau is not None else None, _ptr(ids)))
+        return tau, ids
+
+    def set_emission_state(self, tau=None, ids=None):
+        """Overwrite the optical depths / ids of the particles just uploaded (same order)."""
+        t = np.ascontiguousarray(tau, dtype=np.float64) if tau is not None else None
+        i = np.ascontiguousarray(ids, dtype=np.uint64) if ids is not None else None
+        n = len(t) if t is not None else len(i)
+        _check(self._lib.opal_pop_upload_emission_state(self.h, n, _ptr(t) if t is not None else None,
+                                                        _ptr(i) if i is not None else None))
 
     def extras(self):
         n = len(self)
         out = {k: np.empty(n) for k in ("chi", "work", "y", "z")}
         _check(self._lib.opal_pop_download_extras(self.h, *[_ptr(out[k]) for k in ("chi", "work", "y", "z")]))
         return out
+
+
+def emit_radiation(electrons, photons, seed, step, t, min_energy=None, max_angle=None, max_formation_length=None):
+    """emit_radiation (particle/interactions.rs:45-107); returns the number of electrons that emitted."""
+    f = lambda v: -1.0 if v is None else float(v)
+    n = C.c_size_t()
+    _check(_lib.load().opal_emit_radiation(electrons.h, photons.h, seed, step, t, f(min_energy), f(max_angle),
+                                           f(max_formation_length), C.byref(n)))
+    return n.value
+
+
+def qed_sample(chi, gamma, r1, r2, r3, classical=False):
+    """photon_emission::sample / classical_sample evaluated on the device; returns an (n, 3) array."""
+    a = [np.ascontiguousarray(np.broadcast_to(v, np.shape(chi)), dtype=np.float64) for v in (chi, gamma, r1, r2, r3)]
+    out = np.empty((len(a[0]), 3))
+    _check(_lib.load().opal_qed_sample_batch(len(a[0]), *[_ptr(v) for v in a], 1 if classical else 0, _ptr(out)))
+    return out
+
+
+def qed_randoms(seed, ids, step):
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    out = np.empty((len(ids), 4))
+    _check(_lib.load().opal_qed_randoms_batch(len(ids), seed, _ptr(ids), step, _ptr(out)))
+    return out
+
+
+def qed_rate(chi, gamma):
+    chi = np.ascontiguousarray(chi, dtype=np.float64)
+    gamma = np.ascontiguousarray(np.broadcast_to(gamma, chi.shape), dtype=np.float64)
+    out = np.empty(len(chi))
+    _check(_lib.load().opal_qed_rate_batch(len(chi), _ptr(chi), _ptr(gamma), _ptr(out)))
+    return out
 
 
 class Simulation:
@@ -303,6 +353,8 @@ class Simulation:
         i = self._lib.opal_sim_ions(h)
         self.electrons = Population(ELECTRON, _handle=e) if e else None
         self.ions = Population(ION, _handle=i) if i else None
+        ph = self._lib.opal_sim_photons(h)
+        self.photons = Population(PHOTON, _handle=ph) if ph else None  # only with qed.photon_emission
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -67,6 +67,12 @@ SIGNATURES = {
     "opal_pop_counters": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "opal_pop_track_extras": (C.c_int, [vp, C.c_int]),
     "opal_pop_download_extras": (C.c_int, [vp, vp, vp, vp, vp]),
+    "opal_pop_download_emission_state": (C.c_int, [vp, vp, vp]),
+    "opal_pop_upload_emission_state": (C.c_int, [vp, sz, vp, vp]),
+    "opal_emit_radiation": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
+    "opal_qed_sample_batch": (C.c_int, [sz, vp, vp, vp, vp, vp, C.c_int, vp]),
+    "opal_qed_randoms_batch": (C.c_int, [sz, C.c_uint64, vp, C.c_uint32, vp]),
+    "opal_qed_rate_batch": (C.c_int, [sz, vp, vp, vp]),
     "opal_pop_hist_range": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(C.c_int), vp, vp, C.POINTER(sz)]),
     "opal_pop_hist_fill": (C.c_int, [vp, vp, C.c_char_p, vp, vp, sz, pp]),
     "opal_hist_len": (sz, [vp]),
@@ -80,6 +86,7 @@ SIGNATURES = {
     "opal_hist_filename": (C.c_int, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.c_char_p, sz]),
     "opal_pop_write_data": (C.c_int, [vp, vp, C.c_char_p, sz, C.c_char_p, C.POINTER(C.c_char_p), sz]),
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),
+    "opal_link_create_layout": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.c_int, EXCHANGE_FN, vp, vp]),
     "opal_link_free": (C.c_int, [vp]),
     "opal_link_message_bytes": (sz, [vp]),
     "opal_link_halo_bytes": (sz, [vp]),
@@ -100,6 +107,7 @@ SIGNATURES = {
     "opal_sim_grid": (vp, [vp]),
     "opal_sim_electrons": (vp, [vp]),
     "opal_sim_ions": (vp, [vp]),
+    "opal_sim_photons": (vp, [vp]),
     "opal_sim_energies": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
     "opal_sim_set_fused": (C.c_int, [vp, C.c_int]),
     "opal_prof_enable": (C.c_int, [C.c_int]),

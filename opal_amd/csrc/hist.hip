@@ -32,7 +32,7 @@ struct AccArgs {
     const PopCounters *ctr;
     int species;
     double xmin, dx;      // grid.xmin(), grid.dx()
-    double mass_mev;      // momentum unit: 0.510999 (electron.rs:157-160) or (A m_p / m_e) 0.510999 (ion.rs:140-143)
+    double mass_mev;      // momentum unit: 0.510999 (electron.rs:157-160, photon.rs:211-214) or (A m_p / m_e) 0.510999 (ion.rs:140-143)
     int acc[2];
     int log[2];
     int dim;
@@ -43,6 +43,7 @@ __device__ inline double particle_energy(const AccArgs &a, double u2)
 {
     double g = sqrt(1.0 + u2);
     if (a.species == OPAL_ELECTRON) return g * ELECTRON_MASS_MEV;  // electron.rs:118-120
+    if (a.species == OPAL_PHOTON) return sqrt(u2) * ELECTRON_MASS_MEV;  // photon.rs:222-224
     return (u2 / (1.0 + g)) * a.mass_mev;                          // ion.rs:128-130
 }
 
@@ -52,7 +53,7 @@ __device__ inline double access(const AccArgs &a, int id, size_t i)
     double px = a.ux[i] * a.mass_mev, py = a.uy[i] * a.mass_mev, pz = a.uz[i] * a.mass_mev;
     switch (id) {
     case ACC_X: return a.xmin + (((double)a.cell[i]) + a.x[i]) * a.dx;
-    case ACC_R: return (a.species == OPAL_ELECTRON && a.y) ? hypot(a.y[i], a.z[i]) : 0.0;
+    case ACC_R: return (a.species != OPAL_ION && a.y) ? hypot(a.y[i], a.z[i]) : 0.0;  // ion.rs has no y / z
     case ACC_ENERGY: return particle_energy(a, a.ux[i] * a.ux[i] + a.uy[i] * a.uy[i] + a.uz[i] * a.uz[i]);
     case ACC_PX: return px;
     case ACC_PY: return py;
@@ -263,12 +264,13 @@ AccArgs make_acc(const opal_pop_t *p, const opal_grid_t *g, const Spec &sp)
     memset(&a, 0, sizeof a);
     int k = p->cur;
     a.cell = p->d_cell[k]; a.x = p->d_x[k]; a.ux = p->d_ux[k]; a.uy = p->d_uy[k]; a.uz = p->d_uz[k]; a.w = p->d_w[k];
-    if (p->extras) { a.chi = p->d_chi; a.work = p->d_work; a.y = p->d_y; a.z = p->d_z; }
+    if (p->extras) { a.chi = p->d_ex[EX_CHI]; a.work = p->d_ex[EX_WORK]; a.y = p->d_ex[EX_Y]; a.z = p->d_ex[EX_Z]; }
     a.ctr = p->d_ctr;
     a.species = p->species;
     a.xmin = opal_grid_xmin(g);
     a.dx = g->dx;
-    a.mass_mev = p->species == OPAL_ELECTRON ? ELECTRON_MASS_MEV : (p->a * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV;
+    a.mass_mev = p->species != OPAL_ION ? ELECTRON_MASS_MEV  // photon.rs:211-214: k in units of m_e c
+                                        : (p->a * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV;
     a.dim = sp.dim;
     for (int d = 0; d < 2; d++) {
         a.acc[d] = sp.acc[d];

@@ -102,9 +102,10 @@ int design_balanced(int numtasks, size_t size, double xmin, double dx, size_t mi
 
 // Population::new, particle/mod.rs:172-203, into SoA host arrays.
 // Draw order per particle: x, then (urand, nrand) for ux, uy, uz, then the
-// species' optical depth (one Exp1 for electrons, electron.rs:168-172; none
-// for ions, ion.rs:157-159) -- drawn and discarded here because tau is not
-// observable with photon emission off, but it keeps the stream aligned.
+// species' optical depths (one Exp1 for electrons, electron.rs:168-172, kept
+// in out.tau: it only matters when photon emission is on; none for ions,
+// ion.rs:157-159; four for photons, photon.rs:126-133, which only absorption
+// reads: drawn to keep the stream aligned, then dropped).
 void load_population(int species, size_t npc, const std::function<double(double)> &number_density,
                      const Fn3 &ux, const Fn3 &uy, const Fn3 &uz, double grid_xmin, double dx, size_t ncells,
                      Rng &rng, HostSoA &out)
@@ -123,7 +124,9 @@ void load_population(int species, size_t npc, const std::function<double(double)
             double vy = uy(real_x, ur, nr);
             ur = rng.uniform(); nr = rng.normal();
             double vz = uz(real_x, ur, nr);
-            if (species == 0) (void)rng.exp1();
+            if (species == 0) out.tau.push_back(rng.exp1());
+            if (species == 2)
+                for (int k = 0; k < 4; k++) (void)rng.exp1();
             out.cell.push_back((int32_t)c);
             out.x.push_back(xf);
             out.ux.push_back(vx);

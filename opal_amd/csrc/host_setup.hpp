@@ -21,6 +21,7 @@ using Fn3 = std::function<double(double, double, double)>;
 struct HostSoA {
     std::vector<int32_t> cell;
     std::vector<double> x, ux, uy, uz, w;
+    std::vector<double> tau;  // electrons: the optical depth against emission drawn at load time (electron.rs:168-172)
     size_t size() const { return cell.size(); }
 };
 

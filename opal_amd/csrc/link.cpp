@@ -4,11 +4,14 @@
 // direction; the transport (RCCL, gloo, ...) is the callback the host supplied.
 //
 // Message layout (bytes), P = particle_capacity of the link:
-//   [0, 64)            header: uint32 count[2] (species slot 0 = electrons, 1 = ions), padding
+//   [0, 64)            header: uint32 count[S] (species slot 0 = electrons, 1 = ions, 2 = photons), padding
 //   [64, 704)          halo: 8 cells x (rho jx jy jz Ex Ey Ez Bx By Bz) doubles  (yee.rs:353-354)
-//   then per species slot s = 0, 1 (each block 8-byte aligned):
+//   then per species slot s = 0 .. S-1 (each block 8-byte aligned):
 //       int32  cell[P]            re-based cell index in the receiver's frame (mod.rs:291-293, 366-368)
 //       double x[P] ux[P] uy[P] uz[P] w[P] prev_x[P]
+//       double chi[P] work[P] y[P] z[P] tau[P] id[P]     only when the link was created with 12 fields
+// S = 2 and 6 fields by default; runs with photon emission use S = 3 and 12 fields (the reference ships
+// whole structs, so optical depths and ids must travel with an electron that changes subdomain).
 // A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes; anything with particles moves
 // the whole message.  What a subdomain sends left arrives as its left neighbour's "recv_right".
 #include <hip/hip_runtime_api.h>
@@ -69,7 +72,15 @@ extern "C" {
 int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, size_t particle_capacity,
                      opal_exchange_fn exchange, void *user, void *hip_stream)
 {
-    if (!out || !exchange || size < 1 || rank < 0 || rank >= size) {
+    return opal_link_create_layout(out, rank, size, device_buffers, particle_capacity, 2, 6, exchange, user, hip_stream);
+}
+
+int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_buffers, size_t particle_capacity,
+                            int species_slots, int fields_per_particle, opal_exchange_fn exchange, void *user,
+                            void *hip_stream)
+{
+    if (!out || !exchange || size < 1 || rank < 0 || rank >= size || species_slots < 2 || species_slots > 3
+        || (fields_per_particle != 6 && fields_per_particle != 12)) {
         set_error("opal_link_create: bad arguments");
         return OPAL_ERR_ARG;
     }
@@ -84,8 +95,10 @@ int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, 
     l->exchange = exchange;
     l->user = user;
     l->stream = (hipStream_t)hip_stream;
-    l->species_bytes = particle_capacity * (sizeof(int32_t) + 6 * sizeof(double));
-    l->nbytes = LINK_HEAD_BYTES + 2 * l->species_bytes;
+    l->nslots = species_slots;
+    l->nfields = fields_per_particle;
+    l->species_bytes = particle_capacity * (sizeof(int32_t) + (size_t)fields_per_particle * sizeof(double));
+    l->nbytes = LINK_HEAD_BYTES + (size_t)species_slots * l->species_bytes;
     char **dev[4] = {&l->d_send_left, &l->d_send_right, &l->d_recv_left, &l->d_recv_right};
     for (auto d : dev) {
         OPAL_HIP(hipMalloc((void **)d, l->nbytes));

@@ -13,6 +13,8 @@ struct opal_link {
     bool device_buffers;
     bool external;  // buffers the transport sees belong to the caller
     size_t cap;     // particles per species per direction
+    int nslots;     // species blocks per message: 2 (electrons, ions) or 3 (+ photons)
+    int nfields;    // doubles per particle: 6 (x ux uy uz w prev_x) or 12 (+ chi work y z tau id)
     size_t species_bytes, nbytes;
     opal_exchange_fn exchange;
     void *user;

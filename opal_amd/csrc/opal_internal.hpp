@@ -15,10 +15,12 @@ namespace opal {
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what);
 
+#define OPAL_STR2(x) #x
+#define OPAL_STR(x) OPAL_STR2(x)
 #define OPAL_HIP(call)                                          \
     do {                                                        \
         hipError_t e_ = (call);                                 \
-        if (e_ != hipSuccess) return opal::hip_fail(e_, #call); \
+        if (e_ != hipSuccess) return opal::hip_fail(e_, #call " at " __FILE__ ":" OPAL_STR(__LINE__)); \
     } while (0)
 
 // Device-resident counters of a population (one 64-byte record).
@@ -31,9 +33,12 @@ struct PopCounters {
     int err;                   // bit 0: dxi >= 1; bit 1: gather index; bit 2: deposit index; bit 3: leaver overflow
     unsigned int n_live;       // written by sort / count kernels
     unsigned int n_nonempty;   // non-empty cells at last sort
-    unsigned int pad[8];
+    unsigned int n_emit;       // electrons whose optical depth ran out in the last push (photon emission)
+    unsigned int n_lost;       // photons that found no free slot (capacity is checked by the host first: stays 0)
+    unsigned int pad[6];
 };
 
+enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, NEX = 6 };
 enum { KERNEL_FUSED = 0, KERNEL_ADVANCE = 1, KERNEL_DEPOSIT = 2, KERNEL_FIELD = 3, KERNEL_SORT = 4, KERNEL_COUNT = 5 };
 void prof_begin(int kernel, hipStream_t s);
 void prof_end(int kernel, hipStream_t s);
@@ -73,8 +78,14 @@ struct opal_pop {
     int cur;
     double *d_prev_x;               // allocated on first unfused advance
     bool prev_valid;
-    double *d_chi, *d_work, *d_y, *d_z;  // electron extras (optional)
-    bool extras;
+    // optional per-particle extras, any of which may be absent (null):
+    //   electrons  chi work y z (diagnostics, level 1)  + tau id (photon emission, level 2)
+    //   photons    chi y z id
+    // id is a 64-bit integer kept in a double's bits (only ever copied).
+    double *d_ex[opal::NEX];
+    double *d_ex_alt[opal::NEX];  // re-binning targets, allocated on first use
+    unsigned long long id_base;   // ids of freshly uploaded particles are id_base + slot (set per subdomain)
+    int extras;  // 0 off, 1 diagnostics, 2 + optical depth / id for photon emission
     double z_star, z, a;
     opal::PopCounters *d_ctr;
     opal::PopCounters *h_ctr;  // pinned

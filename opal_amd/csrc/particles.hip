@@ -1,4 +1,4 @@
-// Population<Electron|Ion> on the GPU.
+// Population<Electron|Ion|Photon> on the GPU.
 //
 // HBM layout: structure of arrays, one contiguous array per attribute
 //   cell:i32  x  ux  uy  uz  w : f64          (44 B per macro-particle)
@@ -21,6 +21,7 @@
 #include "link.hpp"
 #include "opal_internal.hpp"
 #include "pic_device.hpp"
+#include "qed_device.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -62,7 +63,7 @@ struct PushArgs {
     double *x, *ux, *uy, *uz;
     const double *w;
     double *prev_x;
-    double *chi, *work, *y, *z;
+    double *ex[NEX];  // extras (any may be null, see opal_pop)
     const double *eb;  // 6 x lenp
     double *jr;        // 4 x lenp
     size_t lenp;
@@ -76,6 +77,7 @@ struct PushArgs {
     int *send_cell[2];
     double *send_f[2];  // x ux uy uz w prev_x, 6 x send_cap
     unsigned send_cap;
+    unsigned send_nextra;  // extras carried behind the 6 base fields (0 for a plain link)
 };
 
 struct LdsFields {
@@ -163,7 +165,7 @@ struct ChunkPtrs {
 // The per-particle body shared by the three modes.  FAST = the particle's stencil lies inside the
 // workgroup's LDS tile (fields from LDS, currents into the LDS accumulators); otherwise fields come
 // from global memory and the taps go to the grid with global atomics.
-template <int SPECIES, int MODE, bool RHO, bool EXTRAS, bool FAST>
+template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool FAST>
 __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkPtrs &cp, const double *s_field,
                                                  double *s_acc, int base, int lane, unsigned kc, int c, double xi,
                                                  V3 u, double wt, double prev, int &err)
@@ -184,13 +186,22 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         }
         Pushed r;
         if (SPECIES == OPAL_ELECTRON) {
-            r = vay_push<EXTRAS>(u, E, B, a.alpha, a.dt_over_dx, a.dt);
+            r = vay_push<EXTRAS != 0>(u, E, B, a.alpha, a.dt_over_dx, a.dt);
             if (EXTRAS) {
                 size_t i = cp.chunk0 + kc;
-                a.chi[i] = r.chi;
-                a.work[i] += r.dwork;
-                a.y[i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
-                a.z[i] += r.v_old.z * a.dt;
+                a.ex[EX_CHI][i] = r.chi;
+                a.ex[EX_WORK][i] += r.dwork;
+                a.ex[EX_Y][i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
+                a.ex[EX_Z][i] += r.v_old.z * a.dt;
+                if (EXTRAS == 2) a.ex[EX_TAU][i] -= qed_rate(r.chi, r.gamma_half) * a.dt;  // electron.rs:284-288
+            }
+        } else if (SPECIES == OPAL_PHOTON) {
+            r = photon_push<EXTRAS != 0>(u, E, B, a.dt_over_dx);
+            if (EXTRAS) {
+                size_t i = cp.chunk0 + kc;
+                a.ex[EX_CHI][i] = r.chi;
+                a.ex[EX_Y][i] += r.v_old.y * a.dt;  // photon.rs:166-167
+                a.ex[EX_Z][i] += r.v_old.z * a.dt;
             }
         } else {
             r = boris_push(u, E, B, a.alpha, a.dt_over_dx);
@@ -254,6 +265,14 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                 f[3 * (size_t)a.send_cap + slot] = u.z;
                 f[4 * (size_t)a.send_cap + slot] = wt;
                 if (MODE == MODE_ADVANCE) f[5 * (size_t)a.send_cap + slot] = prev;
+                if (EXTRAS && a.send_nextra) {
+                    // a link laid out for photon emission carries the extras too (the reference ships the
+                    // whole struct, mod.rs:308-354); values as updated by this push
+                    size_t i = cp.chunk0 + kc;
+#pragma unroll
+                    for (int q = 0; q < NEX; q++)
+                        if (q < (int)a.send_nextra) f[(size_t)(6 + q) * a.send_cap + slot] = a.ex[q] ? a.ex[q][i] : 0.0;
+                }
             } else {
                 err |= 8;
             }
@@ -261,9 +280,11 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         } else {
             stk(cp.cell, kc, newc);
             stk(cp.x, kc, xn);
-            stk(cp.ux, kc, u.x);
-            stk(cp.uy, kc, u.y);
-            stk(cp.uz, kc, u.z);
+            if (SPECIES != OPAL_PHOTON) {  // a photon's momentum never changes
+                stk(cp.ux, kc, u.x);
+                stk(cp.uy, kc, u.y);
+                stk(cp.uz, kc, u.z);
+            }
             if (MODE == MODE_ADVANCE) stk(cp.prev, kc, prev);
         }
     }
@@ -274,7 +295,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
 //                  detection); stores prev_x for a later deposit.
 //   MODE_DEPOSIT : YeeGrid::deposit's per-particle body, yee.rs:573-610.
 //   MODE_FUSED   : both in one pass (prev_x stays in registers).
-template <int SPECIES, int MODE, bool RHO, bool EXTRAS>
+template <int SPECIES, int MODE, bool RHO, int EXTRAS>
 __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, double *s_field, double *s_acc, int *s_min,
                                           int *s_max)
 {
@@ -447,7 +468,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     }
 }
 
-template <int SPECIES, int MODE, bool RHO, bool EXTRAS>
+template <int SPECIES, int MODE, bool RHO, int EXTRAS>
 __global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
 {
     __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
@@ -465,8 +486,8 @@ __global__ __launch_bounds__(BLOCK) void k_push_pair(PushArgs ae, PushArgs ai, u
     __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
     __shared__ double s_acc[MODE != MODE_ADVANCE ? 4 * TILE * REPL : 1];
     __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
-    if (blockIdx.x < nblk_e) push_body<OPAL_ELECTRON, MODE, RHO, false>(ae, blockIdx.x, s_field, s_acc, s_min, s_max);
-    else push_body<OPAL_ION, MODE, RHO, false>(ai, blockIdx.x - nblk_e, s_field, s_acc, s_min, s_max);
+    if (blockIdx.x < nblk_e) push_body<OPAL_ELECTRON, MODE, RHO, 0>(ae, blockIdx.x, s_field, s_acc, s_min, s_max);
+    else push_body<OPAL_ION, MODE, RHO, 0>(ai, blockIdx.x - nblk_e, s_field, s_acc, s_min, s_max);
 }
 
 // ------------------------------------------------------------------ re-binning
@@ -560,8 +581,8 @@ struct SortArgs {
     double *of[5];
     const double *prev;
     double *oprev;
-    const double *ex[4];  // chi work y z (electron extras) or null
-    double *oex[4];
+    const double *ex[NEX];  // extras, each may be null
+    double *oex[NEX];
 };
 
 __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a, const PopCounters *ctr, unsigned *__restrict__ cursor)
@@ -605,10 +626,9 @@ __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a, const PopCount
 #pragma unroll
         for (int q = 0; q < 5; q++) a.of[q][d] = a.f[q][i];
         if (a.prev) a.oprev[d] = a.prev[i];
-        if (a.ex[0]) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) a.oex[q][d] = a.ex[q][i];
-        }
+        for (int q = 0; q < NEX; q++)
+            if (a.ex[q]) a.oex[q][d] = a.ex[q][i];
     }
 }
 
@@ -619,7 +639,7 @@ __global__ void k_sort_finish(PopCounters *ctr)
 }
 
 // ------------------------------------------------------------- kinetic energy
-// electron.rs:122-126 / ion.rs:128-134; per-workgroup partial sums in a fixed tree, then one
+// electron.rs:122-126 / ion.rs:128-134 / photon.rs:222-231; per-workgroup partial sums in a fixed tree, then one
 // workgroup folds the partials: the result does not depend on scheduling.
 template <int SPECIES>
 __global__ void k_kinetic(const int *__restrict__ cell, const double *__restrict__ ux, const double *__restrict__ uy,
@@ -636,6 +656,8 @@ __global__ void k_kinetic(const int *__restrict__ cell, const double *__restrict
         if (SPECIES == OPAL_ELECTRON) {
             double to_joules = 1.0e6 * ELECTRON_MASS_MEV * ELEMENTARY_CHARGE;
             acc += w[i] * u2 * to_joules / (g + 1.0);
+        } else if (SPECIES == OPAL_PHOTON) {  // photon.rs:222-231
+            acc += w[i] * (sqrt(u2) * ELECTRON_MASS_MEV) * 1.0e6 * ELEMENTARY_CHARGE;
         } else {
             double gamma_m1 = u2 / (1.0 + g);
             double energy = gamma_m1 * (a_mass * PROTON_MASS / ELECTRON_MASS) * ELECTRON_MASS_MEV;
@@ -665,7 +687,7 @@ __global__ void k_fold(const double *__restrict__ partial, int n, double *__rest
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
-// T::create, electron.rs:85-103 / ion.rs:81-101: prev_x from the initial momentum
+// T::create, electron.rs:85-103 / ion.rs:81-101 / photon.rs:95-98: prev_x from the initial momentum
 template <int SPECIES>
 __global__ void k_init_prev(const int *cell, const double *x, const double *ux, const double *uy, const double *uz,
                             double *prev_x, unsigned n, double dt, double dx)
@@ -676,6 +698,8 @@ __global__ void k_init_prev(const int *cell, const double *x, const double *ux, 
     if (SPECIES == OPAL_ELECTRON) {
         double gamma = sqrt(1.0 + u2);
         prev_x[i] = x[i] - SPEED_OF_LIGHT * ux[i] * dt / (gamma * dx);
+    } else if (SPECIES == OPAL_PHOTON) {  // photon.rs:95-98
+        prev_x[i] = x[i] - SPEED_OF_LIGHT * ux[i] * dt / (sqrt(u2) * dx);
     } else {
         double gamma_m1 = u2 / (1.0 + sqrt(1.0 + u2));
         double vx = SPEED_OF_LIGHT * ux[i] / (1.0 + gamma_m1);
@@ -694,7 +718,8 @@ struct UnpackArgs {
     int *cell;
     double *f[5];
     double *prev_x;
-    double *ex[4];  // electron extras (chi work y z) or null: arrivals restart them from zero
+    double *ex[NEX];  // extras, each may be null
+    unsigned nextra;  // how many of them the message carries behind the 6 base fields (0: arrivals restart from zero)
     PopCounters *ctr;
     unsigned pop_cap;
     int my_size;
@@ -726,12 +751,11 @@ __global__ void k_unpack(UnpackArgs a)
 #pragma unroll
         for (int c = 0; c < 5; c++) a.f[c][base + k] = rf[(size_t)c * a.link_cap + k];
         if (a.prev_x) a.prev_x[base + k] = rf[(size_t)5 * a.link_cap + k];
-        if (a.ex[0]) {
-            // the link message does not carry chi / work / y / z (diagnostics only): a particle that
-            // changes subdomain restarts them
+        // a plain link's message does not carry the extras (diagnostics only: a particle that changes
+        // subdomain restarts them); a link laid out for photon emission carries all of them
 #pragma unroll
-            for (int q = 0; q < 4; q++) a.ex[q][base + k] = 0.0;
-        }
+        for (int q = 0; q < NEX; q++)
+            if (a.ex[q]) a.ex[q][base + k] = q < (int)a.nextra ? rf[(size_t)(6 + q) * a.link_cap + k] : 0.0;
     }
 }
 
@@ -791,6 +815,7 @@ void free_set(opal_pop_t *p, int k)
     hipFree(p->d_cell[k]); hipFree(p->d_x[k]); hipFree(p->d_ux[k]);
     hipFree(p->d_uy[k]); hipFree(p->d_uz[k]); hipFree(p->d_w[k]);
     p->d_cell[k] = nullptr;
+    p->d_x[k] = p->d_ux[k] = p->d_uy[k] = p->d_uz[k] = p->d_w[k] = nullptr;  // freeing a set twice must be harmless
 }
 
 // Enlarges the population's storage (HBM is plentiful: 288 GB): new arrays, device-to-device copy of
@@ -825,13 +850,41 @@ int grow(opal_pop_t *p, size_t new_cap)
         free_set(p, k ^ 1);
         p->have_alt = false;
     }
-    if (p->d_chi) {
-        if (int rc = regrow(p->d_chi)) return rc;
-        if (int rc = regrow(p->d_work)) return rc;
-        if (int rc = regrow(p->d_y)) return rc;
-        if (int rc = regrow(p->d_z)) return rc;
+    for (int q = 0; q < NEX; q++) {
+        if (p->d_ex[q])
+            if (int rc = regrow(p->d_ex[q])) return rc;
+        if (p->d_ex_alt[q]) {
+            hipFree(p->d_ex_alt[q]);
+            p->d_ex_alt[q] = nullptr;
+        }
     }
     p->cap = new_cap;
+    return OPAL_OK;
+}
+
+// T::create's values for the extras of slots [first, first + n): chi = work = y = z = 0,
+// tau = +inf (electron.rs:98-99), id = id_base + slot
+__global__ void k_reset_extras(double *chi, double *work, double *y, double *z, double *tau, double *id, size_t first,
+                               size_t n, unsigned long long id_base)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    i += first;
+    if (chi) chi[i] = 0.0;
+    if (work) work[i] = 0.0;
+    if (y) y[i] = 0.0;
+    if (z) z[i] = 0.0;
+    if (tau) tau[i] = INFINITY;
+    if (id) reinterpret_cast<unsigned long long *>(id)[i] = id_base + i;
+}
+
+int reset_extras(opal_pop_t *p, size_t first, size_t n)
+{
+    if (!n) return OPAL_OK;
+    k_reset_extras<<<(unsigned)((n + 255) / 256), 256, 0, p->stream>>>(p->d_ex[EX_CHI], p->d_ex[EX_WORK], p->d_ex[EX_Y],
+                                                                       p->d_ex[EX_Z], p->d_ex[EX_TAU], p->d_ex[EX_ID],
+                                                                       first, n, p->id_base);
+    OPAL_HIP(hipGetLastError());
     return OPAL_OK;
 }
 
@@ -844,21 +897,25 @@ int ensure_prev(opal_pop_t *p)
 double species_alpha(const opal_pop_t *p, double dt)
 {
     if (p->species == OPAL_ELECTRON) return ELECTRON_CHARGE * dt / (2.0 * ELECTRON_MASS * SPEED_OF_LIGHT);  // electron.rs:276
+    if (p->species == OPAL_PHOTON) return 0.0;
     double q = p->z_star * ELEMENTARY_CHARGE, M = p->a * PROTON_MASS;                                        // ion.rs:173-175
     return q * dt / (2.0 * M * SPEED_OF_LIGHT);
 }
 double species_charge(const opal_pop_t *p)
 {
+    if (p->species == OPAL_PHOTON) return 0.0;  // photon.rs:199-201
     return p->species == OPAL_ELECTRON ? ELECTRON_CHARGE : p->z_star * ELEMENTARY_CHARGE;  // electron.rs:141, ion.rs:116
 }
 
 template <int SPECIES, int MODE>
-void launch_push(const PushArgs &a, unsigned nblk, bool extras, hipStream_t s)
+void launch_push(const PushArgs &a, unsigned nblk, int extras, hipStream_t s)
 {
-    if (SPECIES == OPAL_ELECTRON && extras && MODE != MODE_DEPOSIT)
-        k_push<SPECIES, MODE, true, true><<<nblk, BLOCK, 0, s>>>(a);
+    if (SPECIES != OPAL_ION && extras == 2 && MODE != MODE_DEPOSIT)
+        k_push<SPECIES, MODE, true, (SPECIES == OPAL_ELECTRON ? 2 : 1)><<<nblk, BLOCK, 0, s>>>(a);
+    else if (SPECIES != OPAL_ION && extras && MODE != MODE_DEPOSIT)
+        k_push<SPECIES, MODE, true, 1><<<nblk, BLOCK, 0, s>>>(a);
     else
-        k_push<SPECIES, MODE, true, false><<<nblk, BLOCK, 0, s>>>(a);
+        k_push<SPECIES, MODE, true, 0><<<nblk, BLOCK, 0, s>>>(a);
 }
 
 int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode, PushArgs &a, unsigned &nblk)
@@ -867,7 +924,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     int k = p->cur;
     a.cell = p->d_cell[k]; a.x = p->d_x[k]; a.ux = p->d_ux[k]; a.uy = p->d_uy[k]; a.uz = p->d_uz[k]; a.w = p->d_w[k];
     a.prev_x = p->d_prev_x;
-    a.chi = p->d_chi; a.work = p->d_work; a.y = p->d_y; a.z = p->d_z;
+    for (int q = 0; q < NEX; q++) a.ex[q] = p->extras ? p->d_ex[q] : nullptr;
     a.eb = g->d_eb[g->cur];
     a.jr = g->j();
     a.lenp = g->lenp;
@@ -891,7 +948,11 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
             set_error("%d subdomains: particle migration needs a link", g->ngrids);
             return OPAL_ERR_ARG;
         }
-        int slot = p->species == OPAL_ELECTRON ? 0 : 1;
+        int slot = p->species;  // electrons 0, ions 1, photons 2
+        if (slot >= link->nslots) {
+            set_error("this link's messages have no room for species %d (see opal_link_set_layout)", slot);
+            return OPAL_ERR_LINK;
+        }
         for (int side = 0; side < 2; side++) {
             char *msg = link_send(link, side);
             char *blk = msg + link_species_offset(link, slot);
@@ -900,6 +961,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
             a.send_f[side] = reinterpret_cast<double *>(blk + sizeof(int) * link->cap);
         }
         a.send_cap = (unsigned)link->cap;
+        a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
     nblk = (unsigned)((p->n_upper + per_block - 1) / per_block);
@@ -914,15 +976,22 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     if (int rc = build_args(p, link, g, dt, mode, a, nblk)) return rc;
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, p->stream);
-    bool ex = p->extras;
+    int ex = p->extras;
     if (p->species == OPAL_ELECTRON) {
         if (mode == MODE_FUSED) launch_push<OPAL_ELECTRON, MODE_FUSED>(a, nblk, ex, p->stream);
         else if (mode == MODE_ADVANCE) launch_push<OPAL_ELECTRON, MODE_ADVANCE>(a, nblk, ex, p->stream);
         else launch_push<OPAL_ELECTRON, MODE_DEPOSIT>(a, nblk, ex, p->stream);
+    } else if (p->species == OPAL_PHOTON) {
+        // photons carry no charge: they are pushed (main.rs:242-244) but never deposited (main.rs:254-258)
+        if (mode != MODE_ADVANCE) {
+            set_error("photons are not deposited (photon.rs:199-201: charge 0)");
+            return OPAL_ERR_ARG;
+        }
+        launch_push<OPAL_PHOTON, MODE_ADVANCE>(a, nblk, ex, p->stream);
     } else {
-        if (mode == MODE_FUSED) launch_push<OPAL_ION, MODE_FUSED>(a, nblk, false, p->stream);
-        else if (mode == MODE_ADVANCE) launch_push<OPAL_ION, MODE_ADVANCE>(a, nblk, false, p->stream);
-        else launch_push<OPAL_ION, MODE_DEPOSIT>(a, nblk, false, p->stream);
+        if (mode == MODE_FUSED) launch_push<OPAL_ION, MODE_FUSED>(a, nblk, 0, p->stream);
+        else if (mode == MODE_ADVANCE) launch_push<OPAL_ION, MODE_ADVANCE>(a, nblk, 0, p->stream);
+        else launch_push<OPAL_ION, MODE_DEPOSIT>(a, nblk, 0, p->stream);
     }
     prof_end(kid, p->stream);
     OPAL_HIP(hipGetLastError());
@@ -969,16 +1038,18 @@ int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
     int k = p->cur;
     u.recv[0] = from_left ? link_recv(link, 0) : nullptr;
     u.recv[1] = from_right ? link_recv(link, 1) : nullptr;
-    u.slot = p->species == OPAL_ELECTRON ? 0 : 1;
+    u.slot = p->species;
+    if (u.slot >= link->nslots) {
+        set_error("this link's messages have no room for species %d (see opal_link_set_layout)", u.slot);
+        return OPAL_ERR_LINK;
+    }
     u.species_off = link_species_offset(link, u.slot);
     u.link_cap = (unsigned)link->cap;
     u.cell = p->d_cell[k];
     u.f[0] = p->d_x[k]; u.f[1] = p->d_ux[k]; u.f[2] = p->d_uy[k]; u.f[3] = p->d_uz[k]; u.f[4] = p->d_w[k];
     u.prev_x = p->prev_valid ? p->d_prev_x : nullptr;
-    u.ex[0] = p->extras ? p->d_chi : nullptr;
-    u.ex[1] = p->d_work;
-    u.ex[2] = p->d_y;
-    u.ex[3] = p->d_z;
+    for (int q = 0; q < NEX; q++) u.ex[q] = p->extras ? p->d_ex[q] : nullptr;
+    u.nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     u.ctr = p->d_ctr;
     u.pop_cap = (unsigned)p->cap;
     u.my_size = (int)g->size;
@@ -1036,17 +1107,13 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     sa.of[0] = p->d_x[o]; sa.of[1] = p->d_ux[o]; sa.of[2] = p->d_uy[o]; sa.of[3] = p->d_uz[o]; sa.of[4] = p->d_w[o];
     sa.prev = d_prev_alt ? p->d_prev_x : nullptr;
     sa.oprev = d_prev_alt;
-    double *ex_alt[4] = {nullptr, nullptr, nullptr, nullptr};
-    double **ex_cur[4] = {&p->d_chi, &p->d_work, &p->d_y, &p->d_z};
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NEX; q++) {
         sa.ex[q] = nullptr;
         sa.oex[q] = nullptr;
-    }
-    if (p->extras && p->d_chi) {
-        for (int q = 0; q < 4; q++) {
-            OPAL_HIP(hipMalloc(&ex_alt[q], sizeof(double) * p->cap));
-            sa.ex[q] = *ex_cur[q];
-            sa.oex[q] = ex_alt[q];
+        if (p->extras && p->d_ex[q]) {
+            if (!p->d_ex_alt[q]) OPAL_HIP(hipMalloc(&p->d_ex_alt[q], sizeof(double) * p->cap));
+            sa.ex[q] = p->d_ex[q];
+            sa.oex[q] = p->d_ex_alt[q];
         }
     }
     k_sort_scatter<<<nblk, 256, 0, p->stream>>>(sa, p->d_ctr, p->d_count);
@@ -1058,12 +1125,8 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
         hipFree(p->d_prev_x);
         p->d_prev_x = d_prev_alt;
     }
-    if (ex_alt[0]) {
-        for (int q = 0; q < 4; q++) {
-            hipFree(*ex_cur[q]);
-            *ex_cur[q] = ex_alt[q];
-        }
-    }
+    for (int q = 0; q < NEX; q++)
+        if (sa.oex[q]) std::swap(p->d_ex[q], p->d_ex_alt[q]);
     p->cur = o;
     p->n_upper = p->h_ctr->n_slots;
     p->steps_since_sort = 0;
@@ -1125,7 +1188,7 @@ extern "C" {
 
 int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_stream)
 {
-    if (!out || (species != OPAL_ELECTRON && species != OPAL_ION)) {
+    if (!out || (species != OPAL_ELECTRON && species != OPAL_ION && species != OPAL_PHOTON)) {
         set_error("opal_pop_create: bad arguments");
         return OPAL_ERR_ARG;
     }
@@ -1165,7 +1228,10 @@ int opal_pop_free(opal_pop_t *p)
     free_set(p, 0);
     if (p->have_alt || p->d_cell[1]) free_set(p, 1);
     if (p->d_prev_x) hipFree(p->d_prev_x);
-    if (p->d_chi) { hipFree(p->d_chi); hipFree(p->d_work); hipFree(p->d_y); hipFree(p->d_z); }
+    for (int q = 0; q < NEX; q++) {
+        if (p->d_ex[q]) hipFree(p->d_ex[q]);
+        if (p->d_ex_alt[q]) hipFree(p->d_ex_alt[q]);
+    }
     if (p->d_count) hipFree(p->d_count);
     hipFree(p->d_partial);
     hipFree(p->d_ctr);
@@ -1211,17 +1277,15 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
         unsigned nb = (unsigned)((n + 255) / 256);
         if (p->species == OPAL_ELECTRON)
             k_init_prev<OPAL_ELECTRON><<<nb, 256, 0, p->stream>>>(p->d_cell[k], p->d_x[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_prev_x, (unsigned)n, dt, dx);
+        else if (p->species == OPAL_PHOTON)
+            k_init_prev<OPAL_PHOTON><<<nb, 256, 0, p->stream>>>(p->d_cell[k], p->d_x[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_prev_x, (unsigned)n, dt, dx);
         else
             k_init_prev<OPAL_ION><<<nb, 256, 0, p->stream>>>(p->d_cell[k], p->d_x[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_prev_x, (unsigned)n, dt, dx);
         p->prev_valid = true;
         OPAL_HIP(hipGetLastError());
     }
-    if (p->extras && n) {
-        OPAL_HIP(hipMemsetAsync(p->d_chi, 0, sizeof(double) * p->cap, p->stream));
-        OPAL_HIP(hipMemsetAsync(p->d_work, 0, sizeof(double) * p->cap, p->stream));
-        OPAL_HIP(hipMemsetAsync(p->d_y, 0, sizeof(double) * p->cap, p->stream));
-        OPAL_HIP(hipMemsetAsync(p->d_z, 0, sizeof(double) * p->cap, p->stream));
-    }
+    if (p->extras && n)
+        if (int rc = reset_extras(p, 0, n)) return rc;
     OPAL_HIP(hipStreamSynchronize(p->stream));
     return OPAL_OK;
 }
@@ -1280,25 +1344,45 @@ int opal_pop_download_soa(const opal_pop_t *p, int32_t *cell, double *x, double 
 int opal_pop_track_extras(opal_pop_t *p, int on)
 {
     if (int rc = check_pop(p)) return rc;
-    if (p->species != OPAL_ELECTRON) return OPAL_OK;
-    if (on && !p->d_chi) {
-        OPAL_HIP(hipMalloc(&p->d_chi, sizeof(double) * p->cap));
-        OPAL_HIP(hipMalloc(&p->d_work, sizeof(double) * p->cap));
-        OPAL_HIP(hipMalloc(&p->d_y, sizeof(double) * p->cap));
-        OPAL_HIP(hipMalloc(&p->d_z, sizeof(double) * p->cap));
-        OPAL_HIP(hipMemsetAsync(p->d_chi, 0, sizeof(double) * p->cap, p->stream));
-        OPAL_HIP(hipMemsetAsync(p->d_work, 0, sizeof(double) * p->cap, p->stream));
-        OPAL_HIP(hipMemsetAsync(p->d_y, 0, sizeof(double) * p->cap, p->stream));
-        OPAL_HIP(hipMemsetAsync(p->d_z, 0, sizeof(double) * p->cap, p->stream));
+    if (p->species == OPAL_ION) return OPAL_OK;  // ion.rs has no chi / y / z; its `work` is not surfaced
+    if (on < 0 || on > 2) {
+        set_error("opal_pop_track_extras: level must be 0, 1 or 2");
+        return OPAL_ERR_ARG;
     }
-    p->extras = on != 0;
+    // which arrays the level needs: electrons chi work y z (+ tau id at level 2), photons chi y z id
+    bool need[NEX] = {false, false, false, false, false, false};
+    if (on) {
+        need[EX_CHI] = need[EX_Y] = need[EX_Z] = true;
+        if (p->species == OPAL_ELECTRON) need[EX_WORK] = true;
+        if (p->species == OPAL_PHOTON) need[EX_ID] = true;
+        if (on == 2 && p->species == OPAL_ELECTRON) need[EX_TAU] = need[EX_ID] = true;
+    }
+    bool fresh[NEX];
+    for (int q = 0; q < NEX; q++) {
+        fresh[q] = need[q] && !p->d_ex[q];
+        if (fresh[q]) OPAL_HIP(hipMalloc(&p->d_ex[q], sizeof(double) * p->cap));
+    }
+    p->extras = on;
+    bool any = false;
+    for (int q = 0; q < NEX; q++) any |= fresh[q];
+    if (any) {
+        // start the new arrays as T::create does for every slot in use (the others keep their values)
+        double *keep[NEX];
+        for (int q = 0; q < NEX; q++) {
+            keep[q] = p->d_ex[q];
+            if (!fresh[q]) p->d_ex[q] = nullptr;
+        }
+        int rc = reset_extras(p, 0, p->cap);
+        for (int q = 0; q < NEX; q++) p->d_ex[q] = keep[q];
+        if (rc) return rc;
+    }
     return OPAL_OK;
 }
 
 int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z)
 {
     if (int rc = check_pop(p)) return rc;
-    if (!p->d_chi) {
+    if (!p->d_ex[EX_CHI]) {
         set_error("opal_pop_download_extras: extras are not tracked");
         return OPAL_ERR_ARG;
     }
@@ -1307,15 +1391,65 @@ int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, dou
     std::vector<int> hc(slots);
     std::vector<double> tmp(slots);
     if (slots) OPAL_HIP(hipMemcpy(hc.data(), p->d_cell[p->cur], sizeof(int) * slots, hipMemcpyDeviceToHost));
-    const double *src[4] = {p->d_chi, p->d_work, p->d_y, p->d_z};
+    const double *src[4] = {p->d_ex[EX_CHI], p->d_ex[EX_WORK], p->d_ex[EX_Y], p->d_ex[EX_Z]};
     double *dst[4] = {chi, work, y, z};
     for (int k = 0; k < 4; k++) {
         if (!dst[k] || !slots) continue;
+        if (!src[k]) {  // a photon has no `work` (photon.rs:207-209)
+            size_t live = 0;
+            for (size_t i = 0; i < slots; i++) live += hc[i] != DEAD_CELL;
+            std::fill(dst[k], dst[k] + live, 0.0);
+            continue;
+        }
         OPAL_HIP(hipMemcpy(tmp.data(), src[k], sizeof(double) * slots, hipMemcpyDeviceToHost));
         size_t o = 0;
         for (size_t i = 0; i < slots; i++)
             if (hc[i] != DEAD_CELL) dst[k][o++] = tmp[i];
     }
+    return OPAL_OK;
+}
+
+// Optical depths against emission and the ids that key the emission random numbers, in slot order
+// (dead slots skipped), for electrons tracked at level 2; for photons `id` is the parent electron's.
+int opal_pop_download_emission_state(const opal_pop_t *p, double *tau, uint64_t *id)
+{
+    if (int rc = check_pop(p)) return rc;
+    if ((tau && !p->d_ex[EX_TAU]) || (id && !p->d_ex[EX_ID])) {
+        set_error("opal_pop_download_emission_state: not tracked (opal_pop_track_extras level 2 for electrons, >= 1 for photons)");
+        return OPAL_ERR_ARG;
+    }
+    if (int rc = fetch_counters(p)) return rc;
+    size_t slots = p->h_ctr->n_slots;
+    if (!slots) return OPAL_OK;
+    std::vector<int> hc(slots);
+    std::vector<double> tmp(slots);
+    OPAL_HIP(hipMemcpy(hc.data(), p->d_cell[p->cur], sizeof(int) * slots, hipMemcpyDeviceToHost));
+    if (tau) {
+        OPAL_HIP(hipMemcpy(tmp.data(), p->d_ex[EX_TAU], sizeof(double) * slots, hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (size_t i = 0; i < slots; i++)
+            if (hc[i] != DEAD_CELL) tau[o++] = tmp[i];
+    }
+    if (id) {
+        OPAL_HIP(hipMemcpy(tmp.data(), p->d_ex[EX_ID], sizeof(double) * slots, hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (size_t i = 0; i < slots; i++)
+            if (hc[i] != DEAD_CELL) memcpy(&id[o++], &tmp[i], sizeof(uint64_t));
+    }
+    return OPAL_OK;
+}
+
+// Overwrites them for the first n slots (as uploaded: call right after opal_pop_upload_soa).
+int opal_pop_upload_emission_state(opal_pop_t *p, size_t n, const double *tau, const uint64_t *id)
+{
+    if (int rc = check_pop(p)) return rc;
+    if ((tau && !p->d_ex[EX_TAU]) || (id && !p->d_ex[EX_ID]) || n > p->cap) {
+        set_error("opal_pop_upload_emission_state: not tracked (opal_pop_track_extras level 2), or n exceeds the capacity");
+        return OPAL_ERR_ARG;
+    }
+    if (tau) OPAL_HIP(hipMemcpyAsync(p->d_ex[EX_TAU], tau, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    if (id) OPAL_HIP(hipMemcpyAsync(p->d_ex[EX_ID], id, sizeof(uint64_t) * n, hipMemcpyHostToDevice, p->stream));
+    OPAL_HIP(hipStreamSynchronize(p->stream));
     return OPAL_OK;
 }
 
@@ -1404,6 +1538,8 @@ int opal_pop_total_kinetic_energy(const opal_pop_t *p, double *energy)
     int nblk = (int)std::min<size_t>((p->n_upper + BLOCK - 1) / BLOCK, p->partial_cap);
     if (p->species == OPAL_ELECTRON)
         k_kinetic<OPAL_ELECTRON><<<nblk, BLOCK, 0, p->stream>>>(p->d_cell[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_w[k], p->d_ctr, p->a, p->d_partial);
+    else if (p->species == OPAL_PHOTON)
+        k_kinetic<OPAL_PHOTON><<<nblk, BLOCK, 0, p->stream>>>(p->d_cell[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_w[k], p->d_ctr, p->a, p->d_partial);
     else
         k_kinetic<OPAL_ION><<<nblk, BLOCK, 0, p->stream>>>(p->d_cell[k], p->d_ux[k], p->d_uy[k], p->d_uz[k], p->d_w[k], p->d_ctr, p->a, p->d_partial);
     k_fold<<<1, BLOCK, 0, p->stream>>>(p->d_partial, nblk, p->d_partial + p->partial_cap);
@@ -1432,6 +1568,13 @@ int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t 
     return run_push_pair(pe, pi, link, g, dt);
 }
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
+// room for `extra` more particles behind the slots in use
+int pop_reserve(opal_pop_t *p, size_t extra)
+{
+    if (p->n_upper + extra <= p->cap) return OPAL_OK;
+    size_t want = p->n_upper + extra;
+    return grow(p, want + want / 2);
+}
 int pop_unpack_and_maybe_sort(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
 {
     if (int rc = unpack_arrivals(p, link, g)) return rc;

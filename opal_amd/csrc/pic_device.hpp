@@ -32,6 +32,7 @@ struct V3 {
     double x, y, z;
 };
 __host__ __device__ inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__host__ __device__ inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __host__ __device__ inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __host__ __device__ inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __host__ __device__ inline V3 cross(V3 a, V3 b)
@@ -165,7 +166,7 @@ struct Pushed {
     double inv_gamma;  // 1 / gamma, shared by the displacement and the deposit's velocity
     double dxi;
     // electron diagnostics (only meaningful when requested)
-    double chi, dwork;
+    double chi, dwork, gamma_half;
     V3 v_old;
 };
 
@@ -198,6 +199,7 @@ __device__ inline Pushed vay_push(V3 u, V3 E, V3 B, double alpha, double dt_over
         V3 w = gamma_half * E + SPEED_OF_LIGHT * cross(u_half, B);
         double eu = dot(E, u_half);
         r.chi = sqrt(dot(w, w) - eu * eu) / CRITICAL_FIELD;
+        r.gamma_half = gamma_half;
         r.v_old = v;
     }
     V3 u_prime = u_half + alpha * E;
@@ -216,6 +218,26 @@ __device__ inline Pushed vay_push(V3 u, V3 E, V3 B, double alpha, double dt_over
     r.gamma = gamma;
     r.inv_gamma = inv_gn;
     r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx * inv_gn;
+    return r;
+}
+
+// Photon::push, photon.rs:150-183: ballistic, with the quantum parameter of the local field.
+template <bool EXTRAS>
+__device__ inline Pushed photon_push(V3 k, V3 E, V3 B, double dt_over_dx)
+{
+    Pushed r;
+    double k0 = sqrt(dot(k, k));
+    V3 v = (SPEED_OF_LIGHT / k0) * k;
+    if (EXTRAS) {
+        V3 w = k0 * E + SPEED_OF_LIGHT * cross(k, B);
+        double ek = dot(E, k);
+        r.chi = sqrt(dot(w, w) - ek * ek) / CRITICAL_FIELD;
+        r.v_old = v;
+    }
+    r.u = k;
+    r.gamma = k0;
+    r.inv_gamma = 1.0 / k0;
+    r.dxi = v.x * dt_over_dx;
     return r;
 }
 

@@ -1,5 +1,5 @@
-// The YAML-driven driver: main() of the reference (src/main.rs:48-286) for the
-// hot-path configurations (no QED), written against this library's own C ABI
+// The YAML-driven driver: main() of the reference (src/main.rs:48-286), photon
+// emission included (absorption is out of scope), written against this library's own C ABI
 // exactly as a Rust host would call it.  Also the C-ABI wrappers of the
 // host-side pieces (GridDesign, loader, Config).
 #include <hip/hip_runtime_api.h>
@@ -147,9 +147,14 @@ struct opal_sim {
     bool current_deposition = false, balance = true, has_laser = false;
     std::function<double(const double *)> laser_y, laser_z;
     opal_grid_t *grid = nullptr;
-    opal_pop_t *electrons = nullptr, *ions = nullptr;
+    opal_pop_t *electrons = nullptr, *ions = nullptr, *photons = nullptr;
     std::string ion_name;
-    std::vector<std::string> electron_output, ion_output;  // the `output:` lists (main.rs:117,134)
+    std::vector<std::string> electron_output, ion_output, photon_output;  // the `output:` lists (main.rs:117,134,156)
+    // qed section (main.rs:78-83); limits < 0 = None
+    bool photon_emission = false;
+    double photon_energy_min = -1.0, photon_angle_max = -1.0, max_formation_length = -1.0;
+    uint64_t emission_seed = 0;
+    size_t step_index = 0;
     double t = 0;
     size_t total_steps = 0, steps_bt_output = 0;
     bool fused = true;
@@ -184,8 +189,15 @@ int load_species(opal_sim_t *s, const char *section, const char *density_key, in
     // headroom for arrivals from neighbouring subdomains between two re-binnings
     size_t cap = soa.size() + soa.size() / 8 + 65536;
     if (int rc = opal_pop_create(out, species, cap, s->stream)) return rc;
-    return opal_pop_upload_soa(*out, soa.size(), soa.cell.data(), soa.x.data(), soa.ux.data(), soa.uy.data(),
-                               soa.uz.data(), soa.w.data(), s->dx, s->dt);
+    (*out)->id_base = (unsigned long long)s->rank << 40;  // ids unique across subdomains
+    if (s->photon_emission && species != OPAL_ION)
+        if (int rc = opal_pop_track_extras(*out, species == OPAL_ELECTRON ? 2 : 1)) return rc;
+    if (int rc = opal_pop_upload_soa(*out, soa.size(), soa.cell.data(), soa.x.data(), soa.ux.data(), soa.uy.data(),
+                                     soa.uz.data(), soa.w.data(), s->dx, s->dt))
+        return rc;
+    if (s->photon_emission && species == OPAL_ELECTRON)  // Population::new ... .with_optical_depths(rng), mod.rs:193
+        return opal_pop_upload_emission_state(*out, soa.size(), soa.tau.data(), nullptr);
+    return OPAL_OK;
 }
 
 // main.rs:63-187
@@ -203,12 +215,19 @@ int sim_setup(opal_sim_t *s)
     if (!in.read_bool("control", "current_deposition", s->current_deposition, ce)) return config_fail(ce);
     if (!in.read_usize("control", "n_outputs", s->n_outputs, ce)) return config_fail(ce);
     if (!in.read_bool("control", "balance", s->balance, ce)) s->balance = true;  // main.rs:76
-    bool photon_emission, photon_absorption;
-    if (!in.read_bool("qed", "photon_emission", photon_emission, ce)) return config_fail(ce);
+    bool photon_absorption;
+    if (!in.read_bool("qed", "photon_emission", s->photon_emission, ce)) return config_fail(ce);
     if (!in.read_bool("qed", "photon_absorption", photon_absorption, ce)) return config_fail(ce);
-    if (photon_emission || photon_absorption) {
-        set_error("qed.photon_emission / photon_absorption are outside this build's hot-path scope (SURVEY.md 8f)");
+    if (photon_absorption) {
+        set_error("qed.photon_absorption is outside this build's scope (SURVEY.md 8f-4)");
         return OPAL_ERR_CONFIG;
+    }
+    {  // main.rs:80-83: all optional
+        ConfigError ignored;
+        double v;
+        if (in.read_f64("qed", "max_formation_length", v, ignored)) s->max_formation_length = v;
+        if (in.read_f64("qed", "photon_energy_min", v, ignored)) s->photon_energy_min = 1.0e-6 * v / 1.602177e-19;  // J -> MeV
+        if (in.read_f64("qed", "photon_angle_max", v, ignored)) s->photon_angle_max = v;
     }
     // main.rs:89-101
     ConfigError ly_err, lz_err;
@@ -260,6 +279,21 @@ int sim_setup(opal_sim_t *s)
         if (int rc = load_species(s, "ions", "ni", OPAL_ION, ipc, rng, &s->ions)) return rc;
         if (int rc = opal_pop_set_charge_state(s->ions, z, z, a)) return rc;  // main.rs:142-147
     }
+    if (s->photon_emission) {  // main.rs:153-170
+        size_t ppc;
+        if (!in.read_usize("photons", "npc", ppc, ce)) return config_fail(ce);
+        if (!in.read_strings("photons", "output", s->photon_output, ce)) return config_fail(ce);
+        if (ppc > 0) {
+            if (int rc = load_species(s, "photons", "nph", OPAL_PHOTON, ppc, rng, &s->photons)) return rc;
+        } else {
+            if (int rc = opal_pop_create(&s->photons, OPAL_PHOTON, 1 << 20, s->stream)) return rc;
+            if (int rc = opal_pop_track_extras(s->photons, 1)) return rc;
+        }
+        // The reference goes on drawing from the generator the loader used (seeded with the rank,
+        // main.rs:53); the build's counter-based generator takes one key for the whole run, so that a
+        // particle's draws do not depend on which subdomain it is in.
+        s->emission_seed = 0x6f70616c5f616d64ull;
+    }
     s->t = s->tstart;
     s->total_steps = (size_t)((s->tend - s->tstart) / s->dt);  // main.rs:186 (`as usize` truncates)
     s->steps_bt_output = s->n_outputs ? s->total_steps / s->n_outputs : 0;
@@ -269,8 +303,10 @@ int sim_setup(opal_sim_t *s)
 // main.rs:23-42
 int write_energies(opal_sim_t *s, size_t index)
 {
-    double f, e, i;
+    double f, e, i, ph = 0.0;
     if (int rc = opal_sim_energies(s, &f, &e, &i)) return rc;
+    if (s->photons)
+        if (int rc = opal_pop_total_kinetic_energy(s->photons, &ph)) return rc;
     if (s->rank != 0) return OPAL_OK;
     std::string fn = s->output_dir + "/" + std::to_string(index) + "_energy.dat";
     FILE *fp = fopen(fn.c_str(), "w");
@@ -281,7 +317,7 @@ int write_energies(opal_sim_t *s, size_t index)
     fprintf(fp, "em_field %s\n", rust_lower_exp_prec(f, 6).c_str());
     fprintf(fp, "electrons %s\n", rust_lower_exp_prec(e, 6).c_str());
     fprintf(fp, "ions %s\n", rust_lower_exp_prec(i, 6).c_str());
-    fprintf(fp, "photons %s\n", rust_lower_exp_prec(0.0, 6).c_str());
+    fprintf(fp, "photons %s\n", rust_lower_exp_prec(ph, 6).c_str());
     fclose(fp);
     return OPAL_OK;
 }
@@ -457,6 +493,7 @@ int opal_sim_free(opal_sim_t *s)
     if (!s) return OPAL_OK;
     opal_pop_free(s->electrons);
     opal_pop_free(s->ions);
+    opal_pop_free(s->photons);
     opal_grid_free(s->grid);
     delete s;
     return OPAL_OK;
@@ -476,7 +513,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         return OPAL_ERR_ARG;
     }
     for (size_t k = 0; k < n; k++) {
-        if (linked && s->fused && s->current_deposition) {
+        if (linked && s->fused && s->current_deposition && !s->photon_emission) {
             // One exchange per step: leavers of both species and the halo travel in the same message.
             // Leavers have already deposited into this subdomain's ghost cells, which the halo overlay
             // hands to the neighbour (yee.rs:424-452), so migration need not precede deposition.
@@ -509,9 +546,13 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 if (int rc = pop_unpack_and_maybe_sort(s->ions, s->link, g)) return rc;
             if (int rc = opal_grid_advance(g, s->dt)) return rc;
             s->t += s->dt;
+            s->step_index++;
             continue;
         }
-        if (s->fused && s->current_deposition) {
+        // With photon emission on, the reference's order is advance -> emit -> deposit (main.rs:240-258) and
+        // the deposit's transverse currents use the velocity after the recoil, so the fused push+deposit
+        // pass does not apply: the separate operators run in the reference's order.
+        if (s->fused && s->current_deposition && !s->photon_emission) {
             // clear first, then one pass per species that pushes and deposits
             if (int rc = opal_grid_clear(s->grid)) return rc;
             if (s->electrons && s->ions && !linked) {
@@ -530,6 +571,15 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) return rc;
             if (s->ions)
                 if (int rc = opal_pop_advance(s->ions, s->link, s->grid, s->dt)) return rc;
+            if (s->photon_emission) {
+                if (s->photons)
+                    if (int rc = opal_pop_advance(s->photons, s->link, s->grid, s->dt)) return rc;  // main.rs:242-244
+                if (s->electrons)  // main.rs:250-252
+                    if (int rc = opal_emit_radiation(s->electrons, s->photons, s->emission_seed, (uint32_t)s->step_index,
+                                                     s->t, s->photon_energy_min, s->photon_angle_max,
+                                                     s->max_formation_length, nullptr))
+                        return rc;
+            }
             if (s->current_deposition) {
                 if (int rc = opal_grid_clear(s->grid)) return rc;
                 if (s->electrons)
@@ -538,6 +588,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                     if (int rc = opal_grid_deposit(s->grid, s->ions, s->dt)) return rc;
             }
         }
+        s->step_index++;
         if (s->has_laser) {
             if (int rc = opal_grid_synchronize(s->grid, s->link, laser_y_cb, laser_z_cb, &lp, s->t, s->dt)) return rc;
         } else {
@@ -560,6 +611,8 @@ int opal_sim_sync(opal_sim_t *s)
         if (int rc = pop_check_err(s->electrons)) return rc;
     if (s->ions)
         if (int rc = pop_check_err(s->ions)) return rc;
+    if (s->photons)
+        if (int rc = pop_check_err(s->photons)) return rc;
     return OPAL_OK;
 }
 
@@ -600,7 +653,8 @@ int opal_sim_run(opal_sim_t *s)
             return opal_pop_write_data(p, s->grid, s->output_dir.c_str(), i, name.c_str(), cs.data(), cs.size());
         };
         if (int rc = one(s->electrons, "electron", s->electron_output)) return rc;
-        return one(s->ions, s->ion_name, s->ion_output);
+        if (int rc = one(s->ions, s->ion_name, s->ion_output)) return rc;
+        return one(s->photons, "photon", s->photon_output);
     };
     for (size_t i = 0; i < s->n_outputs; i++) {
         if (int rc = opal_grid_write_data(s->grid, s->output_dir.c_str(), i)) return rc;
@@ -626,6 +680,7 @@ size_t opal_sim_n_outputs(const opal_sim_t *s) { return s ? s->n_outputs : 0; }
 opal_grid_t *opal_sim_grid(opal_sim_t *s) { return s ? s->grid : nullptr; }
 opal_pop_t *opal_sim_electrons(opal_sim_t *s) { return s ? s->electrons : nullptr; }
 opal_pop_t *opal_sim_ions(opal_sim_t *s) { return s ? s->ions : nullptr; }
+opal_pop_t *opal_sim_photons(opal_sim_t *s) { return s ? s->photons : nullptr; }
 int opal_sim_set_fused(opal_sim_t *s, int fused)
 {
     if (!s) return OPAL_ERR_ARG;
