@@ -1447,6 +1447,7 @@ int opal_pop_upload_emission_state(opal_pop_t *p, size_t n, const double *tau, c
         set_error("opal_pop_upload_emission_state: not tracked (opal_pop_track_extras level 2), or n exceeds the capacity");
         return OPAL_ERR_ARG;
     }
+    if (!n) return OPAL_OK;
     if (tau) OPAL_HIP(hipMemcpyAsync(p->d_ex[EX_TAU], tau, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
     if (id) OPAL_HIP(hipMemcpyAsync(p->d_ex[EX_ID], id, sizeof(uint64_t) * n, hipMemcpyHostToDevice, p->stream));
     OPAL_HIP(hipStreamSynchronize(p->stream));

@@ -512,6 +512,11 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         set_error("%d subdomains need a link", s->numtasks);
         return OPAL_ERR_ARG;
     }
+    if (linked && s->photon_emission && (s->link->nslots < 3 || s->link->nfields < 12)) {
+        set_error("photon emission across subdomains needs a link created with 3 species slots and 12 fields per "
+                  "particle (opal_link_create_layout): optical depths, ids and photons migrate too");
+        return OPAL_ERR_LINK;
+    }
     for (size_t k = 0; k < n; k++) {
         if (linked && s->fused && s->current_deposition && !s->photon_emission) {
             // One exchange per step: leavers of both species and the halo travel in the same message.

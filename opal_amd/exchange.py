@@ -56,16 +56,20 @@ class TorchLink:
     device: torch.device("cuda", i) with the nccl (= RCCL) backend moves device buffers, stream-ordered
     with torch's current stream (which must be the stream the simulation was created on);
     torch.device("cpu") stages through host buffers (gloo), for rehearsals on one GPU.
+    photon_emission=True lays the messages out for three species with their extras (see link.cpp).
     """
 
-    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None):
+    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False):
         self._lib = _lib.load()
         self.transport = NeighbourTransport(rank, world, group)
         self.device = torch.device(device)
         device_buffers = 1 if self.device.type == "cuda" else 0
         self._cb = _lib.EXCHANGE_FN(self._exchange)  # keep alive
         h = C.c_void_p()
-        rc = self._lib.opal_link_create(C.byref(h), rank, world, device_buffers, particle_capacity, self._cb, None, stream)
+        # runs with photon emission move a third species and the electrons' optical depths and ids
+        slots, fields = (3, 12) if photon_emission else (2, 6)
+        rc = self._lib.opal_link_create_layout(C.byref(h), rank, world, device_buffers, particle_capacity, slots, fields,
+                                               self._cb, None, stream)
         if rc:
             raise RuntimeError(self._lib.opal_last_error().decode())
         self.h = h

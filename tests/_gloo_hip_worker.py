@@ -49,6 +49,54 @@ ions:
 """
 
 
+# colliding_beams.yaml's physics on a 20 um domain cut into subdomains, plus a seeded photon population
+# that straddles the cut and flies both ways (so that photons migrate too)
+QED_YAML = """---
+control:
+ dx: 0.01*micro
+ nx: 2000
+ xmin: -10*micro
+ start: -16.0e-6/c
+ end: -2.0e-6/c
+ current_deposition: false
+ n_outputs: 2
+ balance: false
+qed:
+ photon_emission: true
+ photon_absorption: false
+ photon_angle_max: 50 * milli
+electrons:
+ npc: 10
+ ne: S * a0 * critical(omega) * step(x,xmin,xmax)
+ ux: -1000.0 * (1.0 + 0.01 * nrand)
+ uy: 0.0
+ uz: 0.0
+ output: [x]
+ions:
+ npc: 0
+photons:
+ npc: 4
+ nph: 1.0e20 * step(x, -0.5*micro, 0.5*micro)
+ ux: 10.0 * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: nrand
+ uz: 0.0
+ output: [x]
+laser:
+ Ey: >
+  (a0*m*c*omega/e)
+  *sin(omega*(t-x/c))
+  *exp(-ln(2.0)*(omega*(t-x/c))^2/(2.0*pi^2*ncycles^2))
+ Ez: 0.0
+constants:
+ S: 1.0e-6
+ a0: 20.0
+ omega: 2*pi*c/0.8e-6
+ ncycles: 4.0
+ xmin: (4 - 0.5) * micro
+ xmax: (4 + 0.5) * micro
+"""
+
+
 def dump(outdir, rank, g, pe, pi, extra=None):
     out = {k: g.raw(k) for k in ("Ex", "Ey", "Ez", "By", "Bz", "jx", "jy", "jz", "rho")}
     for name, p in (("e", pe), ("i", pi)):
@@ -68,7 +116,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     oa.set_device(0)
-    link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=128) if world > 1 else None
+    link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=128 if mode != "qed" else 1024,
+                     photon_emission=mode == "qed") if world > 1 else None
     dx = 1.0e-8
     dt = 0.95 * dx / C
     if mode == "grow":
@@ -94,6 +143,32 @@ def main():
             g.advance(dt)
             t += dt
         dump(outdir, rank, g, pe, pi)
+    elif mode == "qed":
+        sim = oa.Simulation(yaml_text=QED_YAML, rank=rank, numtasks=world, link=link)
+        out = {}
+        tau, ids = sim.electrons.emission_state()
+        for k, v in sim.electrons.soa().items():
+            out[f"init_e_{k}"] = v
+        out["init_e_tau"], out["init_e_id"] = tau, ids
+        for k, v in sim.photons.soa().items():
+            out[f"init_ph_{k}"] = v
+        nsteps = sim.total_steps if steps <= 0 else steps
+        sim.step(nsteps)
+        sim.sync()
+        tau, ids = sim.electrons.emission_state()
+        for k, v in sim.electrons.soa().items():
+            out[f"e_{k}"] = v
+        out["e_tau"], out["e_id"] = tau, ids
+        for k, v in sim.photons.soa().items():
+            out[f"ph_{k}"] = v
+        out["ph_id"] = sim.photons.emission_state()[1]
+        out["nsteps"] = nsteps
+        out["ke_e"] = sim.electrons.total_kinetic_energy()
+        out["ke_ph"] = sim.photons.total_kinetic_energy()
+        out["fe"] = sim.grid.em_field_energy()
+        out["Ey"] = sim.grid.raw("Ey")
+        out["t"] = sim.t
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     elif mode == "ops":
         nxs, offs = oa.design_unbalanced(world, nx, dx)
         g = oa.Grid(rank, world, oa.BDY_INTERNAL, oa.BDY_INTERNAL, 0.0, dx, nxs, offs)

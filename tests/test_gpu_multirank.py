@@ -119,3 +119,64 @@ def test_receiving_subdomain_grows_its_storage(oracle, tmp_path):
         # (electrons and the unit-charge ions move together here, so the fields are pure round-off
         # noise and not compared)
         assert len(a["x"]) == 0 or np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_photon_emission_across_subdomains(oracle, tmp_path, world):
+    """Config C5's physics decomposed: electrons carry their optical depths and ids across the cuts, photons
+    (emitted and pre-loaded) migrate and leave through the open ends; against the oracle with the same
+    decomposition, started from the driver's own initial state."""
+    import opal_amd as oa
+    o = oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _gloo_hip_worker import QED_YAML
+    _launch("_gloo_hip_worker.py", world, ["qed", tmp_path, 0, 0, 0, 0])
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    cfgp = tmp_path / "cb.yaml"
+    cfgp.write_text(QED_YAML)
+    cfg = oa.Config(path=cfgp)
+    ly = cfg.func("laser", "Ey", ["t", "x"])
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    nx = 2000
+    nxs, offs = o.design_unbalanced(world, nx, dx)
+    grids = [o.Grid(r, world, o.BDY_LASER, o.BDY_ABSORBING, -10e-6, dx, nxs, offs) for r in range(world)]
+    pes, phs = [], []
+    for r in range(world):
+        g = got[r]
+        pe = o.Population.from_soa(o.ELECTRON, *[g[f"init_e_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")], dx, dt)
+        pe.set_electron_state(tau=g["init_e_tau"], ids=g["init_e_id"])
+        pes.append(pe)
+        phs.append(o.Population.from_soa(2, *[g[f"init_ph_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")], dx, dt))
+    assert sum(len(p) for p in pes) == 100 * 10 and sum(len(p) for p in phs) == 100 * 4
+    assert len(np.unique(np.concatenate([g["init_e_id"] for g in got]))) == 1000  # ids unique across subdomains
+    nsteps = int(got[0]["nsteps"])
+    seed = 0x6f70616c5f616d64
+    t = -16.0e-6 / C
+    for k in range(nsteps):
+        assert o.world_pop_advance(pes, grids, dt) == 0
+        assert o.world_pop_advance(phs, grids, dt) == 0
+        for r in range(world):
+            o.emit_radiation(pes[r], phs[r], seed, k, t, max_angle=0.05)
+        o.world_synchronize(grids, ly, None, t, dt)
+        for g in grids:
+            g.advance(dt)
+        t += dt
+    assert abs(float(got[0]["t"]) - t) <= 1e-12 * abs(t)
+    n_ph = sum(len(p) for p in phs)
+    assert n_ph > 1000                       # emission happened, and the pre-loaded photons have left or moved on
+    # the beam ended up in the leftmost subdomain (its head has already left through the open end)
+    assert 100 < len(pes[0]) <= 1000 and all(len(p) == 0 for p in pes[1:])
+    for r in range(world):
+        assert len(got[r]["e_w"]) == len(pes[r]), r
+        assert abs(len(got[r]["ph_w"]) - len(phs[r])) <= max(2, 0.002 * len(phs[r])), r
+        ref = grids[r].raw("Ey")
+        assert np.max(np.abs(got[r]["Ey"] - ref)) <= 1e-9 * max(np.max(np.abs(ref)), 1.0)
+        if len(pes[r]):
+            ia, ib = np.argsort(got[r]["e_id"]), np.argsort(pes[r].electron_ids())
+            assert np.array_equal(got[r]["e_id"][ia], pes[r].electron_ids()[ib])
+            same = np.abs(got[r]["e_ux"][ia] / pes[r].soa()["ux"][ib] - 1.0) < 1e-6
+            assert same.mean() > 0.99
+            assert abs(got[r]["ke_e"] - pes[r].total_kinetic_energy()) / pes[r].total_kinetic_energy() < 5e-4
+        if len(phs[r]):
+            assert abs(got[r]["ke_ph"] - phs[r].total_kinetic_energy()) / phs[r].total_kinetic_energy() < 5e-4
