@@ -163,6 +163,13 @@ int opal_pop_counters(const opal_pop_t *p, uint32_t *out);
 /* level 1: carry chi, work, y, z for electrons (electron.rs:18-25) / chi, y, z, parent id for photons;
  * level 2 (electrons): also the optical depth and id that photon emission needs; 0 = off (default) */
 int opal_pop_track_extras(opal_pop_t *p, int on);
+/* the same by field, so that a run carries only what its outputs read (each costs 8-16 B of HBM traffic per
+ * particle-update): OPAL_TRACK_EMISSION = optical depth + id (+ chi), OPAL_TRACK_ID = a photon's parent id */
+enum { OPAL_TRACK_CHI = 1, OPAL_TRACK_WORK = 2, OPAL_TRACK_YZ = 4, OPAL_TRACK_EMISSION = 8, OPAL_TRACK_ID = 16 };
+int opal_pop_track_fields(opal_pop_t *p, unsigned fields);
+/* opal_pop_advance stores prev_x for a later opal_grid_deposit (default); 0 = the caller never deposits this
+ * population (photons; any species when current_deposition is off), so the 8 B per update are saved */
+int opal_pop_keep_prev_x(opal_pop_t *p, int on);
 int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z);
 /* Optical depth against emission (electron.rs:24) and the id that keys the emission random numbers, for
  * electrons tracked at level 2; for photons (level >= 1) `id` is the parent electron's.  Slot order. */

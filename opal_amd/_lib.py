@@ -66,6 +66,8 @@ SIGNATURES = {
     "opal_pop_set_sort_interval": (C.c_int, [vp, C.c_int]),
     "opal_pop_counters": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "opal_pop_track_extras": (C.c_int, [vp, C.c_int]),
+    "opal_pop_track_fields": (C.c_int, [vp, C.c_uint]),
+    "opal_pop_keep_prev_x": (C.c_int, [vp, C.c_int]),
     "opal_pop_download_extras": (C.c_int, [vp, vp, vp, vp, vp]),
     "opal_pop_download_emission_state": (C.c_int, [vp, vp, vp]),
     "opal_pop_upload_emission_state": (C.c_int, [vp, sz, vp, vp]),

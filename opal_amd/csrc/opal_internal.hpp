@@ -78,12 +78,15 @@ struct opal_pop {
     int cur;
     double *d_prev_x;               // allocated on first unfused advance
     bool prev_valid;
+    bool keep_prev;                 // store prev_x in the unfused advance (only a later deposit reads it)
     // optional per-particle extras, any of which may be absent (null):
     //   electrons  chi work y z (diagnostics, level 1)  + tau id (photon emission, level 2)
     //   photons    chi y z id
     // id is a 64-bit integer kept in a double's bits (only ever copied).
     double *d_ex[opal::NEX];
     double *d_ex_alt[opal::NEX];  // re-binning targets, allocated on first use
+    unsigned int *d_emit_list;    // slots of this step's emitters (photon emission), emit_list_cap entries
+    size_t emit_list_cap;
     unsigned long long id_base;   // ids of freshly uploaded particles are id_base + slot (set per subdomain)
     int extras;  // 0 off, 1 diagnostics, 2 + optical depth / id for photon emission
     double z_star, z, a;

@@ -189,19 +189,24 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             r = vay_push<EXTRAS != 0>(u, E, B, a.alpha, a.dt_over_dx, a.dt);
             if (EXTRAS) {
                 size_t i = cp.chunk0 + kc;
-                a.ex[EX_CHI][i] = r.chi;
-                a.ex[EX_WORK][i] += r.dwork;
-                a.ex[EX_Y][i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
-                a.ex[EX_Z][i] += r.v_old.z * a.dt;
+                // each array is optional (block-uniform tests): a run only carries what its outputs ask for
+                if (a.ex[EX_CHI]) a.ex[EX_CHI][i] = r.chi;
+                if (a.ex[EX_WORK]) a.ex[EX_WORK][i] += r.dwork;
+                if (a.ex[EX_Y]) {
+                    a.ex[EX_Y][i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
+                    a.ex[EX_Z][i] += r.v_old.z * a.dt;
+                }
                 if (EXTRAS == 2) a.ex[EX_TAU][i] -= qed_rate(r.chi, r.gamma_half) * a.dt;  // electron.rs:284-288
             }
         } else if (SPECIES == OPAL_PHOTON) {
             r = photon_push<EXTRAS != 0>(u, E, B, a.dt_over_dx);
             if (EXTRAS) {
                 size_t i = cp.chunk0 + kc;
-                a.ex[EX_CHI][i] = r.chi;
-                a.ex[EX_Y][i] += r.v_old.y * a.dt;  // photon.rs:166-167
-                a.ex[EX_Z][i] += r.v_old.z * a.dt;
+                if (a.ex[EX_CHI]) a.ex[EX_CHI][i] = r.chi;
+                if (a.ex[EX_Y]) {
+                    a.ex[EX_Y][i] += r.v_old.y * a.dt;  // photon.rs:166-167
+                    a.ex[EX_Z][i] += r.v_old.z * a.dt;
+                }
             }
         } else {
             r = boris_push(u, E, B, a.alpha, a.dt_over_dx);
@@ -264,8 +269,8 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                 f[2 * (size_t)a.send_cap + slot] = u.y;
                 f[3 * (size_t)a.send_cap + slot] = u.z;
                 f[4 * (size_t)a.send_cap + slot] = wt;
-                if (MODE == MODE_ADVANCE) f[5 * (size_t)a.send_cap + slot] = prev;
-                if (EXTRAS && a.send_nextra) {
+                if (MODE == MODE_ADVANCE && cp.prev) f[5 * (size_t)a.send_cap + slot] = prev;
+                if (a.send_nextra) {
                     // a link laid out for photon emission carries the extras too (the reference ships the
                     // whole struct, mod.rs:308-354); values as updated by this push
                     size_t i = cp.chunk0 + kc;
@@ -285,7 +290,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                 stk(cp.uy, kc, u.y);
                 stk(cp.uz, kc, u.z);
             }
-            if (MODE == MODE_ADVANCE) stk(cp.prev, kc, prev);
+            if (MODE == MODE_ADVANCE && cp.prev) stk(cp.prev, kc, prev);  // only kept for a later separate deposit
         }
     }
 }
@@ -311,7 +316,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     cp.cell = a.cell + chunk0;
     cp.x = a.x + chunk0; cp.ux = a.ux + chunk0; cp.uy = a.uy + chunk0; cp.uz = a.uz + chunk0;
     cp.w = a.w + chunk0;
-    cp.prev = (MODE != MODE_FUSED) ? a.prev_x + chunk0 : nullptr;
+    cp.prev = (MODE != MODE_FUSED && a.prev_x) ? a.prev_x + chunk0 : nullptr;
     cp.chunk0 = chunk0;
     const unsigned nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
 
@@ -923,7 +928,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     memset(&a, 0, sizeof a);
     int k = p->cur;
     a.cell = p->d_cell[k]; a.x = p->d_x[k]; a.ux = p->d_ux[k]; a.uy = p->d_uy[k]; a.uz = p->d_uz[k]; a.w = p->d_w[k];
-    a.prev_x = p->d_prev_x;
+    a.prev_x = (mode == MODE_ADVANCE && !p->keep_prev) ? nullptr : p->d_prev_x;
     for (int q = 0; q < NEX; q++) a.ex[q] = p->extras ? p->d_ex[q] : nullptr;
     a.eb = g->d_eb[g->cur];
     a.jr = g->j();
@@ -976,7 +981,8 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     if (int rc = build_args(p, link, g, dt, mode, a, nblk)) return rc;
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, p->stream);
-    int ex = p->extras;
+    // which variant of the kernel: 2 runs down the optical depth, 1 touches chi / work / y / z, 0 neither
+    int ex = !p->extras ? 0 : p->d_ex[EX_TAU] ? 2 : (p->d_ex[EX_CHI] || p->d_ex[EX_WORK] || p->d_ex[EX_Y]) ? 1 : 0;
     if (p->species == OPAL_ELECTRON) {
         if (mode == MODE_FUSED) launch_push<OPAL_ELECTRON, MODE_FUSED>(a, nblk, ex, p->stream);
         else if (mode == MODE_ADVANCE) launch_push<OPAL_ELECTRON, MODE_ADVANCE>(a, nblk, ex, p->stream);
@@ -1208,6 +1214,7 @@ int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_st
     p->stream = (hipStream_t)hip_stream;
     p->z_star = p->z = p->a = 1.0;  // ion.rs:93-95
     p->sort_interval = -1;
+    p->keep_prev = true;
     p->ppt = 8;
     if (const char *e = getenv("OPAL_DEBUG_PPT")) p->ppt = std::max(1, std::min(32, atoi(e)));
     if (int rc = alloc_set(p, 0)) return rc;
@@ -1233,6 +1240,7 @@ int opal_pop_free(opal_pop_t *p)
         if (p->d_ex_alt[q]) hipFree(p->d_ex_alt[q]);
     }
     if (p->d_count) hipFree(p->d_count);
+    if (p->d_emit_list) hipFree(p->d_emit_list);
     hipFree(p->d_partial);
     hipFree(p->d_ctr);
     hipHostFree(p->h_ctr);
@@ -1341,32 +1349,33 @@ int opal_pop_download_soa(const opal_pop_t *p, int32_t *cell, double *x, double 
     return OPAL_OK;
 }
 
-int opal_pop_track_extras(opal_pop_t *p, int on)
+int opal_pop_track_fields(opal_pop_t *p, unsigned fields)
 {
     if (int rc = check_pop(p)) return rc;
     if (p->species == OPAL_ION) return OPAL_OK;  // ion.rs has no chi / y / z; its `work` is not surfaced
-    if (on < 0 || on > 2) {
-        set_error("opal_pop_track_extras: level must be 0, 1 or 2");
-        return OPAL_ERR_ARG;
-    }
-    // which arrays the level needs: electrons chi work y z (+ tau id at level 2), photons chi y z id
     bool need[NEX] = {false, false, false, false, false, false};
-    if (on) {
-        need[EX_CHI] = need[EX_Y] = need[EX_Z] = true;
-        if (p->species == OPAL_ELECTRON) need[EX_WORK] = true;
-        if (p->species == OPAL_PHOTON) need[EX_ID] = true;
-        if (on == 2 && p->species == OPAL_ELECTRON) need[EX_TAU] = need[EX_ID] = true;
-    }
-    bool fresh[NEX];
+    need[EX_CHI] = fields & (OPAL_TRACK_CHI | OPAL_TRACK_EMISSION);  // emission reads the electron's chi
+    need[EX_WORK] = (fields & OPAL_TRACK_WORK) && p->species == OPAL_ELECTRON;  // photon.rs:207-209: always 0
+    need[EX_Y] = need[EX_Z] = fields & OPAL_TRACK_YZ;
+    need[EX_TAU] = (fields & OPAL_TRACK_EMISSION) && p->species == OPAL_ELECTRON;
+    need[EX_ID] = need[EX_TAU] || (fields & OPAL_TRACK_ID);
+    bool fresh[NEX], any_fresh = false, any = false;
     for (int q = 0; q < NEX; q++) {
         fresh[q] = need[q] && !p->d_ex[q];
         if (fresh[q]) OPAL_HIP(hipMalloc(&p->d_ex[q], sizeof(double) * p->cap));
+        if (!need[q] && p->d_ex[q]) {
+            OPAL_HIP(hipStreamSynchronize(p->stream));
+            hipFree(p->d_ex[q]);
+            p->d_ex[q] = nullptr;
+            if (p->d_ex_alt[q]) hipFree(p->d_ex_alt[q]);
+            p->d_ex_alt[q] = nullptr;
+        }
+        any_fresh |= fresh[q];
+        any |= need[q];
     }
-    p->extras = on;
-    bool any = false;
-    for (int q = 0; q < NEX; q++) any |= fresh[q];
-    if (any) {
-        // start the new arrays as T::create does for every slot in use (the others keep their values)
+    p->extras = !any ? 0 : need[EX_TAU] ? 2 : 1;
+    if (any_fresh) {
+        // start the new arrays as T::create does for every slot (arrays tracked before keep their values)
         double *keep[NEX];
         for (int q = 0; q < NEX; q++) {
             keep[q] = p->d_ex[q];
@@ -1379,10 +1388,31 @@ int opal_pop_track_extras(opal_pop_t *p, int on)
     return OPAL_OK;
 }
 
+int opal_pop_track_extras(opal_pop_t *p, int on)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (on < 0 || on > 2) {
+        set_error("opal_pop_track_extras: level must be 0, 1 or 2");
+        return OPAL_ERR_ARG;
+    }
+    unsigned fields = 0;
+    if (on) fields = OPAL_TRACK_CHI | OPAL_TRACK_WORK | OPAL_TRACK_YZ | (p->species == OPAL_PHOTON ? OPAL_TRACK_ID : 0u);
+    if (on == 2) fields |= OPAL_TRACK_EMISSION;
+    return opal_pop_track_fields(p, fields);
+}
+
+int opal_pop_keep_prev_x(opal_pop_t *p, int on)
+{
+    if (int rc = check_pop(p)) return rc;
+    p->keep_prev = on != 0;
+    if (!on) p->prev_valid = false;
+    return OPAL_OK;
+}
+
 int opal_pop_download_extras(const opal_pop_t *p, double *chi, double *work, double *y, double *z)
 {
     if (int rc = check_pop(p)) return rc;
-    if (!p->d_ex[EX_CHI]) {
+    if (!p->extras) {
         set_error("opal_pop_download_extras: extras are not tracked");
         return OPAL_ERR_ARG;
     }
@@ -1493,8 +1523,11 @@ int opal_pop_advance(opal_pop_t *p, opal_link_t *link, const opal_grid_t *grid, 
         set_error("opal_pop_advance: null grid");
         return OPAL_ERR_ARG;
     }
-    if (int rc = ensure_prev(p)) return rc;
-    p->prev_valid = true;
+    const bool prev = p->keep_prev && p->species != OPAL_PHOTON;  // photons are never deposited (main.rs:254-258)
+    if (prev)
+        if (int rc = ensure_prev(p)) return rc;
+    p->prev_valid = prev;
+    if (!prev) p->keep_prev = false;
     if (int rc = advance_with_exchange(p, link, const_cast<opal_grid_t *>(grid), dt, MODE_ADVANCE)) return rc;
     if (int rc = maybe_sort(p, grid)) return rc;
     return OPAL_OK;

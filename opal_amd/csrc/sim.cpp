@@ -168,6 +168,36 @@ struct LaserPair {
 double laser_y_cb(double t, double x, void *user) { return call_laser(t, x, static_cast<LaserPair *>(user)->y); }
 double laser_z_cb(double t, double x, void *user) { return call_laser(t, x, static_cast<LaserPair *>(user)->z); }
 
+// Which per-particle extras a population has to carry: the optical depth machinery when emission is on,
+// plus whatever its `output:` specs read (mod.rs:388-449: "r" -> y, z; "work"; "chi").  Everything else
+// stays out of HBM.
+int track_for_outputs(opal_sim_t *s, opal_pop_t *p)
+{
+    const std::vector<std::string> &specs = p->species == OPAL_ELECTRON ? s->electron_output
+                                            : p->species == OPAL_ION    ? s->ion_output
+                                                                        : s->photon_output;
+    auto mentions = [&](const char *name) {
+        for (const std::string &sp : specs) {
+            size_t from = 0;
+            while (from <= sp.size()) {
+                size_t to = sp.find_first_of(":(;)", from);
+                if (to == std::string::npos) to = sp.size();
+                if (sp.compare(from, to - from, name) == 0) return true;
+                from = to + 1;
+            }
+        }
+        return false;
+    };
+    unsigned fields = 0;
+    if (mentions("chi")) fields |= OPAL_TRACK_CHI;
+    if (mentions("work")) fields |= OPAL_TRACK_WORK;
+    if (mentions("r")) fields |= OPAL_TRACK_YZ;
+    if (s->photon_emission) fields |= p->species == OPAL_ELECTRON ? OPAL_TRACK_EMISSION : OPAL_TRACK_ID;
+    if (int rc = opal_pop_track_fields(p, fields)) return rc;
+    // prev_x is only read by a separate deposit pass
+    return opal_pop_keep_prev_x(p, s->current_deposition ? 1 : 0);
+}
+
 int load_species(opal_sim_t *s, const char *section, const char *density_key, int species, size_t npc, Rng &rng,
                  opal_pop_t **out)
 {
@@ -190,8 +220,7 @@ int load_species(opal_sim_t *s, const char *section, const char *density_key, in
     size_t cap = soa.size() + soa.size() / 8 + 65536;
     if (int rc = opal_pop_create(out, species, cap, s->stream)) return rc;
     (*out)->id_base = (unsigned long long)s->rank << 40;  // ids unique across subdomains
-    if (s->photon_emission && species != OPAL_ION)
-        if (int rc = opal_pop_track_extras(*out, species == OPAL_ELECTRON ? 2 : 1)) return rc;
+    if (int rc = track_for_outputs(s, *out)) return rc;
     if (int rc = opal_pop_upload_soa(*out, soa.size(), soa.cell.data(), soa.x.data(), soa.ux.data(), soa.uy.data(),
                                      soa.uz.data(), soa.w.data(), s->dx, s->dt))
         return rc;
@@ -287,7 +316,8 @@ int sim_setup(opal_sim_t *s)
             if (int rc = load_species(s, "photons", "nph", OPAL_PHOTON, ppc, rng, &s->photons)) return rc;
         } else {
             if (int rc = opal_pop_create(&s->photons, OPAL_PHOTON, 1 << 20, s->stream)) return rc;
-            if (int rc = opal_pop_track_extras(s->photons, 1)) return rc;
+            s->photons->id_base = (unsigned long long)s->rank << 40;
+            if (int rc = track_for_outputs(s, s->photons)) return rc;
         }
         // The reference goes on drawing from the generator the loader used (seeded with the rank,
         // main.rs:53); the build's counter-based generator takes one key for the whole run, so that a
