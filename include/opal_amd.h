@@ -114,6 +114,8 @@ int opal_grid_em_field_energy(const opal_grid_t *g, double *energy);
 int opal_grid_interpolate(const opal_grid_t *g, double *out);
 /* yee.rs:749-781 for a single subdomain: writes "{dir}/{index}_grid.dat" */
 int opal_grid_write_data(const opal_grid_t *g, const char *dir, size_t index);
+/* the same from `n` gathered rows of opal_grid_interpolate (11 doubles each): what rank 0 writes, yee.rs:762-773 */
+int opal_grid_write_rows(const double *rows, size_t n, const char *dir, size_t index);
 /* ghost-inclusive component arrays (len doubles), for tests and for drivers that inject currents */
 int opal_grid_get_raw(const opal_grid_t *g, int comp, double *out);
 int opal_grid_set_raw(opal_grid_t *g, int comp, const double *in);
@@ -248,9 +250,9 @@ int opal_link_set_buffers(opal_link_t *l, void *send_left, void *send_right, voi
 void *opal_link_buffer(opal_link_t *l, int which);
 
 /* ------------------------------------------------------------------ Simulation
- * main() of the reference (src/main.rs:48-286) for the hot-path configurations:
- * reads the same YAML input file, builds grid + populations for subdomain `rank`
- * of `numtasks`, and runs the time loop (no QED). */
+ * main() of the reference (src/main.rs:48-286): reads the same YAML input file, builds grid +
+ * populations for subdomain `rank` of `numtasks`, and runs the time loop (photon emission included,
+ * absorption not). */
 int opal_sim_create(opal_sim_t **out, const char *yaml_path, int rank, int numtasks, opal_link_t *link,
                     void *hip_stream);
 int opal_sim_create_from_string(opal_sim_t **out, const char *yaml_text, const char *output_dir, int rank,
@@ -258,7 +260,18 @@ int opal_sim_create_from_string(opal_sim_t **out, const char *yaml_text, const c
 int opal_sim_free(opal_sim_t *s);
 /* `n` iterations of main.rs:238-267 */
 int opal_sim_step(opal_sim_t *s, size_t n);
-/* the whole of main.rs:217-283, writing {i}_energy.dat / {i}_grid.dat into the output directory */
+/* the whole of main.rs:217-283, writing {i}_energy.dat / {i}_grid.dat / {i}_{species}_*.fits into the
+ * output directory.  With more than one subdomain the output-time reductions of the reference
+ * (MPI_Reduce of the energies, main.rs:23-31; gather of the grid rows to rank 0, yee.rs:749-779;
+ * MPI_Allreduce of histogram ranges and counts, hgram.rs:190-192, 249, 260) go through the two
+ * callbacks below, which every subdomain must have set (e.g. torch.distributed all_reduce / all_gather).
+ *   allreduce: in place over all subdomains, op 0 = sum, 1 = min, 2 = max.
+ *   gather: subdomain r contributes counts[r] doubles; `all` (rank 0 only, else may be null) receives
+ *   them concatenated in rank order. */
+typedef int (*opal_allreduce_fn)(void *user, double *values, size_t n, int op);
+typedef int (*opal_gather_fn)(void *user, const double *local, size_t n_local, double *all, const size_t *counts,
+                              int numtasks);
+int opal_sim_set_collectives(opal_sim_t *s, opal_allreduce_fn allreduce, opal_gather_fn gather, void *user);
 int opal_sim_run(opal_sim_t *s);
 int opal_sim_sync(opal_sim_t *s);
 double opal_sim_time(const opal_sim_t *s);

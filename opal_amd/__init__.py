@@ -337,7 +337,10 @@ def qed_rate(chi, gamma):
 class Simulation:
     """main() of the reference (src/main.rs) for one subdomain."""
 
-    def __init__(self, yaml_path=None, yaml_text=None, output_dir=".", rank=0, numtasks=1, link=None, stream=None):
+    def __init__(self, yaml_path=None, yaml_text=None, output_dir=".", rank=0, numtasks=1, link=None, stream=None,
+                 collectives=None):
+        """collectives: an exchange.TorchCollectives for run()'s output-time reductions; built from `link`
+        (same process group and device) when omitted."""
         self._lib = _lib.load()
         h = C.c_void_p()
         lk = link.h if link else None
@@ -348,6 +351,13 @@ class Simulation:
                                                          numtasks, lk, stream))
         self.h = h
         self._link = link
+        if numtasks > 1:
+            if collectives is None and link is not None and hasattr(link, "transport"):
+                from .exchange import TorchCollectives
+                collectives = TorchCollectives(link.device, link.transport.group)
+            if collectives is not None:
+                _check(self._lib.opal_sim_set_collectives(h, collectives.allreduce_cb, collectives.gather_cb, None))
+        self._collectives = collectives
         self.grid = Grid(0, 0, 0, 0, 0, 0, None, None, _handle=self._lib.opal_sim_grid(h))
         e = self._lib.opal_sim_electrons(h)
         i = self._lib.opal_sim_ions(h)

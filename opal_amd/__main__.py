@@ -1,0 +1,54 @@
+"""Run an opal input file on one or more MI355X: the launcher a user of the reference's
+`mpirun -n N opal input.yaml` switches to.
+
+    python -m opal_amd input.yaml                                                   # one GPU
+    python -m torch.distributed.run --nproc-per-node 8 -m opal_amd input.yaml       # one subdomain per GPU
+
+One process per GPU; neighbour exchange over RCCL (backend "nccl"); outputs are written next to the input
+file by rank 0, as the reference does (main.rs:60-61)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+import opal_amd as oa
+from opal_amd.exchange import TorchLink
+
+
+def main(argv):
+    if len(argv) != 2:
+        print("Usage: python -m opal_amd input-file", file=sys.stderr)  # main.rs:56-59
+        return 1
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("OPAL_BACKEND", "nccl")  # "gloo": host-staged exchange (rehearsals on one GPU)
+    device = torch.device("cuda", local if backend == "nccl" else 0)
+    torch.cuda.set_device(device)
+    oa.set_device(device.index)
+    link = None
+    if world > 1:
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                **({"device_id": device} if backend == "nccl" else {}))
+        emission = oa.Config(path=argv[1]).read_bool("qed", "photon_emission")
+        link = TorchLink(rank, world, device if backend == "nccl" else torch.device("cpu"),
+                         particle_capacity=int(os.environ.get("OPAL_LINK_CAPACITY", "65536")),
+                         photon_emission=emission, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        sim = oa.Simulation(yaml_path=argv[1], rank=rank, numtasks=world, link=link,
+                            stream=torch.cuda.current_stream().cuda_stream)
+        if rank == 0:
+            print(f"Running {world} task{'s' if world > 1 else ''} on {world} GPU{'s' if world > 1 else ''}...")
+        sim.run()
+    except oa.OpalError as e:
+        print(e, file=sys.stderr)
+        return 1
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

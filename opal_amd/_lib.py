@@ -13,6 +13,9 @@ FN1 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
 FN2 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)
 FN3 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_int)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double),
+                        C.POINTER(C.c_size_t), C.c_int)
 
 vp = C.c_void_p
 dbl = C.c_double
@@ -110,6 +113,8 @@ SIGNATURES = {
     "opal_sim_electrons": (vp, [vp]),
     "opal_sim_ions": (vp, [vp]),
     "opal_sim_photons": (vp, [vp]),
+    "opal_sim_set_collectives": (C.c_int, [vp, ALLREDUCE_FN, GATHER_FN, vp]),
+    "opal_grid_write_rows": (C.c_int, [vp, sz, C.c_char_p, sz]),
     "opal_sim_energies": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
     "opal_sim_set_fused": (C.c_int, [vp, C.c_int]),
     "opal_prof_enable": (C.c_int, [C.c_int]),

@@ -155,6 +155,10 @@ struct opal_sim {
     double photon_energy_min = -1.0, photon_angle_max = -1.0, max_formation_length = -1.0;
     uint64_t emission_seed = 0;
     size_t step_index = 0;
+    std::vector<size_t> nxs;  // interior cells of every subdomain (GridDesign)
+    opal_allreduce_fn allreduce = nullptr;
+    opal_gather_fn gather = nullptr;
+    void *coll_user = nullptr;
     double t = 0;
     size_t total_steps = 0, steps_bt_output = 0;
     bool fused = true;
@@ -287,6 +291,7 @@ int sim_setup(opal_sim_t *s)
     if (int rc = opal_grid_build(&s->grid, s->rank, s->numtasks, left, right, s->xmin, s->dx, nxs.data(), offs.data(),
                                  s->stream))
         return rc;
+    s->nxs = nxs;
 
     Rng rng;
     rng.seed((uint64_t)s->rank);  // main.rs:53
@@ -337,6 +342,14 @@ int write_energies(opal_sim_t *s, size_t index)
     if (int rc = opal_sim_energies(s, &f, &e, &i)) return rc;
     if (s->photons)
         if (int rc = opal_pop_total_kinetic_energy(s->photons, &ph)) return rc;
+    if (s->numtasks > 1) {  // yee.rs:801-808, mod.rs:232-239: MPI_Reduce(sum) to rank 0
+        double v[4] = {f, e, i, ph};
+        if (s->allreduce(s->coll_user, v, 4, 0)) {
+            set_error("energy reduction failed in the caller's allreduce");
+            return OPAL_ERR_LINK;
+        }
+        f = v[0]; e = v[1]; i = v[2]; ph = v[3];
+    }
     if (s->rank != 0) return OPAL_OK;
     std::string fn = s->output_dir + "/" + std::to_string(index) + "_energy.dat";
     FILE *fp = fopen(fn.c_str(), "w");
@@ -363,12 +376,24 @@ int opal_grid_write_data(const opal_grid_t *g, const char *dir, size_t index)
         return OPAL_ERR_ARG;
     }
     if (opal_grid_ngrids(g) != 1) {
-        set_error("opal_grid_write_data: single-subdomain only; gather opal_grid_interpolate() rows on rank 0 otherwise");
+        set_error("opal_grid_write_data: single-subdomain only; gather opal_grid_interpolate() rows on rank 0 and "
+                  "call opal_grid_write_rows otherwise (opal_sim_run does)");
         return OPAL_ERR_ARG;
     }
     size_t n = opal_grid_size(g);
     std::vector<double> rows(11 * n);
     if (int rc = opal_grid_interpolate(g, rows.data())) return rc;
+    return opal_grid_write_rows(rows.data(), n, dir, index);
+}
+
+/* {index}_grid.dat from `n` rows of opal_grid_interpolate (x rho jx jy jz Ex Ey Ez Bx By Bz), yee.rs:762-773 */
+int opal_grid_write_rows(const double *rows_in, size_t n, const char *dir, size_t index)
+{
+    if (!rows_in || !dir) {
+        set_error("opal_grid_write_rows: bad arguments");
+        return OPAL_ERR_ARG;
+    }
+    const double *rows = rows_in;
     std::string fn = std::string(dir) + "/" + std::to_string(index) + "_grid.dat";
     FILE *fp = fopen(fn.c_str(), "w");
     if (!fp) {
@@ -376,7 +401,7 @@ int opal_grid_write_data(const opal_grid_t *g, const char *dir, size_t index)
         return OPAL_ERR_IO;
     }
     for (size_t k = 0; k < n; k++) {  // yee.rs:765-773
-        const double *r = &rows[11 * k];
+        const double *r = rows + 11 * k;
         std::string line;
         for (int c = 0; c < 10; c++) line += rust_lower_exp(r[c]) + " ";
         line += rust_display(r[10]);
@@ -669,6 +694,88 @@ int opal_sim_energies(opal_sim_t *s, double *em_field, double *electrons, double
     return OPAL_OK;
 }
 
+int opal_sim_set_collectives(opal_sim_t *s, opal_allreduce_fn allreduce, opal_gather_fn gather, void *user)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    s->allreduce = allreduce;
+    s->gather = gather;
+    s->coll_user = user;
+    return OPAL_OK;
+}
+
+namespace {
+
+// Grid::write_data, yee.rs:749-779: every subdomain's interpolated rows, in rank order, written by rank 0
+int write_grid(opal_sim_t *s, size_t index)
+{
+    if (s->numtasks == 1) return opal_grid_write_data(s->grid, s->output_dir.c_str(), index);
+    size_t n = opal_grid_size(s->grid), total = 0;
+    std::vector<double> rows(11 * n), all;
+    if (int rc = opal_grid_interpolate(s->grid, rows.data())) return rc;
+    std::vector<size_t> counts(s->nxs.size());
+    for (size_t r = 0; r < s->nxs.size(); r++) {
+        counts[r] = 11 * s->nxs[r];
+        total += s->nxs[r];
+    }
+    if (s->rank == 0) all.resize(11 * total);
+    if (s->gather(s->coll_user, rows.data(), rows.size(), s->rank == 0 ? all.data() : nullptr, counts.data(), s->numtasks)) {
+        set_error("gathering the grid rows failed in the caller's gather");
+        return OPAL_ERR_LINK;
+    }
+    if (s->rank != 0) return OPAL_OK;
+    return opal_grid_write_rows(all.data(), total, s->output_dir.c_str(), index);
+}
+
+// Population::write_data (mod.rs:383-568) across subdomains: the two-phase histogram ABI with the
+// reference's all-reductions (hgram.rs:190-192, 249, 260) in between.  Collective: every subdomain calls
+// it with the same specs.
+int write_pop(opal_sim_t *s, opal_pop_t *p, const std::string &name, const std::vector<std::string> &specs, size_t index)
+{
+    if (!p || specs.empty()) return OPAL_OK;
+    if (s->numtasks == 1) {
+        std::vector<const char *> cs;
+        for (auto &sp : specs) cs.push_back(sp.c_str());
+        return opal_pop_write_data(p, s->grid, s->output_dir.c_str(), index, name.c_str(), cs.data(), cs.size());
+    }
+    auto reduce = [&](double *v, size_t n, int op) -> int {
+        if (s->allreduce(s->coll_user, v, n, op)) {
+            set_error("histogram reduction failed in the caller's allreduce");
+            return OPAL_ERR_LINK;
+        }
+        return OPAL_OK;
+    };
+    for (const std::string &spec : specs) {
+        char path[4096];
+        if (opal_hist_filename(s->output_dir.c_str(), index, name.c_str(), spec.c_str(), path, sizeof path) != OPAL_OK)
+            continue;  // a spec the reference skips: skipped by every subdomain alike
+        int dim;
+        double mn[2], mx[2];
+        size_t n;
+        if (int rc = opal_pop_hist_range(p, s->grid, spec.c_str(), &dim, mn, mx, &n)) return rc;
+        double cnt = (double)n;
+        if (int rc = reduce(mn, 2, 1)) return rc;
+        if (int rc = reduce(mx, 2, 2)) return rc;
+        if (int rc = reduce(&cnt, 1, 0)) return rc;
+        if (cnt == 0.0) continue;  // hgram.rs:195-197
+        opal_hist_t *h = nullptr;
+        if (int rc = opal_pop_hist_fill(p, s->grid, spec.c_str(), mn, mx, (size_t)cnt, &h)) return rc;
+        double total = opal_hist_total(h);
+        int rc = reduce(opal_hist_counts(h), opal_hist_len(h), 0);
+        if (!rc) rc = reduce(&total, 1, 0);
+        if (!rc) rc = opal_hist_set_total(h, total);
+        if (!rc) rc = opal_hist_finish(h);
+        if (!rc && s->rank == 0) rc = opal_hist_write_fits(h, path);
+        opal_hist_free(h);
+        if (rc) return rc;
+    }
+    return OPAL_OK;
+}
+
+}  // namespace
+
 // main.rs:217-283
 int opal_sim_run(opal_sim_t *s)
 {
@@ -676,34 +783,28 @@ int opal_sim_run(opal_sim_t *s)
         set_error("null simulation handle");
         return OPAL_ERR_ARG;
     }
-    if (s->numtasks != 1) {
-        set_error("opal_sim_run writes single-subdomain output; drive multi-subdomain runs with opal_sim_step");
+    if (s->numtasks != 1 && (!s->allreduce || !s->gather)) {
+        set_error("opal_sim_run with %d subdomains needs opal_sim_set_collectives (output-time reductions)", s->numtasks);
         return OPAL_ERR_ARG;
     }
-    auto write_pops = [&](size_t i) -> int {  // main.rs:219-221
-        auto one = [&](opal_pop_t *p, const std::string &name, const std::vector<std::string> &specs) -> int {
-            if (!p || specs.empty()) return OPAL_OK;
-            std::vector<const char *> cs;
-            for (auto &sp : specs) cs.push_back(sp.c_str());
-            return opal_pop_write_data(p, s->grid, s->output_dir.c_str(), i, name.c_str(), cs.data(), cs.size());
-        };
-        if (int rc = one(s->electrons, "electron", s->electron_output)) return rc;
-        if (int rc = one(s->ions, s->ion_name, s->ion_output)) return rc;
-        return one(s->photons, "photon", s->photon_output);
+    auto write_all = [&](size_t i) -> int {  // main.rs:219-222
+        if (int rc = write_grid(s, i)) return rc;
+        if (int rc = write_pop(s, s->electrons, "electron", s->electron_output, i)) return rc;
+        if (int rc = write_pop(s, s->ions, s->ion_name, s->ion_output, i)) return rc;
+        if (int rc = write_pop(s, s->photons, "photon", s->photon_output, i)) return rc;
+        return write_energies(s, i);
     };
     for (size_t i = 0; i < s->n_outputs; i++) {
-        if (int rc = opal_grid_write_data(s->grid, s->output_dir.c_str(), i)) return rc;
-        if (int rc = write_pops(i)) return rc;
-        if (int rc = write_energies(s, i)) return rc;
-        printf("Output %4zu at t = %s...\n", i, simulation_time(s->t).c_str());
-        fflush(stdout);
+        if (int rc = write_all(i)) return rc;
+        if (s->rank == 0) {
+            printf("Output %4zu at t = %s...\n", i, simulation_time(s->t).c_str());
+            fflush(stdout);
+        }
         if (int rc = opal_sim_step(s, s->steps_bt_output)) return rc;
         if (int rc = opal_sim_sync(s)) return rc;
     }
-    if (int rc = opal_grid_write_data(s->grid, s->output_dir.c_str(), s->n_outputs)) return rc;
-    if (int rc = write_pops(s->n_outputs)) return rc;
-    if (int rc = write_energies(s, s->n_outputs)) return rc;
-    printf("Output %4zu at t = %s\n", s->n_outputs, simulation_time(s->t).c_str());
+    if (int rc = write_all(s->n_outputs)) return rc;
+    if (s->rank == 0) printf("Output %4zu at t = %s\n", s->n_outputs, simulation_time(s->t).c_str());
     return OPAL_OK;
 }
 

@@ -115,3 +115,52 @@ class TorchLink:
         except Exception:  # never let an exception cross the C boundary
             traceback.print_exc(file=sys.stderr)
             return 1
+
+
+class TorchCollectives:
+    """The output-time reductions of a decomposed run (opal_sim_set_collectives) on torch.distributed:
+    energies and histograms are all-reduced, grid rows gathered to rank 0 (the reference's MPI_Reduce /
+    MPI_Allreduce / gather-by-p2p at output cadence).  Nothing here is on the step
+    path."""
+
+    def __init__(self, device, group=None):
+        self.device = torch.device(device)
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.allreduce_cb = _lib.ALLREDUCE_FN(self._allreduce)
+        self.gather_cb = _lib.GATHER_FN(self._gather)
+
+    def _allreduce(self, user, values, n, op):
+        try:
+            import numpy as np
+            a = np.ctypeslib.as_array(values, shape=(n,))
+            t = torch.from_numpy(a.copy()).to(self.device)
+            dist.all_reduce(t, op=(dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX)[op], group=self.group)
+            a[:] = t.cpu().numpy()
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    def _gather(self, user, local, n_local, out, counts, numtasks):
+        try:
+            import numpy as np
+            cnt = [counts[r] for r in range(numtasks)]
+            width = max(cnt)
+            mine = torch.zeros(width, dtype=torch.float64)
+            if n_local:
+                mine[:n_local] = torch.from_numpy(np.ctypeslib.as_array(local, shape=(n_local,)).copy())
+            mine = mine.to(self.device)
+            parts = [torch.empty(width, dtype=torch.float64, device=self.device) for _ in range(numtasks)]
+            dist.all_gather(parts, mine, group=self.group)  # equal-size pieces: the one collective both backends have
+            if self.rank == 0:
+                dst = np.ctypeslib.as_array(out, shape=(sum(cnt),))
+                at = 0
+                for r in range(numtasks):
+                    dst[at:at + cnt[r]] = parts[r][:cnt[r]].cpu().numpy()
+                    at += cnt[r]
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            return 1

@@ -169,6 +169,18 @@ def main():
         out["Ey"] = sim.grid.raw("Ey")
         out["t"] = sim.t
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    elif mode == "run":
+        # the whole of main(): outputs included (grid rows gathered, energies and histograms reduced)
+        sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc).replace("n_outputs: 2", "n_outputs: 3")
+                            .replace("end: 1.0e-12", "end: 30.5 * 0.95e-8 / c"),
+                            output_dir=outdir, rank=rank, numtasks=world, link=link)
+        init = {}
+        for name, p in (("e", sim.electrons), ("i", sim.ions)):
+            for k, v in p.soa().items():
+                init[f"init_{name}_{k}"] = v
+        init["steps"] = sim.total_steps
+        sim.run()
+        dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
     elif mode == "ops":
         nxs, offs = oa.design_unbalanced(world, nx, dx)
         g = oa.Grid(rank, world, oa.BDY_INTERNAL, oa.BDY_INTERNAL, 0.0, dx, nxs, offs)

@@ -180,3 +180,76 @@ def test_photon_emission_across_subdomains(oracle, tmp_path, world):
             assert abs(got[r]["ke_e"] - pes[r].total_kinetic_energy()) / pes[r].total_kinetic_energy() < 5e-4
         if len(phs[r]):
             assert abs(got[r]["ke_ph"] - phs[r].total_kinetic_energy()) / phs[r].total_kinetic_energy() < 5e-4
+
+
+def test_decomposed_run_writes_the_reference_outputs(oracle, tmp_path):
+    """opal_sim_run on 2 subdomains: {i}_grid.dat gathered in rank order (yee.rs:749-779), {i}_energy.dat
+    reduced (main.rs:23-42), {i}_{species}_x-px.fits all-reduced (hgram.rs:190-260) -- against the oracle run
+    with the same decomposition from the driver's own initial particles."""
+    from test_gpu_histograms import read_fits
+    o = oracle
+    world, nx, npc = 2, 64, 16
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    _launch("_gloo_hip_worker.py", world, ["run", tmp_path, nx, npc, 0, 1])
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    steps = int(got[0]["steps"])
+    assert steps == 30
+    st_e = [tuple(g[f"init_e_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
+    st_i = [tuple(g[f"init_i_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
+    files = sorted(f for f in os.listdir(tmp_path) if not f.endswith(".npz"))
+    want = sorted([f"{i}_{k}" for i in range(4) for k in ("grid.dat", "energy.dat", "electron_x-px.fits", "positron_x-px.fits")])
+    assert files == want
+    grids, pes, pis = _oracle_world(o, world, nx, dx, dt, st_e, st_i, steps)
+    # grid rows: x rho jx jy jz Ex Ey Ez Bx By Bz for every interior cell of every subdomain, in order
+    rows = np.loadtxt(os.path.join(tmp_path, "3_grid.dat"))
+    ref = np.concatenate([g.interpolate() for g in grids])
+    assert rows.shape == ref.shape == (nx, 11)
+    assert np.array_equal(rows[:, 0], ref[:, 0])
+    for c in range(1, 11):
+        scale = max(np.max(np.abs(ref[:, c])), 1e-300)
+        assert np.max(np.abs(rows[:, c] - ref[:, c])) / scale < 1e-9, c
+    e = {k: float(v) for k, v in (line.split() for line in open(os.path.join(tmp_path, "3_energy.dat")))}
+    assert e["em_field"] == pytest.approx(sum(g.em_field_energy() for g in grids), rel=1e-6)
+    assert e["electrons"] == pytest.approx(sum(p.total_kinetic_energy() for p in pes), rel=1e-6)
+    assert e["ions"] == pytest.approx(sum(p.total_kinetic_energy() for p in pis), rel=1e-6)
+    # the histogram of all electrons = the oracle's histogram of the union on one global grid
+    nxs, _ = o.design_unbalanced(world, nx, dx)
+    parts = [p.soa() for p in pes]
+    cat = {k: np.concatenate([d[k] + (sum(nxs[:r]) if k == "cell" else 0) for r, d in enumerate(parts)])
+           for k in ("cell", "x", "ux", "uy", "uz", "w")}
+    union = o.Population.from_soa(o.ELECTRON, cat["cell"], cat["x"], cat["ux"], cat["uy"], cat["uz"], cat["w"], dx, dt)
+    href = o.histogram(union, o.Grid.single(nx, 0.0, dx), ["x", "px"])
+    cards, shape, data = read_fits(os.path.join(tmp_path, "3_electron_x-px.fits"))
+    assert shape == [href["nbins"][1], href["nbins"][0]]
+    assert float(cards["TOTAL"]) == pytest.approx(href["total"], rel=1e-12)
+    scale = np.max(href["cts"])
+    assert np.sum(np.abs(data - href["cts"]) > 1e-9 * scale) <= 4
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_launcher_runs_an_input_file(tmp_path, world):
+    """`python -m opal_amd input.yaml`, alone and as 2 ranks (gloo rehearsal of the torchrun + RCCL launch):
+    outputs land next to the input file (main.rs:60-61)."""
+    import subprocess
+    from test_exchange_gloo import _free_port
+    from test_gpu_driver import TWO_STREAM
+    yml = tmp_path / "two_stream.yaml"
+    yml.write_text(TWO_STREAM.replace("npc: 100", "npc: 20"))
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OPAL_BACKEND="gloo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", "opal_amd", str(yml)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, outs[r][-3000:]
+    assert "Output    4 at t =" in outs[0]
+    files = sorted(f for f in os.listdir(tmp_path) if f != "two_stream.yaml")
+    assert files == sorted([f"{i}_{k}" for i in range(5) for k in ("grid.dat", "energy.dat", "electron_x-px.fits")])
+    rows = np.loadtxt(tmp_path / "4_grid.dat")
+    assert rows.shape == (1000, 11) and np.all(np.diff(rows[:, 0]) > 0)
+    e = {k: float(v) for k, v in (line.split() for line in open(tmp_path / "4_energy.dat"))}
+    assert e["electrons"] > 0 and e["em_field"] > 0
