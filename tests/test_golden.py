@@ -144,3 +144,49 @@ def test_hip_against_golden(gold):
         ref = np.array(a)
         assert np.max(np.abs(g.raw(c) - ref)) <= 1e-13 * np.max(np.abs(ref)), c
     assert abs(g.em_field_energy() - fs["energy"]) <= 1e-13 * fs["energy"]
+
+
+# ----------------------------------------------------------------------------- photon emission
+@pytest.fixture(scope="module")
+def qgold():
+    return json.load(open(os.path.join(HERE, "golden", "qed_emission_vectors.json")))
+
+
+def test_oracle_emission_vectors(oracle, qgold):
+    """The oracle (and the generated sampling tables it reads) against the committed emission vectors.
+    Integer work bit for bit; floating point to 1e-12 (libm's log / exp / pow / acos may differ in the last
+    digit between glibc versions)."""
+    o = oracle
+    for v in qgold["philox"]:
+        assert list(o.philox(v["ctr"], v["key"])) == v["out"]
+    for v in qgold["randoms"]:
+        assert list(o.emission_randoms(v["seed"], v["id"], v["step"])) == v["out"]
+    for v in qgold["rate"]:
+        assert o.rate(v["chi"], v["gamma"]) == pytest.approx(v["out"], rel=1e-13)
+    for v in qgold["sample"]:
+        got = o.qed_sample(v["chi"], v["gamma"], *v["r"])
+        assert got[0] == pytest.approx(v["out"][0], rel=1e-12) and got[2] == v["out"][2]
+        assert got[1] * v["gamma"] == pytest.approx(v["out"][1] * v["gamma"], rel=1e-9, abs=1e-12)
+    for v in qgold["classical"]:
+        got = o.qed_classical_sample(v["chi"], v["gamma"], *v["r"])
+        assert got[0] == pytest.approx(v["out"][0], rel=1e-12)
+        assert got[1] * v["gamma"] == pytest.approx(v["out"][1] * v["gamma"], rel=1e-9, abs=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_emission_vectors(qgold):
+    import opal_amd as oa
+    for v in qgold["randoms"]:
+        assert list(oa.qed_randoms(v["seed"], [v["id"]], v["step"])[0]) == v["out"]
+    r = qgold["rate"]
+    got = oa.qed_rate([v["chi"] for v in r], np.array([v["gamma"] for v in r]))
+    assert np.max(np.abs(got / np.array([v["out"] for v in r]) - 1.0)) < 1e-13
+    for key, classical in (("sample", False), ("classical", True)):
+        s = qgold[key]
+        rr = np.array([v["r"] for v in s])
+        gam = np.array([v["gamma"] for v in s])
+        got = oa.qed_sample(np.array([v["chi"] for v in s]), gam, rr[:, 0], rr[:, 1], rr[:, 2], classical=classical)
+        want = np.array([v["out"] for v in s])
+        assert np.max(np.abs(got[:, 0] / want[:, 0] - 1.0)) < 1e-7
+        assert np.max(np.abs(got[:, 1] - want[:, 1]) * gam / np.maximum(want[:, 1] * gam, 1e-3)) < 1e-6
+        assert np.array_equal(got[:, 2], want[:, 2])
