@@ -363,7 +363,7 @@ class Simulation:
         i = self._lib.opal_sim_ions(h)
         self.electrons = Population(ELECTRON, _handle=e) if e else None
         self.ions = Population(ION, _handle=i) if i else None
-        ph = self._lib.opal_sim_photons(h)
+        ph = self._lib.opal_sim_photons(h) if hasattr(self._lib, "opal_sim_photons") else None
         self.photons = Population(PHOTON, _handle=ph) if ph else None  # only with qed.photon_emission
 
     def __del__(self):

@@ -165,7 +165,7 @@ struct ChunkPtrs {
 // The per-particle body shared by the three modes.  FAST = the particle's stencil lies inside the
 // workgroup's LDS tile (fields from LDS, currents into the LDS accumulators); otherwise fields come
 // from global memory and the taps go to the grid with global atomics.
-template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool FAST>
+template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool FAST>
 __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkPtrs &cp, const double *s_field,
                                                  double *s_acc, int base, int lane, unsigned kc, int c, double xi,
                                                  V3 u, double wt, double prev, int &err)
@@ -270,14 +270,10 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                 f[3 * (size_t)a.send_cap + slot] = u.z;
                 f[4 * (size_t)a.send_cap + slot] = wt;
                 if (MODE == MODE_ADVANCE && cp.prev) f[5 * (size_t)a.send_cap + slot] = prev;
-                if (a.send_nextra) {
-                    // a link laid out for photon emission carries the extras too (the reference ships the
-                    // whole struct, mod.rs:308-354); values as updated by this push
-                    size_t i = cp.chunk0 + kc;
-#pragma unroll
-                    for (int q = 0; q < NEX; q++)
-                        if (q < (int)a.send_nextra) f[(size_t)(6 + q) * a.send_cap + slot] = a.ex[q] ? a.ex[q][i] : 0.0;
-                }
+                // A link laid out for photon emission carries the extras too (the reference ships the whole
+                // struct, mod.rs:308-354).  Only the leaver's slot is noted here; k_pack_extras copies the
+                // values afterwards, which keeps six more pointers out of this kernel's registers.
+                if (SENDX) f[6 * (size_t)a.send_cap + slot] = (double)(cp.chunk0 + kc);
             } else {
                 err |= 8;
             }
@@ -300,7 +296,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
 //                  detection); stores prev_x for a later deposit.
 //   MODE_DEPOSIT : YeeGrid::deposit's per-particle body, yee.rs:573-610.
 //   MODE_FUSED   : both in one pass (prev_x stays in registers).
-template <int SPECIES, int MODE, bool RHO, int EXTRAS>
+template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX>
 __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, double *s_field, double *s_acc, int *s_min,
                                           int *s_max)
 {
@@ -439,7 +435,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
                 in_tile = true;
             }
         }
-        if (in_tile) process_particle<SPECIES, MODE, RHO, EXTRAS, true>(a, cp, s_field, s_acc, base, lane, kc, c, xi, u, wt, prev, err);
+        if (in_tile) process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, true>(a, cp, s_field, s_acc, base, lane, kc, c, xi, u, wt, prev, err);
         else pending |= 1u << p;
     }
     // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.
@@ -450,7 +446,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             unsigned kc = (unsigned)p * BLOCK + tid;
             V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
             double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
-            process_particle<SPECIES, MODE, RHO, EXTRAS, false>(a, cp, s_field, s_acc, base, lane, kc, cp.cell[kc], cp.x[kc], u, cp.w[kc], prev, err);
+            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cp.cell[kc], cp.x[kc], u, cp.w[kc], prev, err);
             slow++;
         }
         atomicAdd(&a.ctr->n_slow, slow);
@@ -473,26 +469,29 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     }
 }
 
-template <int SPECIES, int MODE, bool RHO, int EXTRAS>
-__global__ __launch_bounds__(BLOCK) void k_push(PushArgs a)
+template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX>
+__global__ __launch_bounds__(BLOCK, (EXTRAS == 0 && MODE == MODE_FUSED) ? 6 : 1) void k_push(PushArgs a)
 {
     __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
     __shared__ double s_acc[MODE != MODE_ADVANCE ? 4 * TILE * REPL : 1];
     __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
-    push_body<SPECIES, MODE, RHO, EXTRAS>(a, blockIdx.x, s_field, s_acc, s_min, s_max);
+    push_body<SPECIES, MODE, RHO, EXTRAS, SENDX>(a, blockIdx.x, s_field, s_acc, s_min, s_max);
 }
 
 // Both charged species of a step in one launch: the first `nblk_e` workgroups take electrons, the rest
 // ions.  One launch instead of two means one ragged tail of finishing workgroups per step instead of two
 // (the species are independent: both read the fields and add into the same current arrays atomically).
+#ifndef OPAL_PAIR_WAVES
+#define OPAL_PAIR_WAVES 6  // measured: 6 waves/SIMD (80 VGPRs) beats 5 (94) by 1 % and 7 (spills) by 3 %
+#endif
 template <int MODE, bool RHO>
-__global__ __launch_bounds__(BLOCK) void k_push_pair(PushArgs ae, PushArgs ai, unsigned nblk_e)
+__global__ __launch_bounds__(BLOCK, OPAL_PAIR_WAVES) void k_push_pair(PushArgs ae, PushArgs ai, unsigned nblk_e)
 {
     __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
     __shared__ double s_acc[MODE != MODE_ADVANCE ? 4 * TILE * REPL : 1];
     __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
-    if (blockIdx.x < nblk_e) push_body<OPAL_ELECTRON, MODE, RHO, 0>(ae, blockIdx.x, s_field, s_acc, s_min, s_max);
-    else push_body<OPAL_ION, MODE, RHO, 0>(ai, blockIdx.x - nblk_e, s_field, s_acc, s_min, s_max);
+    if (blockIdx.x < nblk_e) push_body<OPAL_ELECTRON, MODE, RHO, 0, false>(ae, blockIdx.x, s_field, s_acc, s_min, s_max);
+    else push_body<OPAL_ION, MODE, RHO, 0, false>(ai, blockIdx.x - nblk_e, s_field, s_acc, s_min, s_max);
 }
 
 // ------------------------------------------------------------------ re-binning
@@ -764,6 +763,29 @@ __global__ void k_unpack(UnpackArgs a)
     }
 }
 
+// Fills the extras columns of the leavers packed by the push (which left each leaver's slot number in the
+// first extras column): one workgroup per side.
+struct PackExtrasArgs {
+    char *send[2];
+    size_t species_off;
+    int slot;
+    unsigned link_cap, nextra;
+    const double *ex[NEX];
+};
+__global__ void k_pack_extras(PackExtrasArgs a)
+{
+    char *msg = a.send[blockIdx.x];
+    if (!msg) return;
+    unsigned count = min(reinterpret_cast<const unsigned *>(msg)[a.slot], a.link_cap);
+    double *f = reinterpret_cast<double *>(msg + a.species_off + sizeof(int) * (size_t)a.link_cap);
+    for (unsigned k = threadIdx.x; k < count; k += blockDim.x) {
+        size_t i = (size_t)f[(size_t)6 * a.link_cap + k];
+#pragma unroll
+        for (int q = 0; q < NEX; q++)
+            if (q < (int)a.nextra) f[(size_t)(6 + q) * a.link_cap + k] = a.ex[q] ? a.ex[q][i] : 0.0;
+    }
+}
+
 int check_pop(const opal_pop_t *p)
 {
     if (!p) {
@@ -915,12 +937,23 @@ double species_charge(const opal_pop_t *p)
 template <int SPECIES, int MODE>
 void launch_push(const PushArgs &a, unsigned nblk, int extras, hipStream_t s)
 {
+    // SENDX: leavers note their slot for k_pack_extras (links that carry the extras); a separate variant
+    // because the four registers it costs would take the plain kernel from 5 to 4 waves per SIMD
+    if (a.send_nextra && MODE != MODE_DEPOSIT) {
+        if (SPECIES != OPAL_ION && extras == 2)
+            k_push<SPECIES, MODE, true, (SPECIES == OPAL_ELECTRON ? 2 : 1), true><<<nblk, BLOCK, 0, s>>>(a);
+        else if (SPECIES != OPAL_ION && extras)
+            k_push<SPECIES, MODE, true, 1, true><<<nblk, BLOCK, 0, s>>>(a);
+        else
+            k_push<SPECIES, MODE, true, 0, true><<<nblk, BLOCK, 0, s>>>(a);
+        return;
+    }
     if (SPECIES != OPAL_ION && extras == 2 && MODE != MODE_DEPOSIT)
-        k_push<SPECIES, MODE, true, (SPECIES == OPAL_ELECTRON ? 2 : 1)><<<nblk, BLOCK, 0, s>>>(a);
+        k_push<SPECIES, MODE, true, (SPECIES == OPAL_ELECTRON ? 2 : 1), false><<<nblk, BLOCK, 0, s>>>(a);
     else if (SPECIES != OPAL_ION && extras && MODE != MODE_DEPOSIT)
-        k_push<SPECIES, MODE, true, 1><<<nblk, BLOCK, 0, s>>>(a);
+        k_push<SPECIES, MODE, true, 1, false><<<nblk, BLOCK, 0, s>>>(a);
     else
-        k_push<SPECIES, MODE, true, 0><<<nblk, BLOCK, 0, s>>>(a);
+        k_push<SPECIES, MODE, true, 0, false><<<nblk, BLOCK, 0, s>>>(a);
 }
 
 int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode, PushArgs &a, unsigned &nblk)
@@ -1007,7 +1040,7 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
 // electrons and ions of one step in a single launch (fused pass only)
 int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt)
 {
-    if (pe->n_upper == 0 || pi->n_upper == 0 || pe->extras || pe->stream != pi->stream) {
+    if (pe->n_upper == 0 || pi->n_upper == 0 || pe->extras || pe->stream != pi->stream || (link && link->nfields > 6)) {
         if (int rc = run_push(pe, link, g, dt, MODE_FUSED)) return rc;
         return run_push(pi, link, g, dt, MODE_FUSED);
     }
@@ -1070,6 +1103,23 @@ bool needs_link(const opal_grid_t *g)
     return g->ngrids > 1 && (g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL);
 }
 
+int pack_leaver_extras(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
+{
+    if (link->nfields <= 6 || p->n_upper == 0) return OPAL_OK;
+    PackExtrasArgs a;
+    memset(&a, 0, sizeof a);
+    a.send[0] = g->left_bdy == OPAL_BDY_INTERNAL ? link_send(link, 0) : nullptr;
+    a.send[1] = g->right_bdy == OPAL_BDY_INTERNAL ? link_send(link, 1) : nullptr;
+    a.slot = p->species;
+    a.species_off = link_species_offset(link, a.slot);
+    a.link_cap = (unsigned)link->cap;
+    a.nextra = (unsigned)(link->nfields - 6);
+    for (int q = 0; q < NEX; q++) a.ex[q] = p->extras ? p->d_ex[q] : nullptr;
+    k_pack_extras<<<2, 256, 0, p->stream>>>(a);
+    OPAL_HIP(hipGetLastError());
+    return OPAL_OK;
+}
+
 // Population::advance's exchange (mod.rs:303-354) for one species on its own: push, then one
 // whole-message exchange, then append the arrivals.
 int advance_with_exchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode)
@@ -1081,6 +1131,7 @@ int advance_with_exchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, doub
     }
     if (int rc = link_begin(link, p->stream)) return rc;
     if (int rc = run_push(p, link, g, dt, mode)) return rc;
+    if (int rc = pack_leaver_extras(p, link, g)) return rc;
     if (int rc = link_exchange(link, link->nbytes, g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL, p->stream)) return rc;
     return unpack_arrivals(p, link, g);
 }
@@ -1592,14 +1643,18 @@ int pop_check_err(opal_pop_t *p) { return check_pop_err(p); }
 int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt)
 {
     p->prev_valid = false;
-    return run_push(p, link, g, dt, MODE_FUSED);
+    if (int rc = run_push(p, link, g, dt, MODE_FUSED)) return rc;
+    return link ? pack_leaver_extras(p, link, g) : OPAL_OK;
 }
 // both species of a fused step in one launch; no exchange, no re-binning bookkeeping
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt)
 {
     pe->prev_valid = false;
     pi->prev_valid = false;
-    return run_push_pair(pe, pi, link, g, dt);
+    if (int rc = run_push_pair(pe, pi, link, g, dt)) return rc;
+    if (!link) return OPAL_OK;
+    if (int rc = pack_leaver_extras(pe, link, g)) return rc;
+    return pack_leaver_extras(pi, link, g);
 }
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
 // room for `extra` more particles behind the slots in use
