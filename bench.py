@@ -115,7 +115,15 @@ def main():
     ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU,
                     help="other BASELINE configs, e.g. configs[2] on one GPU: --cells-per-gpu 32768 --npc 1526")
     ap.add_argument("--unfused", action="store_true", help="time the reference's operator sequence instead")
+    ap.add_argument("--self-exchange", action="store_true",
+                    help="N=1 rehearsal of the multi-GPU step: the lone periodic subdomain sends its halo and leavers "
+                         "to itself through RCCL (pack kernels, torch.distributed P2P, unpack) instead of wrapping in place")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: everything else that libraries print there (RCCL's version banner
+    # at communicator creation, for one) is sent to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import opal_amd as oa
@@ -131,13 +139,35 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     oa.set_device(dev_index)
+    link_kind = os.environ.get("OPAL_BENCH_LINK", "rccl")
+
+    def make_link(r, w, device):
+        """Neighbour transport over RCCL: native (the library issues the send/recv itself on the simulation's
+        stream) unless OPAL_BENCH_LINK=torch asks for the torch.distributed callback."""
+        from opal_amd.exchange import RcclLink, TorchLink
+        nonlocal link_kind
+        if link_kind == "rccl":
+            try:
+                return RcclLink(r, w, device)
+            except Exception as e:  # e.g. no librccl to open: the torch.distributed transport does the same job
+                print(f"[bench] native RCCL link unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
+                link_kind = "torch"
+        return TorchLink(r, w, device)
+
     link = None
+    if args.self_exchange and world == 1:
+        import torch.distributed as dist
+        from opal_amd.exchange import TorchLink
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+        link = make_link(0, 1, torch.device("cuda", dev_index))
     if world > 1:
         import torch.distributed as dist
         from opal_amd.exchange import TorchLink
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-            link = TorchLink(rank, world, torch.device("cuda", dev_index))
+            link = make_link(rank, world, torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
             link = TorchLink(rank, world, torch.device("cpu"))
@@ -149,6 +179,8 @@ def main():
     sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=args.npc), rank=rank, numtasks=world, link=link,
                         stream=stream)
     sim.set_fused(not args.unfused)
+    if args.self_exchange and world == 1:
+        sim.grid.set_self_exchange(True)
     n_local = len(sim.electrons) + len(sim.ions)
 
     def barrier():
@@ -222,7 +254,10 @@ def main():
                 "particles_total": n_total,
                 "cells_total": nx,
                 "path": "fused advance+deposit" if not args.unfused else "advance, clear, deposit (reference order)",
-                "parallelism": f"{world} subdomain(s), 1 per GPU",
+                "parallelism": f"{world} subdomain(s), 1 per GPU"
+                               + (", self-exchange through RCCL (multi-GPU step rehearsed on one GPU)" if args.self_exchange else "")
+                               + (f", neighbour exchange: {'native RCCL send/recv' if link_kind == 'rccl' else 'torch.distributed P2P'}"
+                                  if link is not None and backend == "nccl" else ""),
                 "frac_of_hbm_roofline_whole_step": value * BYTES_PER_UPDATE / (world * HBM_PEAK_GBS * 1e9),
             },
             "roofline": {
@@ -243,8 +278,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             del sim
             out["cpu_baseline"] = cpu_baseline(oa)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or args.self_exchange:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

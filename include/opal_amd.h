@@ -87,6 +87,10 @@ int opal_grid_build(opal_grid_t **out, int id, int numtasks, int left, int right
 int opal_grid_free(opal_grid_t *g);
 int opal_grid_rank(const opal_grid_t *g);          /* yee.rs:321 */
 int opal_grid_ngrids(const opal_grid_t *g);        /* yee.rs:325 */
+/* A lone periodic subdomain is its own neighbour (yee.rs:365-370, mod.rs:313-326: self-copy).  By default
+ * that is done in place; with on != 0 its halo and leavers go through the link instead (to itself), which
+ * drives the whole multi-subdomain machinery -- packing, transport, unpacking -- on one GPU. */
+int opal_grid_set_self_exchange(opal_grid_t *g, int on);
 int opal_grid_to_left(const opal_grid_t *g);       /* yee.rs:329; -1 = None */
 int opal_grid_to_right(const opal_grid_t *g);      /* yee.rs:337; -1 = None */
 double opal_grid_xmin(const opal_grid_t *g);       /* yee.rs:531 */
@@ -236,6 +240,16 @@ int opal_link_create(opal_link_t **out, int rank, int size, int device_buffers, 
 int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_buffers, size_t particle_capacity,
                             int species_slots, int fields_per_particle, opal_exchange_fn exchange, void *user,
                             void *hip_stream);
+/* Native transport: the exchange is four RCCL point-to-point calls (send left, send right, receive right,
+ * receive left) in one group on `hip_stream`, the stream the simulation runs on -- no host-language callback,
+ * no second stream.  `librccl_path` is opened with dlopen (pass the copy the process already uses, e.g.
+ * PyTorch's torch/lib/librccl.so); `unique_id` is the 128-byte ncclUniqueId that rank 0 obtained from
+ * opal_rccl_unique_id and handed to every subdomain (any broadcast will do).  Collective: every subdomain
+ * must call it. */
+#define OPAL_RCCL_UNIQUE_ID_BYTES 128
+int opal_rccl_unique_id(const char *librccl_path, void *id128);
+int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle_capacity, int species_slots,
+                          int fields_per_particle, const char *librccl_path, const void *unique_id, void *hip_stream);
 int opal_link_free(opal_link_t *l);
 /* bytes per direction of a whole message (halo + both species' leavers) and of its halo-only prefix;
  * the `nbytes` passed to the exchange callback is always one of the two */

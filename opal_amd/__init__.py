@@ -110,6 +110,10 @@ class Grid:
     def xmin(self):
         return self._lib.opal_grid_xmin(self.h)
 
+    def set_self_exchange(self, on=True):
+        """A lone periodic subdomain exchanges with itself through the link instead of wrapping in place."""
+        _check(self._lib.opal_grid_set_self_exchange(self.h, 1 if on else 0))
+
     def clear(self):
         _check(self._lib.opal_grid_clear(self.h))
 

@@ -91,6 +91,8 @@ SIGNATURES = {
     "opal_hist_filename": (C.c_int, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.c_char_p, sz]),
     "opal_pop_write_data": (C.c_int, [vp, vp, C.c_char_p, sz, C.c_char_p, C.POINTER(C.c_char_p), sz]),
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),
+    "opal_rccl_unique_id": (C.c_int, [C.c_char_p, vp]),
+    "opal_link_create_rccl": (C.c_int, [pp, C.c_int, C.c_int, sz, C.c_int, C.c_int, C.c_char_p, vp, vp]),
     "opal_link_create_layout": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.c_int, EXCHANGE_FN, vp, vp]),
     "opal_link_free": (C.c_int, [vp]),
     "opal_link_message_bytes": (sz, [vp]),
@@ -113,6 +115,7 @@ SIGNATURES = {
     "opal_sim_electrons": (vp, [vp]),
     "opal_sim_ions": (vp, [vp]),
     "opal_sim_photons": (vp, [vp]),
+    "opal_grid_set_self_exchange": (C.c_int, [vp, C.c_int]),
     "opal_sim_set_collectives": (C.c_int, [vp, ALLREDUCE_FN, GATHER_FN, vp]),
     "opal_grid_write_rows": (C.c_int, [vp, sz, C.c_char_p, sz]),
     "opal_sim_energies": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),

@@ -289,7 +289,7 @@ int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_
     a.R = g->R;
     a.recv_left = g->left_bdy == OPAL_BDY_INTERNAL ? recv_left : nullptr;
     a.recv_right = g->right_bdy == OPAL_BDY_INTERNAL ? recv_right : nullptr;
-    a.self_periodic = g->ngrids == 1 && g->left_bdy == OPAL_BDY_INTERNAL && g->right_bdy == OPAL_BDY_INTERNAL;
+    a.self_periodic = g->ngrids == 1 && !g->self_link && g->left_bdy == OPAL_BDY_INTERNAL && g->right_bdy == OPAL_BDY_INTERNAL;
     a.left_bdy = g->left_bdy;
     a.right_bdy = g->right_bdy;
     a.laser_y = ly;
@@ -423,6 +423,16 @@ int opal_grid_free(opal_grid_t *g)
 
 int opal_grid_rank(const opal_grid_t *g) { return g ? g->id : -1; }
 int opal_grid_ngrids(const opal_grid_t *g) { return g ? g->ngrids : 0; }
+int opal_grid_set_self_exchange(opal_grid_t *g, int on)
+{
+    if (int rc = check_grid(g)) return rc;
+    if (on && (g->ngrids != 1 || g->left_bdy != OPAL_BDY_INTERNAL || g->right_bdy != OPAL_BDY_INTERNAL)) {
+        set_error("opal_grid_set_self_exchange: only a lone periodic subdomain is its own neighbour");
+        return OPAL_ERR_ARG;
+    }
+    g->self_link = on != 0;
+    return OPAL_OK;
+}
 int opal_grid_to_left(const opal_grid_t *g) { return g && g->left_bdy == OPAL_BDY_INTERNAL ? g->rank_to_left : -1; }
 int opal_grid_to_right(const opal_grid_t *g) { return g && g->right_bdy == OPAL_BDY_INTERNAL ? g->rank_to_right : -1; }
 double opal_grid_xmin(const opal_grid_t *g) { return g ? g->cell_x((size_t)g->L) : 0.0; }
@@ -582,7 +592,7 @@ int opal_grid_synchronize(opal_grid_t *g, opal_link_t *link, opal_fn2 laser_y, o
     }
     bool need_halo = g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL;
     const double *recv_left = nullptr, *recv_right = nullptr;
-    if (need_halo && g->ngrids == 1) {
+    if (need_halo && g->ngrids == 1 && !g->self_link) {
         // yee.rs:365-370, 390-395: a lone periodic subdomain receives its own sends; the overlay
         // kernel reads them straight from the arrays
     } else if (need_halo) {

@@ -29,10 +29,16 @@ size_t link_species_offset(const opal_link_t *l, int slot) { return LINK_HEAD_BY
 char *link_send(opal_link_t *l, int side) { return side == 0 ? l->d_send_left : l->d_send_right; }
 char *link_recv(opal_link_t *l, int side) { return side == 0 ? l->d_recv_left : l->d_recv_right; }
 
+// Leaver counts of the send messages start a step at zero.  The kernel that unpacks a step's arrivals also
+// re-zeroes them (they have been shipped by then) and marks the link clean, so only the first step -- or one
+// after an aborted exchange -- pays for the two memsets.
 int link_begin(opal_link_t *l, hipStream_t st)
 {
-    OPAL_HIP(hipMemsetAsync(l->d_send_left, 0, LINK_HEADER_BYTES, st));
-    OPAL_HIP(hipMemsetAsync(l->d_send_right, 0, LINK_HEADER_BYTES, st));
+    if (!l->counts_clean) {
+        OPAL_HIP(hipMemsetAsync(l->d_send_left, 0, LINK_HEADER_BYTES, st));
+        OPAL_HIP(hipMemsetAsync(l->d_send_right, 0, LINK_HEADER_BYTES, st));
+    }
+    l->counts_clean = false;  // a push is about to count leavers into them
     return OPAL_OK;
 }
 
@@ -118,6 +124,7 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
 int opal_link_free(opal_link_t *l)
 {
     if (!l) return OPAL_OK;
+    if (l->user_free) l->user_free(l->user);
     if (!(l->external && l->device_buffers)) {
         hipFree(l->d_send_left); hipFree(l->d_send_right); hipFree(l->d_recv_left); hipFree(l->d_recv_right);
     }
@@ -155,6 +162,7 @@ int opal_link_set_buffers(opal_link_t *l, void *send_left, void *send_right, voi
         l->h_recv_left = (char *)recv_left; l->h_recv_right = (char *)recv_right;
     }
     l->external = true;
+    l->counts_clean = false;
     return OPAL_OK;
 }
 

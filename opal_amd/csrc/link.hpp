@@ -12,12 +12,14 @@ struct opal_link {
     int rank, size;
     bool device_buffers;
     bool external;  // buffers the transport sees belong to the caller
+    bool counts_clean;  // the send messages' leaver counts are known to be zero (see link_begin)
     size_t cap;     // particles per species per direction
     int nslots;     // species blocks per message: 2 (electrons, ions) or 3 (+ photons)
     int nfields;    // doubles per particle: 6 (x ux uy uz w prev_x) or 12 (+ chi work y z tau id)
     size_t species_bytes, nbytes;
     opal_exchange_fn exchange;
     void *user;
+    void (*user_free)(void *);  // releases `user` with the link (native transports), or null
     hipStream_t stream;
     char *d_send_left, *d_send_right, *d_recv_left, *d_recv_right;  // device side (kernels pack / unpack here)
     char *h_send_left, *h_send_right, *h_recv_left, *h_recv_right;  // host staging when device_buffers == 0

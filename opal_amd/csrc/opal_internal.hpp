@@ -47,6 +47,7 @@ void prof_end(int kernel, hipStream_t s);
 
 struct opal_grid {
     int id, ngrids, rank_to_left, rank_to_right;
+    bool self_link;  // a lone periodic subdomain sends to itself through the link instead of wrapping in place
     int left_bdy, right_bdy;
     int L, R;  // left / right boundary sizes (cells)
     size_t size, len, lenp;

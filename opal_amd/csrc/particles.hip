@@ -729,10 +729,28 @@ struct UnpackArgs {
     int my_size;
 };
 
-__global__ void k_unpack(UnpackArgs a)
+// up to three species per launch (blocks 2 s and 2 s + 1 belong to species s); the first workgroup also
+// zeroes the leaver counts of the send messages for the next step when asked to (they have been shipped)
+struct UnpackBatch {
+    UnpackArgs a[3];
+    int n;
+    unsigned *zero[2];
+};
+
+__device__ void unpack_one(const UnpackArgs &a, int side);
+
+__global__ void k_unpack(UnpackBatch b)
+{
+    if (blockIdx.x == 0 && threadIdx.x < 16) {
+        if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
+        if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
+    }
+    unpack_one(b.a[blockIdx.x >> 1], blockIdx.x & 1);
+}
+
+__device__ void unpack_one(const UnpackArgs &a, int side)
 {
     __shared__ unsigned s_base;
-    int side = blockIdx.x;
     const char *msg = a.recv[side];
     if (!msg) return;
     unsigned count = reinterpret_cast<const unsigned *>(msg)[a.slot];
@@ -976,7 +994,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     a.charge = species_charge(p);
     auto edge = [&](int bdy, int neighbour) {
         if (bdy != OPAL_BDY_INTERNAL) return (int)EDGE_DELETE;  // yee.rs:329-343 -> None -> leavers dropped
-        return neighbour == g->id ? (int)EDGE_WRAP : (int)EDGE_SEND;
+        return (neighbour == g->id && !g->self_link) ? (int)EDGE_WRAP : (int)EDGE_SEND;
     };
     a.left_mode = edge(g->left_bdy, g->rank_to_left);
     a.right_mode = edge(g->right_bdy, g->rank_to_right);
@@ -1057,11 +1075,10 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
 
 int do_sort(opal_pop_t *p, const opal_grid_t *g);
 
-// appends what the neighbours sent (already in the link's recv buffers) to this population
-int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
+// room for a step's arrivals and the kernel arguments that append them to one population
+int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, UnpackArgs &u)
 {
     bool from_left = g->left_bdy == OPAL_BDY_INTERNAL, from_right = g->right_bdy == OPAL_BDY_INTERNAL;
-    if (!from_left && !from_right) return OPAL_OK;
     size_t incoming = ((size_t)from_left + (size_t)from_right) * link->cap;
     if (p->n_upper + incoming > p->cap) {
         // compact first (synchronises); the true slot count replaces the running upper bound
@@ -1073,7 +1090,6 @@ int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
             if (int rc = grow(p, want)) return rc;
         }
     }
-    UnpackArgs u;
     int k = p->cur;
     u.recv[0] = from_left ? link_recv(link, 0) : nullptr;
     u.recv[1] = from_right ? link_recv(link, 1) : nullptr;
@@ -1092,15 +1108,38 @@ int unpack_arrivals(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
     u.ctr = p->d_ctr;
     u.pop_cap = (unsigned)p->cap;
     u.my_size = (int)g->size;
-    k_unpack<<<2, 256, 0, p->stream>>>(u);
-    OPAL_HIP(hipGetLastError());
     p->n_upper += incoming;
+    return OPAL_OK;
+}
+
+// appends what the neighbours sent (already in the link's recv buffers) to the populations, one launch;
+// with zero_counts the send messages' leaver counts are reset for the next step (instead of link_begin)
+int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g, bool zero_counts)
+{
+    if (g->left_bdy != OPAL_BDY_INTERNAL && g->right_bdy != OPAL_BDY_INTERNAL) return OPAL_OK;
+    UnpackBatch b;
+    memset(&b, 0, sizeof b);
+    hipStream_t st = nullptr;
+    for (int i = 0; i < npops && b.n < 3; i++) {
+        if (!pops[i]) continue;
+        if (int rc = prepare_unpack(pops[i], link, g, b.a[b.n])) return rc;
+        st = pops[i]->stream;
+        b.n++;
+    }
+    if (!b.n) return OPAL_OK;
+    if (zero_counts) {
+        b.zero[0] = reinterpret_cast<unsigned *>(link_send(link, 0));
+        b.zero[1] = reinterpret_cast<unsigned *>(link_send(link, 1));
+    }
+    k_unpack<<<2 * b.n, 256, 0, st>>>(b);
+    OPAL_HIP(hipGetLastError());
+    if (zero_counts) link->counts_clean = true;
     return OPAL_OK;
 }
 
 bool needs_link(const opal_grid_t *g)
 {
-    return g->ngrids > 1 && (g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL);
+    return (g->ngrids > 1 || g->self_link) && (g->left_bdy == OPAL_BDY_INTERNAL || g->right_bdy == OPAL_BDY_INTERNAL);
 }
 
 int pack_leaver_extras(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
@@ -1133,7 +1172,7 @@ int advance_with_exchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, doub
     if (int rc = run_push(p, link, g, dt, mode)) return rc;
     if (int rc = pack_leaver_extras(p, link, g)) return rc;
     if (int rc = link_exchange(link, link->nbytes, g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL, p->stream)) return rc;
-    return unpack_arrivals(p, link, g);
+    return unpack_arrivals(&p, 1, link, g, true);
 }
 
 int do_sort(opal_pop_t *p, const opal_grid_t *g)
@@ -1664,9 +1703,14 @@ int pop_reserve(opal_pop_t *p, size_t extra)
     size_t want = p->n_upper + extra;
     return grow(p, want + want / 2);
 }
-int pop_unpack_and_maybe_sort(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
+// the arrivals of every species of a fused linked step in one launch, then each one's re-binning policy;
+// also resets the send messages' leaver counts, so the next step needs no link_begin
+int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g)
 {
-    if (int rc = unpack_arrivals(p, link, g)) return rc;
-    return maybe_sort(p, g);
+    if (int rc = unpack_arrivals(pops, npops, link, g, true)) return rc;
+    for (int i = 0; i < npops; i++)
+        if (pops[i])
+            if (int rc = maybe_sort(pops[i], g)) return rc;
+    return OPAL_OK;
 }
 }

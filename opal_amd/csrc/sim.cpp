@@ -22,7 +22,7 @@ using namespace opal;
 namespace opal {
 int pop_check_err(opal_pop_t *p);
 int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
-int pop_unpack_and_maybe_sort(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g);
+int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
 int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right);
@@ -562,7 +562,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         return OPAL_ERR_ARG;
     }
     LaserPair lp{&s->laser_y, &s->laser_z};
-    const bool linked = s->numtasks > 1 && (opal_grid_to_left(s->grid) >= 0 || opal_grid_to_right(s->grid) >= 0);
+    const bool linked = (s->numtasks > 1 || s->grid->self_link) && (opal_grid_to_left(s->grid) >= 0 || opal_grid_to_right(s->grid) >= 0);
     if (linked && !s->link) {
         set_error("%d subdomains need a link", s->numtasks);
         return OPAL_ERR_ARG;
@@ -580,7 +580,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             opal_grid_t *g = s->grid;
             hipStream_t st = (hipStream_t)s->stream;
             if (int rc = opal_grid_clear(g)) return rc;
-            if (int rc = link_begin(s->link, st)) return rc;
+            if (int rc = link_begin(s->link, st)) return rc;  // free after the first step: the unpack kernel re-zeroes
             if (s->electrons && s->ions) {
                 if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, s->link, g, s->dt)) return rc;
             } else {
@@ -600,10 +600,10 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 lz = 2.0 * r * laser_z_cb(s->t, xs, &lp);
             }
             if (int rc = grid_apply_sync(g, rl, rr, ly, lz)) return rc;
-            if (s->electrons)
-                if (int rc = pop_unpack_and_maybe_sort(s->electrons, s->link, g)) return rc;
-            if (s->ions)
-                if (int rc = pop_unpack_and_maybe_sort(s->ions, s->link, g)) return rc;
+            {
+                opal_pop_t *pops[2] = {s->electrons, s->ions};
+                if (int rc = pops_unpack_and_maybe_sort(pops, 2, s->link, g)) return rc;
+            }
             if (int rc = opal_grid_advance(g, s->dt)) return rc;
             s->t += s->dt;
             s->step_index++;

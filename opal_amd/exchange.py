@@ -117,6 +117,49 @@ class TorchLink:
             return 1
 
 
+def _librccl_path():
+    """The RCCL the process already uses: PyTorch's own copy if there is one, else the system's."""
+    import os
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else "librccl.so"
+
+
+class RcclLink:
+    """opal_link_t with the native transport (rccl_link.cpp): RCCL send/recv issued by the library itself on
+    the simulation's stream.  torch.distributed is only used once, to hand rank 0's ncclUniqueId to the other
+    ranks (any backend), and by the output-time collectives."""
+
+    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False):
+        self._lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("RcclLink moves device buffers: it needs a cuda device")
+        self.transport = NeighbourTransport(rank, world, group) if world > 1 else None
+        path = _librccl_path().encode()
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            if self._lib.opal_rccl_unique_id(path, uid):
+                raise RuntimeError(self._lib.opal_last_error().decode())
+        if world > 1:
+            box = [uid.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = C.create_string_buffer(box[0], 128)
+        slots, fields = (3, 12) if photon_emission else (2, 6)
+        h = C.c_void_p()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.opal_link_create_rccl(C.byref(h), rank, world, particle_capacity, slots, fields, path, uid, stream)
+        if rc:
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        self.h = h
+        self.nbytes = self._lib.opal_link_message_bytes(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._lib.opal_link_free(self.h)
+            self.h = None
+
+
 class TorchCollectives:
     """The output-time reductions of a decomposed run (opal_sim_set_collectives) on torch.distributed:
     energies and histograms are all-reduced, grid rows gathered to rank 0 (the reference's MPI_Reduce /

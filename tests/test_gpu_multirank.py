@@ -253,3 +253,52 @@ def test_launcher_runs_an_input_file(tmp_path, world):
     assert rows.shape == (1000, 11) and np.all(np.diff(rows[:, 0]) > 0)
     e = {k: float(v) for k, v in (line.split() for line in open(tmp_path / "4_energy.dat"))}
     assert e["electrons"] > 0 and e["em_field"] > 0
+
+
+def test_self_exchange_through_rccl_equals_in_place_wrap(tmp_path):
+    """The nccl (= RCCL) transport with device buffers on the one GPU a test box has: a lone periodic subdomain
+    made its own neighbour, so halo and leavers travel pack -> torch.distributed P2P -> unpack every step.
+    Must reproduce the in-place periodic wrap (yee.rs:365-370, mod.rs:313-326)."""
+    import subprocess
+    from test_exchange_gloo import _free_port
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["OPAL_ROOT"]); sys.path.insert(0, os.path.join(os.environ["OPAL_ROOT"], "tests"))
+import opal_amd as oa
+from opal_amd.exchange import RcclLink, TorchLink
+from _gloo_hip_worker import YAML
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+stream = torch.cuda.current_stream().cuda_stream
+out = {}
+for mode in ("wrap", "self", "native"):
+    link = None
+    if mode == "self":
+        link = TorchLink(0, 1, dev, particle_capacity=512)      # torch.distributed P2P callback
+    if mode == "native":
+        link = RcclLink(0, 1, dev, particle_capacity=512)       # the library's own RCCL send/recv
+    sim = oa.Simulation(yaml_text=YAML.format(nx=64, npc=16), rank=0, numtasks=1, link=link, stream=stream)
+    if link is not None:
+        sim.grid.set_self_exchange(True)
+    sim.step(25); sim.sync()
+    out[mode] = {k: sim.grid.raw(k) for k in ("Ex", "Ey", "Ez", "By", "Bz")}
+    for name, p in (("e", sim.electrons), ("i", sim.ions)):
+        s = p.soa(); o = np.lexsort((s["x"], s["ux"], s["w"]))
+        out[mode][name] = {k: v[o] for k, v in s.items()}
+    out[mode]["calls"] = getattr(link, "calls", 0)
+    del sim, link
+assert out["self"]["calls"] == 25, out["self"]["calls"]            # one exchange per step
+for mode in ("self", "native"):
+    for k in ("Ex", "Ey", "Ez", "By", "Bz"):
+        a, b = out[mode][k], out["wrap"][k]
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), (mode, k)
+    for name in ("e", "i"):
+        a, b = out[mode][name], out["wrap"][name]
+        assert len(a["w"]) == len(b["w"]) == 64 * 16
+        assert np.array_equal(a["cell"], b["cell"]) and np.max(np.abs(a["x"] - b["x"])) < 1e-9
+dist.destroy_process_group()
+print("SELF-EXCHANGE OK")
+'''
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OPAL_ROOT=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SELF-EXCHANGE OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
