@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 import opal_amd as oa
-from opal_amd.exchange import TorchLink
+from opal_amd.exchange import RcclLink, TorchLink
 
 
 def main(argv):
@@ -31,9 +31,13 @@ def main(argv):
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": device} if backend == "nccl" else {}))
         emission = oa.Config(path=argv[1]).read_bool("qed", "photon_emission")
-        link = TorchLink(rank, world, device if backend == "nccl" else torch.device("cpu"),
-                         particle_capacity=int(os.environ.get("OPAL_LINK_CAPACITY", "65536")),
-                         photon_emission=emission, stream=torch.cuda.current_stream().cuda_stream)
+        cap = int(os.environ.get("OPAL_LINK_CAPACITY", "65536"))
+        stream = torch.cuda.current_stream().cuda_stream
+        if backend == "nccl" and os.environ.get("OPAL_LINK", "rccl") == "rccl":
+            link = RcclLink(rank, world, device, cap, photon_emission=emission, stream=stream)  # native send/recv
+        else:
+            link = TorchLink(rank, world, device if backend == "nccl" else torch.device("cpu"), cap,
+                             photon_emission=emission, stream=stream)
     try:
         sim = oa.Simulation(yaml_path=argv[1], rank=rank, numtasks=world, link=link,
                             stream=torch.cuda.current_stream().cuda_stream)
