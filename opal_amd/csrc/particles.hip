@@ -48,9 +48,6 @@ constexpr int TILE_MARGIN = OPAL_TILE_MARGIN;  // tile cells below the chunk's l
 #ifndef OPAL_REPL
 #define OPAL_REPL 8
 #endif
-#ifndef OPAL_PF_DEPTH
-#define OPAL_PF_DEPTH 1  // particle slots per lane kept in flight ahead of the one being processed
-#endif
 constexpr int REPL = OPAL_REPL;        // lane-private replicas per accumulator
 constexpr int TILE_LO = 3;      // a particle whose old cell sits at tile offset in [TILE_LO, TILE - 4]
 constexpr int TILE_HI = TILE - 4;  // gathers (rel-1..rel+2) and deposits (rel-3..rel+3) inside the tile
@@ -317,7 +314,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     const unsigned nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
 
     // The first slots' loads go out before anything else: the first cell also decides the tile base, and
-    // the other values are in flight while the tile is set up.  PF_DEPTH slots per lane stay in flight.
+    // the other values are in flight while the tile is set up.  One slot per lane stays in flight.
     struct Slot {
         int c;
         double x, ux, uy, uz, w, prev;
@@ -337,9 +334,6 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     };
     unsigned k = tid;
     Slot s_n = fetch(k, k < nloc);
-#if OPAL_PF_DEPTH == 2
-    Slot s_m = fetch(k + BLOCK, a.ppt > 1 && k + BLOCK < nloc);
-#endif
     const int c_n = s_n.c;
     // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin.  Slots that
     // hold far-away cells (particles that wrapped around a periodic domain, arrivals appended from both
@@ -407,12 +401,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         const double xi = s_n.x, wt = s_n.w, prev = s_n.prev;
         const V3 u = {s_n.ux, s_n.uy, s_n.uz};
         k += BLOCK;
-#if OPAL_PF_DEPTH == 2
-        s_n = s_m;
-        s_m = fetch(k + BLOCK, (p + 2 < a.ppt) && k + BLOCK < nloc);
-#else
-        s_n = fetch(k, (p + 1 < a.ppt) && k < nloc);
-#endif
+        s_n = fetch(k, (p + 1 < a.ppt) && k < nloc);  // one slot per lane in flight (two measured 1.5 % slower)
         if (!live) continue;
         int rel = c + a.L - base;
         bool ok, in_tile;
@@ -1250,8 +1239,8 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
     // costs about 100 ns of kernel time (slow path + the workgroup it delays; tuned on the two-stream
     // bench, scripts/sustained_probe.py); once the time lost to misses since the last re-binning exceeds
     // what a re-binning costs, re-bin.
-    static const int check_every = getenv("OPAL_DEBUG_CHECK") ? atoi(getenv("OPAL_DEBUG_CHECK")) : 4;
-    static const double miss_ns = getenv("OPAL_DEBUG_MISSNS") ? atof(getenv("OPAL_DEBUG_MISSNS")) : 100.0;
+    constexpr int check_every = 4;
+    constexpr double miss_ns = 100.0;
     if (p->steps_since_sort % check_every != 0) return OPAL_OK;
     // The counters are copied to pinned memory asynchronously and read at the NEXT check, 8 steps later:
     // waiting for that older copy keeps the host at most ~16 steps ahead of the device (so the policy sees
@@ -1306,7 +1295,6 @@ int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_st
     p->sort_interval = -1;
     p->keep_prev = true;
     p->ppt = 8;
-    if (const char *e = getenv("OPAL_DEBUG_PPT")) p->ppt = std::max(1, std::min(32, atoi(e)));
     if (int rc = alloc_set(p, 0)) return rc;
     OPAL_HIP(hipMalloc(&p->d_ctr, sizeof(PopCounters)));
     OPAL_HIP(hipHostMalloc(&p->h_ctr, sizeof(PopCounters)));
