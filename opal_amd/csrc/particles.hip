@@ -1673,6 +1673,17 @@ int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, 
     if (int rc = run_push(p, link, g, dt, MODE_FUSED)) return rc;
     return link ? pack_leaver_extras(p, link, g) : OPAL_OK;
 }
+// Population::advance's push (separate-operator order) without its exchange: leavers are packed into the
+// link's messages, which the caller ships once for all species
+int pop_push_advance_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt)
+{
+    const bool prev = p->keep_prev && p->species != OPAL_PHOTON;
+    if (prev)
+        if (int rc = ensure_prev(p)) return rc;
+    p->prev_valid = prev;
+    if (int rc = run_push(p, link, g, dt, MODE_ADVANCE)) return rc;
+    return link ? pack_leaver_extras(p, link, g) : OPAL_OK;
+}
 // both species of a fused step in one launch; no exchange, no re-binning bookkeeping
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt)
 {

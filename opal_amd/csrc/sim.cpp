@@ -22,6 +22,7 @@ using namespace opal;
 namespace opal {
 int pop_check_err(opal_pop_t *p);
 int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
+int pop_push_advance_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
@@ -572,7 +573,57 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                   "particle (opal_link_create_layout): optical depths, ids and photons migrate too");
         return OPAL_ERR_LINK;
     }
+    // yee.rs:456-462: the laser is injected by rank 0 at one cell, at the pre-increment time
+    auto laser_now = [&](double &ly, double &lz) {
+        ly = lz = 0.0;
+        opal_grid_t *g = s->grid;
+        if (s->has_laser && opal_grid_rank(g) == 0) {
+            double xs = g->cell_x((size_t)(g->L - 2));
+            double r = 2.997925e8 * s->dt / s->dx;
+            ly = 2.0 * r * laser_y_cb(s->t, xs, &lp);
+            lz = 2.0 * r * laser_z_cb(s->t, xs, &lp);
+        }
+    };
     for (size_t k = 0; k < n; k++) {
+        if (linked && !(s->fused && s->current_deposition && !s->photon_emission)) {
+            // The reference's operator order across subdomains (main.rs:240-267) with the leavers of every
+            // species in ONE message per neighbour.  Without current deposition the halo does not depend on
+            // the particles and rides along (one exchange per step); with it the halo follows the deposit in
+            // a second, 704-byte exchange.
+            opal_grid_t *g = s->grid;
+            hipStream_t st = (hipStream_t)s->stream;
+            opal_pop_t *pops[3] = {s->electrons, s->ions, s->photon_emission ? s->photons : nullptr};
+            const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
+            if (int rc = link_begin(s->link, st)) return rc;
+            for (opal_pop_t *p : pops)
+                if (p)
+                    if (int rc = pop_push_advance_noexchange(p, s->link, g, s->dt)) return rc;
+            const double *rl = nullptr, *rr = nullptr;
+            if (!s->current_deposition)
+                if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr)) return rc;
+            if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, st)) return rc;
+            if (int rc = pops_unpack_and_maybe_sort(pops, 3, s->link, g)) return rc;
+            if (s->photon_emission && s->electrons)  // main.rs:250-252
+                if (int rc = opal_emit_radiation(s->electrons, s->photons, s->emission_seed, (uint32_t)s->step_index, s->t,
+                                                 s->photon_energy_min, s->photon_angle_max, s->max_formation_length,
+                                                 nullptr))
+                    return rc;
+            if (s->current_deposition) {  // main.rs:254-258
+                if (int rc = opal_grid_clear(g)) return rc;
+                if (s->electrons)
+                    if (int rc = opal_grid_deposit(g, s->electrons, s->dt)) return rc;
+                if (s->ions)
+                    if (int rc = opal_grid_deposit(g, s->ions, s->dt)) return rc;
+                if (int rc = grid_exchange_halo(g, s->link, true, &rl, &rr)) return rc;
+            }
+            double ly, lz;
+            laser_now(ly, lz);
+            if (int rc = grid_apply_sync(g, rl, rr, ly, lz)) return rc;
+            if (int rc = opal_grid_advance(g, s->dt)) return rc;
+            s->t += s->dt;
+            s->step_index++;
+            continue;
+        }
         if (linked && s->fused && s->current_deposition && !s->photon_emission) {
             // One exchange per step: leavers of both species and the halo travel in the same message.
             // Leavers have already deposited into this subdomain's ghost cells, which the halo overlay
@@ -592,13 +643,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             const double *rl = nullptr, *rr = nullptr;
             if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr)) return rc;
             if (int rc = link_exchange(s->link, s->link->nbytes, opal_grid_to_left(g) >= 0, opal_grid_to_right(g) >= 0, st)) return rc;
-            double ly = 0.0, lz = 0.0;
-            if (s->has_laser && opal_grid_rank(g) == 0) {  // yee.rs:456-462
-                double xs = g->cell_x((size_t)(g->L - 2));
-                double r = 2.997925e8 * s->dt / s->dx;
-                ly = 2.0 * r * laser_y_cb(s->t, xs, &lp);
-                lz = 2.0 * r * laser_z_cb(s->t, xs, &lp);
-            }
+            double ly, lz;
+            laser_now(ly, lz);
             if (int rc = grid_apply_sync(g, rl, rr, ly, lz)) return rc;
             {
                 opal_pop_t *pops[2] = {s->electrons, s->ions};

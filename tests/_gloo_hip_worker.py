@@ -144,7 +144,9 @@ def main():
             t += dt
         dump(outdir, rank, g, pe, pi)
     elif mode == "qed":
-        sim = oa.Simulation(yaml_text=QED_YAML, rank=rank, numtasks=world, link=link)
+        deposit = nx == 1  # argv[3] doubles as the current_deposition switch in this mode
+        text = QED_YAML.replace("current_deposition: false", "current_deposition: true") if deposit else QED_YAML
+        sim = oa.Simulation(yaml_text=text, rank=rank, numtasks=world, link=link)
         out = {}
         tau, ids = sim.electrons.emission_state()
         for k, v in sim.electrons.soa().items():
@@ -168,6 +170,8 @@ def main():
         out["fe"] = sim.grid.em_field_energy()
         out["Ey"] = sim.grid.raw("Ey")
         out["t"] = sim.t
+        # leavers of all three species in one message; with deposition a second, halo-only one
+        assert link.calls == nsteps * (2 if deposit else 1), (link.calls, nsteps)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     elif mode == "run":
         # the whole of main(): outputs included (grid rows gathered, energies and histograms reduced)
@@ -215,7 +219,8 @@ def main():
         sim.sync()
         dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
         if link is not None:
-            assert link.calls == (steps if fused else 3 * steps), link.calls
+            # one message per neighbour per step when fused; leavers (all species) + a halo-only message otherwise
+            assert link.calls == (steps if fused else 2 * steps), link.calls
     dist.barrier()
     dist.destroy_process_group()
 

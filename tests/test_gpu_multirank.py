@@ -64,14 +64,15 @@ def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused
     assert total == nx * npc
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world):
-    """The YAML driver's linked step (leavers of both species + halo in ONE message per neighbour)."""
+@pytest.mark.parametrize("world,fused", [(2, 1), (2, 0)])
+def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused):
+    """The YAML driver's linked step: leavers of both species + halo in ONE message per neighbour (fused), or
+    the reference's operator order with the leavers in one message and the halo in a second (fused = 0)."""
     o = oracle
     nx, npc, steps = 64, 16, 15
     dx = 1.0e-8
     dt = 0.95 * dx / C
-    _launch("_gloo_hip_worker.py", world, ["sim", tmp_path, nx, npc, steps, 1])
+    _launch("_gloo_hip_worker.py", world, ["sim", tmp_path, nx, npc, steps, fused])
     got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     st_e = [tuple(g[f"init_e_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
     st_i = [tuple(g[f"init_i_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
@@ -121,8 +122,8 @@ def test_receiving_subdomain_grows_its_storage(oracle, tmp_path):
         assert len(a["x"]) == 0 or np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_photon_emission_across_subdomains(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,deposit", [(2, 0), (3, 0), (2, 1)])
+def test_photon_emission_across_subdomains(oracle, tmp_path, world, deposit):
     """Config C5's physics decomposed: electrons carry their optical depths and ids across the cuts, photons
     (emitted and pre-loaded) migrate and leave through the open ends; against the oracle with the same
     decomposition, started from the driver's own initial state."""
@@ -130,7 +131,7 @@ def test_photon_emission_across_subdomains(oracle, tmp_path, world):
     o = oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _gloo_hip_worker import QED_YAML
-    _launch("_gloo_hip_worker.py", world, ["qed", tmp_path, 0, 0, 0, 0])
+    _launch("_gloo_hip_worker.py", world, ["qed", tmp_path, deposit, 0, 0, 0])
     got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
     cfgp = tmp_path / "cb.yaml"
     cfgp.write_text(QED_YAML)
@@ -158,6 +159,10 @@ def test_photon_emission_across_subdomains(oracle, tmp_path, world):
         assert o.world_pop_advance(phs, grids, dt) == 0
         for r in range(world):
             o.emit_radiation(pes[r], phs[r], seed, k, t, max_angle=0.05)
+        if deposit:  # main.rs:254-258: after the emission, so with the recoiled velocities
+            for r in range(world):
+                grids[r].clear()
+                assert grids[r].deposit(pes[r], dt) == 0
         o.world_synchronize(grids, ly, None, t, dt)
         for g in grids:
             g.advance(dt)
