@@ -516,3 +516,51 @@ def test_colliding_beams_outputs(tmp_path):
     e0 = {k: float(v) for k, v in (line.split() for line in open(tmp_path / "0_energy.dat"))}
     assert e0["photons"] == 0.0 and e["photons"] > 0.0
     assert e["electrons"] < e0["electrons"]
+
+
+@pytest.mark.filterwarnings("ignore")
+def test_emission_statistics_in_a_static_magnetic_field(oa):
+    """End to end against the physics rather than the oracle: electrons of gamma = 1000 gyrating in a uniform
+    B with chi = 0.5 for four steps.  Number of photons = N * rate * T (Poisson) and mean photon energy
+    = int f dN / int dN of the quantum synchrotron spectrum (quadrature), within statistics."""
+    from scipy.integrate import quad
+    from test_qed_oracle import _marginal
+    nx, n, dx = 64, 60000, 1.0e-8
+    dt = 0.5 * dx / C
+    gamma, chi, steps = 1000.0, 0.5, 4
+    u0 = math.sqrt(gamma ** 2 - 1.0)
+    bz = chi * 1.323285e18 / (u0 * C)
+    g = oa.Grid.single(nx, 0.0, dx)
+    g.set_raw("Bz", np.full(g.len, bz))
+    rng = np.random.default_rng(61)
+    phi = rng.uniform(0, 2 * math.pi, n)
+    cell = np.sort(rng.integers(0, nx, n)).astype(np.int32)
+    p = oa.Population(oa.ELECTRON, 2 * n)
+    p.track_extras(2)
+    p.upload(cell, rng.random(n), u0 * np.cos(phi), u0 * np.sin(phi), np.zeros(n), np.ones(n), dx, dt)
+    p.set_emission_state(rng.exponential(size=n), np.arange(n, dtype=np.uint64))
+    ph = oa.Population(PHOTON, 1024)
+    ke0 = p.total_kinetic_energy()
+    emitted = 0
+    for step in range(steps):
+        p.advance(g, dt)
+        ph.advance(g, dt)
+        emitted += oa.emit_radiation(p, ph, seed=123, step=step, t=step * dt)
+    assert np.allclose(p.extras()["chi"].mean(), chi * (p.total_kinetic_energy() / ke0), rtol=0.02)
+    rate = oa.qed_rate([chi], gamma)[0]
+    expect = n * rate * steps * dt
+    assert 0.15 * n < expect < 0.3 * n
+    # recoil lowers gamma (and with it chi and the rate) by about half the radiated fraction over the run
+    s = ph.soa()
+    f = np.sqrt(s["ux"] ** 2 + s["uy"] ** 2 + s["uz"] ** 2) / gamma
+    lost = f.sum() / n
+    assert abs(emitted - expect * (1.0 - 0.5 * lost)) < 4.0 * math.sqrt(expect) + 0.01 * expect
+    gq = lambda l: _marginal(np.exp(l), chi) * np.exp(l)
+    num = quad(lambda l: gq(l) * np.exp(l) / (1.0 + np.exp(l)), -50.0, np.log(40.0 * chi), limit=400)[0]
+    den = quad(gq, -50.0, np.log(40.0 * chi), limit=400)[0]
+    assert abs(f.mean() - num / den) < 4.0 * f.std() / math.sqrt(len(f)) + 0.02 * num / den
+    # energy is conserved between electrons and photons (a static B does no work)
+    assert (ke0 - p.total_kinetic_energy()) == pytest.approx(ph.total_kinetic_energy(), rel=2e-3)
+    # photons are beamed along the electron's motion, i.e. into the x-y plane: angles of a few 1 / gamma
+    # (soft photons wider, ~ (omega_c / omega)^(1/3) / gamma), against 0.5 for an isotropic source
+    assert np.abs(s["uz"] / (f * gamma)).mean() < 20.0 / gamma
