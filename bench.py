@@ -140,6 +140,10 @@ def main():
     torch.cuda.set_device(dev_index)
     oa.set_device(dev_index)
     link_kind = os.environ.get("OPAL_BENCH_LINK", "rccl")
+    # leavers per species, neighbour and step that a message has room for: the two-stream flux through a cut is
+    # npc * <|v_x|> dt / dx ~ 2441 * 0.009 ~ 25 per step, so 1024 is 40x headroom (an overflow is reported, not
+    # silent); messages are fixed-size, 704 B + 2 species * 1024 * 52 B = 107 KB per neighbour per step
+    LINK_CAPACITY = 1024
 
     def make_link(r, w, device):
         """Neighbour transport over RCCL: native (the library issues the send/recv itself on the simulation's
@@ -148,11 +152,11 @@ def main():
         nonlocal link_kind
         if link_kind == "rccl":
             try:
-                return RcclLink(r, w, device)
+                return RcclLink(r, w, device, particle_capacity=LINK_CAPACITY)
             except Exception as e:  # e.g. no librccl to open: the torch.distributed transport does the same job
                 print(f"[bench] native RCCL link unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
                 link_kind = "torch"
-        return TorchLink(r, w, device)
+        return TorchLink(r, w, device, particle_capacity=LINK_CAPACITY)
 
     link = None
     if args.self_exchange and world == 1:
