@@ -152,6 +152,8 @@ def main():
         nonlocal link_kind
         if link_kind == "rccl":
             try:
+                if os.environ.get("OPAL_BENCH_EXACT"):  # diagnostic: big buffers, messages sized to their content
+                    return RcclLink(r, w, device, particle_capacity=1 << 18, exact=True)
                 return RcclLink(r, w, device, particle_capacity=LINK_CAPACITY)
             except Exception as e:  # e.g. no librccl to open: the torch.distributed transport does the same job
                 print(f"[bench] native RCCL link unavailable ({e}); using torch.distributed P2P", file=sys.stderr)

@@ -250,6 +250,10 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
 int opal_rccl_unique_id(const char *librccl_path, void *id128);
 int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle_capacity, int species_slots,
                           int fields_per_particle, const char *librccl_path, const void *unique_id, void *hip_stream);
+/* on != 0: whole-message exchanges ship the 704-byte head first and then only the occupied part of every
+ * column (one host synchronisation per exchange) instead of all `particle_capacity` slots: for links sized
+ * for a large peak flux.  Off by default. */
+int opal_link_set_exact(opal_link_t *l, int on);
 int opal_link_free(opal_link_t *l);
 /* bytes per direction of a whole message (halo + both species' leavers) and of its halo-only prefix;
  * the `nbytes` passed to the exchange callback is always one of the two */

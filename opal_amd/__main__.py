@@ -31,10 +31,15 @@ def main(argv):
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": device} if backend == "nccl" else {}))
         emission = oa.Config(path=argv[1]).read_bool("qed", "photon_emission")
+        # room for the leavers of one step through one cut, per species (an overflow is reported as an error).
+        # Messages normally have a fixed size -- all slots travel every step; OPAL_LINK_EXACT=1 sizes them to
+        # their content instead (two RCCL groups and a host synchronisation per step: worth it only for links
+        # that need a very large capacity, e.g. a dense beam crossing the cuts)
         cap = int(os.environ.get("OPAL_LINK_CAPACITY", "65536"))
         stream = torch.cuda.current_stream().cuda_stream
         if backend == "nccl" and os.environ.get("OPAL_LINK", "rccl") == "rccl":
-            link = RcclLink(rank, world, device, cap, photon_emission=emission, stream=stream)  # native send/recv
+            link = RcclLink(rank, world, device, cap, photon_emission=emission, stream=stream,
+                            exact=os.environ.get("OPAL_LINK_EXACT", "0") == "1")  # native RCCL send/recv
         else:
             link = TorchLink(rank, world, device if backend == "nccl" else torch.device("cpu"), cap,
                              photon_emission=emission, stream=stream)

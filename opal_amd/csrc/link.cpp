@@ -13,7 +13,10 @@
 // S = 2 and 6 fields by default; runs with photon emission use S = 3 and 12 fields (the reference ships
 // whole structs, so optical depths and ids must travel with an electron that changes subdomain).
 // A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes; anything with particles moves
-// the whole message.  What a subdomain sends left arrives as its left neighbour's "recv_right".
+// the whole message -- all P slots of every column, because the receiver cannot know the counts before they
+// arrive -- unless the transport offers an exact-size exchange (rccl_link.cpp: head first, then only the
+// occupied part of every column, at the price of one host synchronisation per exchange).
+// What a subdomain sends left arrives as its left neighbour's "recv_right".
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
@@ -48,6 +51,10 @@ int link_exchange(opal_link_t *l, size_t nbytes, bool to_left, bool to_right, hi
     if (nbytes > l->nbytes) {
         set_error("link_exchange: %zu bytes exceed the link's message size %zu", nbytes, l->nbytes);
         return OPAL_ERR_ARG;
+    }
+    if (l->exchange_exact && nbytes == l->nbytes) {
+        if (l->exchange_exact(l, to_left, to_right, st)) return OPAL_ERR_LINK;  // the callee has set the error text
+        return OPAL_OK;
     }
     if (!l->device_buffers) {
         if (to_left) OPAL_HIP(hipMemcpyAsync(l->h_send_left, l->d_send_left, nbytes, hipMemcpyDeviceToHost, st));

@@ -129,7 +129,10 @@ class RcclLink:
     the simulation's stream.  torch.distributed is only used once, to hand rank 0's ncclUniqueId to the other
     ranks (any backend), and by the output-time collectives."""
 
-    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False):
+    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False,
+                 exact=False):
+        """exact: size every message to the leavers it holds (one host synchronisation per exchange) instead of
+        shipping all particle_capacity slots: for links that must have room for a large peak flux."""
         self._lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -153,6 +156,8 @@ class RcclLink:
             raise RuntimeError(self._lib.opal_last_error().decode())
         self.h = h
         self.nbytes = self._lib.opal_link_message_bytes(h)
+        if exact and self._lib.opal_link_set_exact(h, 1):
+            raise RuntimeError(self._lib.opal_last_error().decode())
 
     def __del__(self):
         if getattr(self, "h", None):

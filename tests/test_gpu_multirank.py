@@ -276,12 +276,14 @@ dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 stream = torch.cuda.current_stream().cuda_stream
 out = {}
-for mode in ("wrap", "self", "native"):
+for mode in ("wrap", "self", "native", "exact"):
     link = None
     if mode == "self":
         link = TorchLink(0, 1, dev, particle_capacity=512)      # torch.distributed P2P callback
     if mode == "native":
         link = RcclLink(0, 1, dev, particle_capacity=512)       # the library's own RCCL send/recv
+    if mode == "exact":                                         # ... shipping only the occupied slots
+        link = RcclLink(0, 1, dev, particle_capacity=1 << 18, exact=True)
     sim = oa.Simulation(yaml_text=YAML.format(nx=64, npc=16), rank=0, numtasks=1, link=link, stream=stream)
     if link is not None:
         sim.grid.set_self_exchange(True)
@@ -293,7 +295,7 @@ for mode in ("wrap", "self", "native"):
     out[mode]["calls"] = getattr(link, "calls", 0)
     del sim, link
 assert out["self"]["calls"] == 25, out["self"]["calls"]            # one exchange per step
-for mode in ("self", "native"):
+for mode in ("self", "native", "exact"):
     for k in ("Ex", "Ey", "Ez", "By", "Bz"):
         a, b = out[mode][k], out["wrap"][k]
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), (mode, k)
