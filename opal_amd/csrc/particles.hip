@@ -37,6 +37,9 @@ int grid_check_err(const opal_grid_t *g);
 namespace {
 
 constexpr int BLOCK = 256;
+#ifndef OPAL_MAX_PPT
+#define OPAL_MAX_PPT 8  // particles per thread of a push workgroup, at most
+#endif
 #ifndef OPAL_TILE
 #define OPAL_TILE 64
 #endif
@@ -1225,7 +1228,7 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
     double per_cell = (double)p->h_ctr->n_live / ne;
     int ppt = (int)((TILE / 4) * per_cell / BLOCK);
-    p->ppt = std::max(1, std::min(8, ppt));
+    p->ppt = std::max(1, std::min(OPAL_MAX_PPT, ppt));
     return OPAL_OK;
 }
 
@@ -1296,7 +1299,7 @@ int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_st
     p->z_star = p->z = p->a = 1.0;  // ion.rs:93-95
     p->sort_interval = -1;
     p->keep_prev = true;
-    p->ppt = 8;
+    p->ppt = OPAL_MAX_PPT;
     if (int rc = alloc_set(p, 0)) return rc;
     OPAL_HIP(hipMalloc(&p->d_ctr, sizeof(PopCounters)));
     OPAL_HIP(hipHostMalloc(&p->h_ctr, sizeof(PopCounters)));
