@@ -88,6 +88,10 @@ struct opal_pop {
     double *d_ex_alt[opal::NEX];  // re-binning targets, allocated on first use
     unsigned int *d_emit_list;    // slots of this step's emitters (photon emission), emit_list_cap entries
     size_t emit_list_cap;
+    hipEvent_t upper_event;       // asynchronous snapshots of n_slots that tighten n_upper (see pop_tighten_upper)
+    unsigned int *h_upper;        // pinned
+    bool upper_pending;
+    size_t added_since_snapshot;
     unsigned long long id_base;   // ids of freshly uploaded particles are id_base + slot (set per subdomain)
     int extras;  // 0 off, 1 diagnostics, 2 + optical depth / id for photon emission
     double z_star, z, a;

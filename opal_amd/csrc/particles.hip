@@ -818,6 +818,11 @@ int check_pop_err(opal_pop_t *p)
 {
     if (int rc = fetch_counters(p)) return rc;
     int err = p->h_ctr->err;
+    if (p->h_ctr->n_lost) {
+        OPAL_HIP(hipMemsetAsync(&p->d_ctr->n_lost, 0, sizeof(unsigned), p->stream));
+        set_error("%u emitted photons found no free slot", p->h_ctr->n_lost);
+        return OPAL_ERR_CAPACITY;
+    }
     if (err) {
         OPAL_HIP(hipMemsetAsync(&p->d_ctr->err, 0, sizeof(int), p->stream));
         if (err & 8) {
@@ -827,6 +832,11 @@ int check_pop_err(opal_pop_t *p)
         if (err & 16) {
             set_error("population capacity exceeded by arrivals from a neighbouring subdomain");
             return OPAL_ERR_CAPACITY;
+        }
+        if (err & 32) {
+            set_error("photon emission at chi >= 100, which the reference's sampler does not implement "
+                      "(photon_emission.rs:143-144 unimplemented!())");
+            return OPAL_ERR_ASSERT;
         }
         set_error("particle invariant violated on device (flags 0x%x):%s%s%s", err,
                   (err & 1) ? " moved >= 1 cell in a step (electron.rs:313 / ion.rs:199);" : "",
@@ -1103,6 +1113,7 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     u.pop_cap = (unsigned)p->cap;
     u.my_size = (int)g->size;
     p->n_upper += incoming;
+    p->added_since_snapshot += incoming;
     return OPAL_OK;
 }
 
@@ -1219,6 +1230,10 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
         if (sa.oex[q]) std::swap(p->d_ex[q], p->d_ex_alt[q]);
     p->cur = o;
     p->n_upper = p->h_ctr->n_slots;
+    if (p->upper_pending) {  // a snapshot from before the compaction: no longer a bound worth having
+        hipEventSynchronize(p->upper_event);
+        p->upper_pending = false;
+    }
     p->steps_since_sort = 0;
     if (p->ctr_pending) {
         hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
@@ -1324,6 +1339,8 @@ int opal_pop_free(opal_pop_t *p)
     }
     if (p->d_count) hipFree(p->d_count);
     if (p->d_emit_list) hipFree(p->d_emit_list);
+    if (p->upper_event) hipEventDestroy(p->upper_event);
+    if (p->h_upper) hipHostFree(p->h_upper);
     hipFree(p->d_partial);
     hipFree(p->d_ctr);
     hipHostFree(p->h_ctr);
@@ -1700,6 +1717,36 @@ int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t 
     return pack_leaver_extras(pi, link, g);
 }
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
+// The host's bound on the slots in use (n_upper) when particles are appended by the device without the host
+// knowing how many (photon emission): the true count is copied to pinned memory asynchronously after an
+// append; once a copy has landed, n_upper drops to that count plus whatever has been reserved since.
+int pop_tighten_upper(opal_pop_t *p)
+{
+    if (!p->upper_pending) return OPAL_OK;
+    hipError_t q = hipEventQuery(p->upper_event);
+    if (q == hipErrorNotReady) return OPAL_OK;
+    OPAL_HIP(q);
+    p->upper_pending = false;
+    size_t bound = (size_t)*p->h_upper + p->added_since_snapshot;
+    if (bound < p->n_upper) p->n_upper = bound;
+    return OPAL_OK;
+}
+int pop_snapshot_upper(opal_pop_t *p, size_t just_added)
+{
+    if (p->upper_pending) {  // an older snapshot is still in flight: it does not know about this append
+        p->added_since_snapshot += just_added;
+        return OPAL_OK;
+    }
+    if (!p->upper_event) {
+        OPAL_HIP(hipEventCreateWithFlags(&p->upper_event, hipEventDisableTiming));
+        OPAL_HIP(hipHostMalloc((void **)&p->h_upper, sizeof(unsigned)));
+    }
+    OPAL_HIP(hipMemcpyAsync(p->h_upper, &p->d_ctr->n_slots, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream));
+    OPAL_HIP(hipEventRecord(p->upper_event, p->stream));
+    p->upper_pending = true;
+    p->added_since_snapshot = 0;  // taken behind this append in stream order
+    return OPAL_OK;
+}
 // room for `extra` more particles behind the slots in use
 int pop_reserve(opal_pop_t *p, size_t extra)
 {

@@ -1,0 +1,16 @@
+"""Diagnostic: BASELINE configs[0] (examples/two_stream.yaml as shipped: 1e5 electrons, 1000 cells) is
+launch-latency-bound on a GPU: time per step with everything queued asynchronously."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import opal_amd as oa
+from test_gpu_driver import TWO_STREAM
+
+sim = oa.Simulation(yaml_text=TWO_STREAM)
+n = len(sim.electrons)
+sim.step(200); sim.sync()
+for rep in range(3):
+    t0 = time.perf_counter()
+    sim.step(5000); sim.sync()
+    el = time.perf_counter() - t0
+    print("particles %d  us/step %.2f  updates/s %.3e" % (n, el / 5000 * 1e6, n * 5000 / el), flush=True)
