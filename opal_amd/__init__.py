@@ -306,13 +306,15 @@ class Population:
         return out
 
 
-def emit_radiation(electrons, photons, seed, step, t, min_energy=None, max_angle=None, max_formation_length=None):
-    """emit_radiation (particle/interactions.rs:45-107); returns the number of electrons that emitted."""
+def emit_radiation(electrons, photons, seed, step, t, min_energy=None, max_angle=None, max_formation_length=None,
+                   count=True):
+    """emit_radiation (particle/interactions.rs:45-107); returns the number of electrons that emitted, or with
+    count=False nothing: the library then reads nothing back from the device (the driver's mode)."""
     f = lambda v: -1.0 if v is None else float(v)
     n = C.c_size_t()
     _check(_lib.load().opal_emit_radiation(electrons.h, photons.h, seed, step, t, f(min_energy), f(max_angle),
-                                           f(max_formation_length), C.byref(n)))
-    return n.value
+                                           f(max_formation_length), C.byref(n) if count else None))
+    return n.value if count else None
 
 
 def qed_sample(chi, gamma, r1, r2, r3, classical=False):

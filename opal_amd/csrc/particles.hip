@@ -1377,6 +1377,11 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     OPAL_HIP(hipMemsetAsync(p->d_ctr, 0, sizeof(PopCounters), p->stream));
     OPAL_HIP(hipMemcpyAsync(&p->d_ctr->n_slots, &p->h_ctr->n_slots, sizeof(unsigned), hipMemcpyHostToDevice, p->stream));
     p->n_upper = n;
+    if (p->upper_pending) {  // a snapshot of the previous contents
+        hipEventSynchronize(p->upper_event);
+        p->upper_pending = false;
+    }
+    p->added_since_snapshot = 0;
     p->steps_since_sort = 0;
     p->dx_last = dx;
     // T::create: prev_x (only kept if the caller later uses the separate deposit operator)
