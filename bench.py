@@ -187,6 +187,8 @@ def main():
     sim.set_fused(not args.unfused)
     if args.self_exchange and world == 1:
         sim.grid.set_self_exchange(True)
+    if os.environ.get("OPAL_BENCH_OVERLAP", "0") == "1":  # diagnostic: exchange on a second stream under the bulk push
+        sim.set_overlap(True)
     n_local = len(sim.electrons) + len(sim.ions)
 
     def barrier():

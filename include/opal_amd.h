@@ -305,6 +305,13 @@ opal_pop_t *opal_sim_photons(opal_sim_t *s); /* null unless qed.photon_emission 
 int opal_sim_energies(opal_sim_t *s, double *em_field, double *electrons, double *ions);
 /* 1 = use the fused advance+deposit pass (default), 0 = the reference's operator sequence */
 int opal_sim_set_fused(opal_sim_t *s, int fused);
+/* 1 = in the fused step of a decomposed run, push the particles near the subdomain's ends first, start the
+ * neighbour exchange on a second stream and push the rest meanwhile; 0 (default) = push, then exchange.
+ * In the one-GPU rehearsal (bench.py --self-exchange) the overlap costs more (a small extra launch, the RCCL
+ * kernel competing with the push for CUs: 0.357 against 0.338 ms/step) than the 25 us exchange it hides;
+ * it is there for links whose latency is larger than that. */
+int opal_sim_set_overlap(opal_sim_t *s, int on);
+size_t opal_sim_overlapped_steps(const opal_sim_t *s); /* how many steps so far ran that way (diagnostic) */
 /* per-kernel timing with HIP events on the library's stream: stride 0 = off, n = time every n-th
  * launch of each tracked kernel (an odd n samples both species, which alternate) */
 int opal_prof_enable(int stride);

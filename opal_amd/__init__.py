@@ -386,6 +386,14 @@ class Simulation:
     def run(self):
         _check(self._lib.opal_sim_run(self.h))
 
+    @property
+    def overlapped_steps(self):
+        return self._lib.opal_sim_overlapped_steps(self.h)
+
+    def set_overlap(self, on):
+        """Overlap the neighbour exchange with the bulk of the push in decomposed fused runs (default off)."""
+        _check(self._lib.opal_sim_set_overlap(self.h, 1 if on else 0))
+
     def set_fused(self, fused):
         _check(self._lib.opal_sim_set_fused(self.h, 1 if fused else 0))
 

@@ -116,6 +116,8 @@ SIGNATURES = {
     "opal_sim_electrons": (vp, [vp]),
     "opal_sim_ions": (vp, [vp]),
     "opal_sim_photons": (vp, [vp]),
+    "opal_sim_set_overlap": (C.c_int, [vp, C.c_int]),
+    "opal_sim_overlapped_steps": (sz, [vp]),
     "opal_grid_set_self_exchange": (C.c_int, [vp, C.c_int]),
     "opal_sim_set_collectives": (C.c_int, [vp, ALLREDUCE_FN, GATHER_FN, vp]),
     "opal_grid_write_rows": (C.c_int, [vp, sz, C.c_char_p, sz]),

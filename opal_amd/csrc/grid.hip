@@ -271,9 +271,9 @@ int check_grid(const opal_grid_t *g)
 
 namespace opal {
 // used by particles.hip and link.cpp
-int grid_pack_halo(opal_grid_t *g, double *send_left, double *send_right)
+int grid_pack_halo(opal_grid_t *g, double *send_left, double *send_right, hipStream_t st)
 {
-    k_pack_halo<<<1, 192, 0, g->stream>>>(g->d_eb[g->cur], g->j(), g->lenp, (int)g->len, send_left, send_right);
+    k_pack_halo<<<1, 192, 0, st>>>(g->d_eb[g->cur], g->j(), g->lenp, (int)g->len, send_left, send_right);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
 }
@@ -302,14 +302,16 @@ int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_
 
 // packs this subdomain's halo into the link's messages; with `exchange` also moves the halo part now
 // (yee.rs:358-409).  Returns device pointers to the received halos.
-int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right)
+int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right,
+                       hipStream_t st)
 {
+    if (!st) st = g->stream;
     double *sl = reinterpret_cast<double *>(link_send(link, 0) + LINK_HEADER_BYTES);
     double *sr = reinterpret_cast<double *>(link_send(link, 1) + LINK_HEADER_BYTES);
-    if (int rc = grid_pack_halo(g, sl, sr)) return rc;
+    if (int rc = grid_pack_halo(g, sl, sr, st)) return rc;
     if (exchange) {
         if (int rc = link_exchange(link, LINK_HEAD_BYTES, g->left_bdy == OPAL_BDY_INTERNAL,
-                                   g->right_bdy == OPAL_BDY_INTERNAL, g->stream))
+                                   g->right_bdy == OPAL_BDY_INTERNAL, st))
             return rc;
     }
     *recv_left = reinterpret_cast<const double *>(link_recv(link, 0) + LINK_HEADER_BYTES);
@@ -600,7 +602,7 @@ int opal_grid_synchronize(opal_grid_t *g, opal_link_t *link, opal_fn2 laser_y, o
             set_error("opal_grid_synchronize: %d subdomains need a link", g->ngrids);
             return OPAL_ERR_ARG;
         }
-        if (int rc = grid_exchange_halo(g, link, true, &recv_left, &recv_right)) return rc;
+        if (int rc = grid_exchange_halo(g, link, true, &recv_left, &recv_right, nullptr)) return rc;
     }
     return grid_apply_sync(g, recv_left, recv_right, ly, lz);
 }

@@ -46,8 +46,16 @@ int link_begin(opal_link_t *l, hipStream_t st)
 }
 
 // Moves `nbytes` of each send buffer to the neighbours and fills the recv buffers.
+// whether exchanges may be issued on `st` rather than on the stream the link was created with: host-staged
+// transports are synchronous (the library brackets them with copies on `st`), native ones follow set_stream
+bool link_can_use_stream(const opal_link_t *l, hipStream_t st)
+{
+    return st == l->stream || !l->device_buffers || l->set_stream;
+}
+
 int link_exchange(opal_link_t *l, size_t nbytes, bool to_left, bool to_right, hipStream_t st)
 {
+    if (l->set_stream) l->set_stream(l->user, st);
     if (nbytes > l->nbytes) {
         set_error("link_exchange: %zu bytes exceed the link's message size %zu", nbytes, l->nbytes);
         return OPAL_ERR_ARG;

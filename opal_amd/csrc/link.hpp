@@ -22,6 +22,9 @@ struct opal_link {
     void (*user_free)(void *);  // releases `user` with the link (native transports), or null
     // optional: ships a whole message but only the leavers it holds (see rccl_link.cpp); null = fixed size
     int (*exchange_exact)(opal_link *l, bool to_left, bool to_right, hipStream_t st);
+    // optional: tells a stream-ordered transport which stream the next exchanges are ordered on; null = it only
+    // knows the stream it was created with (e.g. a host-language callback tied to its framework's stream)
+    void (*set_stream)(void *user, hipStream_t st);
     hipStream_t stream;
     char *d_send_left, *d_send_right, *d_recv_left, *d_recv_right;  // device side (kernels pack / unpack here)
     char *h_send_left, *h_send_right, *h_recv_left, *h_recv_right;  // host staging when device_buffers == 0
@@ -33,6 +36,7 @@ char *link_send(opal_link_t *l, int side);
 char *link_recv(opal_link_t *l, int side);
 int link_begin(opal_link_t *l, hipStream_t st);
 int link_exchange(opal_link_t *l, size_t nbytes, bool to_left, bool to_right, hipStream_t st);
+bool link_can_use_stream(const opal_link_t *l, hipStream_t st);
 size_t link_body_bytes(const opal_link_t *l, const unsigned *counts);
 int link_repack(opal_link_t *l, char *const strided[2], char *const compact[2], bool to_compact, hipStream_t st);
 }  // namespace opal

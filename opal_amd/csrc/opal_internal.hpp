@@ -88,6 +88,13 @@ struct opal_pop {
     double *d_ex_alt[opal::NEX];  // re-binning targets, allocated on first use
     unsigned int *d_emit_list;    // slots of this step's emitters (photon emission), emit_list_cap entries
     size_t emit_list_cap;
+    // where each cell's particles ended up at the last re-binning (or sorted upload): slot index one past the last
+    // particle of cell c, for c < n_cell_end; host copy, used to tell which slots can reach a subdomain edge
+    unsigned int *h_cell_end;
+    size_t n_cell_end;
+    // this step's split into edge and bulk workgroups (pop_plan_split): blocks [0, split_lo) and [split_hi, all) can
+    // hold particles that leave or deposit into the halo cells; the blocks in between cannot
+    unsigned split_lo, split_hi;
     hipEvent_t upper_event;       // asynchronous snapshots of n_slots that tighten n_upper (see pop_tighten_upper)
     unsigned int *h_upper;        // pinned
     bool upper_pending;

@@ -32,6 +32,8 @@ using namespace opal;
 
 namespace opal {
 int grid_check_err(const opal_grid_t *g);
+int pop_tighten_upper(opal_pop_t *p);
+int pop_snapshot_upper(opal_pop_t *p, size_t just_added);
 }
 
 namespace {
@@ -478,14 +480,30 @@ __global__ __launch_bounds__(BLOCK, (EXTRAS == 0 && MODE == MODE_FUSED) ? 6 : 1)
 #ifndef OPAL_PAIR_WAVES
 #define OPAL_PAIR_WAVES 6  // measured: 6 waves/SIMD (80 VGPRs) beats 5 (94) by 1 % and 7 (spills) by 3 %
 #endif
+// Which workgroups (= chunks of BLOCK x ppt slots) of each species a launch covers: two runs of consecutive
+// chunks per species.  A whole step is {0, all, 0, 0}; the edge launch of a split step takes the first and
+// the last chunks, the bulk launch the ones in between (see pop_plan_split).
+struct PairPlan {
+    unsigned e0, en0, e1, en1;
+    unsigned i0, in0, i1, in1;
+};
+
 template <int MODE, bool RHO>
-__global__ __launch_bounds__(BLOCK, OPAL_PAIR_WAVES) void k_push_pair(PushArgs ae, PushArgs ai, unsigned nblk_e)
+__global__ __launch_bounds__(BLOCK, OPAL_PAIR_WAVES) void k_push_pair(PushArgs ae, PushArgs ai, PairPlan plan)
 {
     __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
     __shared__ double s_acc[MODE != MODE_ADVANCE ? 4 * TILE * REPL : 1];
     __shared__ int s_min[BLOCK / 64], s_max[BLOCK / 64];
-    if (blockIdx.x < nblk_e) push_body<OPAL_ELECTRON, MODE, RHO, 0, false>(ae, blockIdx.x, s_field, s_acc, s_min, s_max);
-    else push_body<OPAL_ION, MODE, RHO, 0, false>(ai, blockIdx.x - nblk_e, s_field, s_acc, s_min, s_max);
+    unsigned b = blockIdx.x;
+    const unsigned ne = plan.en0 + plan.en1;
+    if (b < ne) {
+        b = b < plan.en0 ? plan.e0 + b : plan.e1 + (b - plan.en0);
+        push_body<OPAL_ELECTRON, MODE, RHO, 0, false>(ae, b, s_field, s_acc, s_min, s_max);
+    } else {
+        b -= ne;
+        b = b < plan.in0 ? plan.i0 + b : plan.i1 + (b - plan.in0);
+        push_body<OPAL_ION, MODE, RHO, 0, false>(ai, b, s_field, s_acc, s_min, s_max);
+    }
 }
 
 // ------------------------------------------------------------------ re-binning
@@ -1059,10 +1077,46 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     return OPAL_OK;
 }
 
-// electrons and ions of one step in a single launch (fused pass only)
-int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt)
+enum { PART_ALL = 0, PART_EDGES = 1, PART_BULK = 2 };
+
+bool pair_launch_possible(const opal_pop_t *pe, const opal_pop_t *pi, const opal_link_t *link)
 {
-    if (pe->n_upper == 0 || pi->n_upper == 0 || pe->extras || pe->stream != pi->stream || (link && link->nfields > 6)) {
+    return pe->n_upper && pi->n_upper && !pe->extras && pe->stream == pi->stream && !(link && link->nfields > 6);
+}
+
+// Decides, for the push about to run, which chunks of `p` can hold a particle that leaves the subdomain or
+// deposits into the cells the halo message carries.  Slots [0, n_cell_end's total) are where the last
+// re-binning (s = steps_since_sort pushes ago) put them; a particle moves less than a cell per push, so one
+// that was W = s + 7 or more cells from both edges is still 7 or more away now: it cannot leave, and its
+// stencil (3 cells) stays clear of the 4 interior cells that travel with the halo.  Everything appended since
+// (arrivals) counts as edge.  Returns false when there is nothing to gain (or no ordering information).
+bool pop_plan_split(opal_pop_t *p, const opal_grid_t *g)
+{
+    p->split_lo = p->split_hi = 0;
+    const size_t size = g->size;
+    if (!p->h_cell_end || p->n_cell_end != size) return false;
+    const size_t W = (size_t)p->steps_since_sort + 7;
+    if (2 * W + 16 >= size) return false;
+    const size_t chunk = (size_t)BLOCK * p->ppt;
+    const size_t left_end = p->h_cell_end[W - 1];             // slots of cells [0, W)
+    const size_t right_begin = p->h_cell_end[size - W - 1];   // slots of cells [size - W, size) start here
+    const size_t lo = (left_end + chunk - 1) / chunk, hi = right_begin / chunk;
+    const size_t all = (p->n_upper + chunk - 1) / chunk;
+    if (lo >= hi || hi > all || (hi - lo) * 2 < all) return false;  // the bulk must be worth a launch of its own
+    p->split_lo = (unsigned)lo;
+    p->split_hi = (unsigned)hi;
+    return true;
+}
+
+// electrons and ions of one step in a single launch (fused pass only); `part` selects the edge or the bulk
+// chunks of a step that pop_plan_split has split for BOTH species
+int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, int part = PART_ALL)
+{
+    if (!pair_launch_possible(pe, pi, link)) {
+        if (part != PART_ALL) {
+            set_error("run_push_pair: a split step needs the paired launch");
+            return OPAL_ERR_ARG;
+        }
         if (int rc = run_push(pe, link, g, dt, MODE_FUSED)) return rc;
         return run_push(pi, link, g, dt, MODE_FUSED);
     }
@@ -1070,8 +1124,13 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     unsigned ne, ni;
     if (int rc = build_args(pe, link, g, dt, MODE_FUSED, ae, ne)) return rc;
     if (int rc = build_args(pi, link, g, dt, MODE_FUSED, ai, ni)) return rc;
+    PairPlan plan = {0, ne, 0, 0, 0, ni, 0, 0};
+    if (part == PART_EDGES) plan = {0, pe->split_lo, pe->split_hi, ne - pe->split_hi, 0, pi->split_lo, pi->split_hi, ni - pi->split_hi};
+    if (part == PART_BULK) plan = {pe->split_lo, pe->split_hi - pe->split_lo, 0, 0, pi->split_lo, pi->split_hi - pi->split_lo, 0, 0};
+    unsigned total = plan.en0 + plan.en1 + plan.in0 + plan.in1;
+    if (!total) return OPAL_OK;
     prof_begin(KERNEL_FUSED, pe->stream);
-    k_push_pair<MODE_FUSED, true><<<ne + ni, BLOCK, 0, pe->stream>>>(ae, ai, ne);
+    k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     prof_end(KERNEL_FUSED, pe->stream);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
@@ -1084,6 +1143,9 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
 {
     bool from_left = g->left_bdy == OPAL_BDY_INTERNAL, from_right = g->right_bdy == OPAL_BDY_INTERNAL;
     size_t incoming = ((size_t)from_left + (size_t)from_right) * link->cap;
+    // the host only knows that at most `incoming` particles arrive per step; counter snapshots that land a
+    // step or two later pull its bound on the slots in use back down to the true count
+    if (int rc = opal::pop_tighten_upper(p)) return rc;
     if (p->n_upper + incoming > p->cap) {
         // compact first (synchronises); the true slot count replaces the running upper bound
         if (p->n_upper)
@@ -1139,6 +1201,11 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
     k_unpack<<<2 * b.n, 256, 0, st>>>(b);
     OPAL_HIP(hipGetLastError());
     if (zero_counts) link->counts_clean = true;
+    // (only once the reservations since the last snapshot add up to a few per cent of the population: a
+    // snapshot is a small copy on the stream, not worth having every step)
+    for (int i = 0; i < npops; i++)
+        if (pops[i] && pops[i]->added_since_snapshot > pops[i]->n_upper / 32)
+            if (int rc = opal::pop_snapshot_upper(pops[i], 0)) return rc;
     return OPAL_OK;
 }
 
@@ -1230,6 +1297,13 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
         if (sa.oex[q]) std::swap(p->d_ex[q], p->d_ex_alt[q]);
     p->cur = o;
     p->n_upper = p->h_ctr->n_slots;
+    // after the scatter the cursor of cell c stands one past its last particle: the host keeps that map
+    if (p->n_cell_end != ncells) {
+        free(p->h_cell_end);
+        p->h_cell_end = (unsigned *)malloc(sizeof(unsigned) * ncells);
+        p->n_cell_end = p->h_cell_end ? ncells : 0;
+    }
+    if (p->h_cell_end) OPAL_HIP(hipMemcpy(p->h_cell_end, p->d_count, sizeof(unsigned) * ncells, hipMemcpyDeviceToHost));
     if (p->upper_pending) {  // a snapshot from before the compaction: no longer a bound worth having
         hipEventSynchronize(p->upper_event);
         p->upper_pending = false;
@@ -1339,6 +1413,7 @@ int opal_pop_free(opal_pop_t *p)
     }
     if (p->d_count) hipFree(p->d_count);
     if (p->d_emit_list) hipFree(p->d_emit_list);
+    free(p->h_cell_end);
     if (p->upper_event) hipEventDestroy(p->upper_event);
     if (p->h_upper) hipHostFree(p->h_upper);
     hipFree(p->d_partial);
@@ -1384,6 +1459,23 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     p->added_since_snapshot = 0;
     p->steps_since_sort = 0;
     p->dx_last = dx;
+    {   // where each cell's particles are, if the caller's order is by cell (the loader's is)
+        free(p->h_cell_end);
+        p->h_cell_end = nullptr;
+        p->n_cell_end = 0;
+        bool sorted = n > 0;
+        for (size_t i = 1; i < n && sorted; i++) sorted = cell[i] >= cell[i - 1];
+        if (sorted && cell[0] >= 0) {
+            size_t ncells = (size_t)cell[n - 1] + 1;
+            p->h_cell_end = (unsigned *)calloc(ncells, sizeof(unsigned));
+            if (p->h_cell_end) {
+                for (size_t i = 0; i < n; i++) p->h_cell_end[cell[i]] = (unsigned)(i + 1);
+                for (size_t c = 1; c < ncells; c++)
+                    if (!p->h_cell_end[c]) p->h_cell_end[c] = p->h_cell_end[c - 1];  // empty cell
+                p->n_cell_end = ncells;
+            }
+        }
+    }
     // T::create: prev_x (only kept if the caller later uses the separate deposit operator)
     if (n) {
         if (int rc = ensure_prev(p)) return rc;
@@ -1720,6 +1812,21 @@ int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t 
     if (!link) return OPAL_OK;
     if (int rc = pack_leaver_extras(pe, link, g)) return rc;
     return pack_leaver_extras(pi, link, g);
+}
+// A fused step in two launches so that the neighbour exchange can overlap the second: true when this step of
+// both species can be split into edge chunks (everything that can leave or touch the halo cells) and bulk
+// chunks; then call pops_push_fused_pair_part with edges = true, start the exchange, and call it with false.
+bool pops_plan_split(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, const opal_grid_t *g)
+{
+    if (!pair_launch_possible(pe, pi, link)) return false;
+    bool a = pop_plan_split(pe, g), b = pop_plan_split(pi, g);
+    return a && b;
+}
+int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, bool edges)
+{
+    pe->prev_valid = false;
+    pi->prev_valid = false;
+    return run_push_pair(pe, pi, link, g, dt, edges ? PART_EDGES : PART_BULK);
 }
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
 // The host's bound on the slots in use (n_upper) when particles are appended by the device without the host

@@ -221,6 +221,7 @@ int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle
         return rc;
     }
     (*out)->user_free = rccl_free;
+    (*out)->set_stream = [](void *user, hipStream_t s) { static_cast<RcclState *>(user)->stream = s; };
     return OPAL_OK;
 }
 

@@ -26,7 +26,10 @@ int pop_push_advance_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
-int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right);
+int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right,
+                       hipStream_t st);
+bool pops_plan_split(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, const opal_grid_t *g);
+int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, bool edges);
 int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz);
 }
 
@@ -156,6 +159,11 @@ struct opal_sim {
     double photon_energy_min = -1.0, photon_angle_max = -1.0, max_formation_length = -1.0;
     uint64_t emission_seed = 0;
     size_t step_index = 0;
+    // overlapping the neighbour exchange with the bulk of the push (fused linked step)
+    bool overlap = false;  // off by default: measured slower than push-then-exchange in the one-GPU rehearsal
+    size_t n_overlapped = 0;  // steps that took the overlapped path (diagnostic)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_edges = nullptr, ev_comm = nullptr;
     std::vector<size_t> nxs;  // interior cells of every subdomain (GridDesign)
     opal_allreduce_fn allreduce = nullptr;
     opal_gather_fn gather = nullptr;
@@ -551,7 +559,19 @@ int opal_sim_free(opal_sim_t *s)
     opal_pop_free(s->ions);
     opal_pop_free(s->photons);
     opal_grid_free(s->grid);
+    if (s->ev_edges) hipEventDestroy(s->ev_edges);
+    if (s->ev_comm) hipEventDestroy(s->ev_comm);
+    if (s->comm_stream) hipStreamDestroy(s->comm_stream);
     delete s;
+    return OPAL_OK;
+}
+
+static int ensure_comm_stream(opal_sim_t *s)
+{
+    if (s->comm_stream) return OPAL_OK;
+    OPAL_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    OPAL_HIP(hipEventCreateWithFlags(&s->ev_edges, hipEventDisableTiming));
+    OPAL_HIP(hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
     return OPAL_OK;
 }
 
@@ -600,7 +620,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                     if (int rc = pop_push_advance_noexchange(p, s->link, g, s->dt)) return rc;
             const double *rl = nullptr, *rr = nullptr;
             if (!s->current_deposition)
-                if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr)) return rc;
+                if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
             if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, st)) return rc;
             if (int rc = pops_unpack_and_maybe_sort(pops, 3, s->link, g)) return rc;
             if (s->photon_emission && s->electrons)  // main.rs:250-252
@@ -614,7 +634,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                     if (int rc = opal_grid_deposit(g, s->electrons, s->dt)) return rc;
                 if (s->ions)
                     if (int rc = opal_grid_deposit(g, s->ions, s->dt)) return rc;
-                if (int rc = grid_exchange_halo(g, s->link, true, &rl, &rr)) return rc;
+                if (int rc = grid_exchange_halo(g, s->link, true, &rl, &rr, nullptr)) return rc;
             }
             double ly, lz;
             laser_now(ly, lz);
@@ -632,17 +652,36 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             hipStream_t st = (hipStream_t)s->stream;
             if (int rc = opal_grid_clear(g)) return rc;
             if (int rc = link_begin(s->link, st)) return rc;  // free after the first step: the unpack kernel re-zeroes
-            if (s->electrons && s->ions) {
-                if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, s->link, g, s->dt)) return rc;
-            } else {
-                if (s->electrons)
-                    if (int rc = pop_push_fused_noexchange(s->electrons, s->link, g, s->dt)) return rc;
-                if (s->ions)
-                    if (int rc = pop_push_fused_noexchange(s->ions, s->link, g, s->dt)) return rc;
-            }
             const double *rl = nullptr, *rr = nullptr;
-            if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr)) return rc;
-            if (int rc = link_exchange(s->link, s->link->nbytes, opal_grid_to_left(g) >= 0, opal_grid_to_right(g) >= 0, st)) return rc;
+            const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
+            // Overlap: only the particles within a few cells of the subdomain's ends can leave it or deposit
+            // into the cells the halo carries, and after a re-binning they sit in the first and last chunks
+            // of the arrays.  Push those first, ship the message on a second stream, and push everybody
+            // else meanwhile; the exchange -- RCCL kernel, xGMI transfer, a neighbour that is a little
+            // late -- is off the critical path as long as it takes less than the bulk push.
+            if (s->overlap && s->electrons && s->ions && pops_plan_split(s->electrons, s->ions, s->link, g) &&
+                ensure_comm_stream(s) == OPAL_OK && link_can_use_stream(s->link, s->comm_stream)) {
+                if (int rc = pops_push_fused_pair_part(s->electrons, s->ions, s->link, g, s->dt, true)) return rc;
+                OPAL_HIP(hipEventRecord(s->ev_edges, st));
+                OPAL_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_edges, 0));
+                if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, s->comm_stream)) return rc;
+                if (int rc = pops_push_fused_pair_part(s->electrons, s->ions, s->link, g, s->dt, false)) return rc;
+                if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, s->comm_stream)) return rc;
+                OPAL_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
+                OPAL_HIP(hipStreamWaitEvent(st, s->ev_comm, 0));
+                s->n_overlapped++;
+            } else {
+                if (s->electrons && s->ions) {
+                    if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, s->link, g, s->dt)) return rc;
+                } else {
+                    if (s->electrons)
+                        if (int rc = pop_push_fused_noexchange(s->electrons, s->link, g, s->dt)) return rc;
+                    if (s->ions)
+                        if (int rc = pop_push_fused_noexchange(s->ions, s->link, g, s->dt)) return rc;
+                }
+                if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
+                if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, st)) return rc;
+            }
             double ly, lz;
             laser_now(ly, lz);
             if (int rc = grid_apply_sync(g, rl, rr, ly, lz)) return rc;
@@ -869,6 +908,13 @@ int opal_sim_set_fused(opal_sim_t *s, int fused)
     s->fused = fused != 0;
     return OPAL_OK;
 }
+int opal_sim_set_overlap(opal_sim_t *s, int on)
+{
+    if (!s) return OPAL_ERR_ARG;
+    s->overlap = on != 0;
+    return OPAL_OK;
+}
+size_t opal_sim_overlapped_steps(const opal_sim_t *s) { return s ? s->n_overlapped : 0; }
 
 // -------------------------------------------------------------------- config
 struct opal_config {

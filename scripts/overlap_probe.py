@@ -1,0 +1,26 @@
+"""Diagnostic: the decomposed fused step rehearsed on one GPU (self-exchange through the native RCCL link),
+with and without overlapping the exchange with the bulk of the push; no kernel timers.
+Measured: 0.338 ms/step push-then-exchange, 0.357 ms/step overlapped (in place, no exchange at all: 0.327)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.distributed as dist
+import bench
+import opal_amd as oa
+from opal_amd.exchange import RcclLink
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29547")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+stream = torch.cuda.current_stream().cuda_stream
+for overlap in (False, True, False, True):
+    link = RcclLink(0, 1, dev, particle_capacity=1024)
+    sim = oa.Simulation(yaml_text=bench.YAML.format(nx=4096, npc=2441), rank=0, numtasks=1, link=link, stream=stream)
+    sim.grid.set_self_exchange(True)
+    sim.set_overlap(overlap)
+    sim.step(50); sim.sync()
+    t0 = time.perf_counter()
+    sim.step(400); sim.sync()
+    el = time.perf_counter() - t0
+    print("overlap", overlap, "ms/step %.4f" % (el * 1e3 / 400), "overlapped steps", sim.overlapped_steps, flush=True)
+    del sim, link
+dist.destroy_process_group()

@@ -211,6 +211,9 @@ def main():
     else:
         sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc), rank=rank, numtasks=world, link=link)
         sim.set_fused(bool(fused))
+        sim.set_overlap(nx >= 512)  # the optional overlapped step: edge chunks, exchange on a second stream, bulk chunks
+        sim.electrons.set_sort_interval(16)  # re-bin on a fixed schedule so that the test crosses re-binnings
+        sim.ions.set_sort_interval(16)
         init = {}
         for name, p in (("e", sim.electrons), ("i", sim.ions)):
             for k, v in p.soa().items():
@@ -218,6 +221,9 @@ def main():
         sim.step(steps)
         sim.sync()
         dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
+        if link is not None and fused and nx >= 512:
+            # (not before the first re-binning: until then a chunk is 8 x 256 slots, half of such a small population)
+            assert sim.overlapped_steps >= steps // 3, sim.overlapped_steps
         if link is not None:
             # one message per neighbour per step when fused; leavers (all species) + a halo-only message otherwise
             assert link.calls == (steps if fused else 2 * steps), link.calls
