@@ -45,7 +45,7 @@ def _state(nx, npc, seed):
     return cell, x, u[0], u[1], u[2], w
 
 
-@pytest.mark.parametrize("species", [0, 1])
+@pytest.mark.parametrize("species", [0, 1, 2])
 @pytest.mark.parametrize("spec,names,bspec,weight", [
     ("x", ["x"], "auto", "weight"),
     ("x:px", ["x", "px"], "auto", "weight"),
@@ -71,6 +71,7 @@ def test_histogram_matches_oracle(oracle, species, spec, names, bspec, weight):
     if species == 1:
         p.set_charge_state(6.0, 6.0, 12.0)
         op.set_charge_state(6.0, 6.0, 12.0)
+    # species 2: photons (photon.rs:211-224: momentum k m_e c, energy |k| m_e c^2), as emission fills them
     h = p.histogram(g, spec)
     ref = o.histogram(op, og, names, bspec, weight)
     assert h["nbins"][:len(names)] == ref["nbins"][:len(names)]
@@ -118,3 +119,34 @@ def test_write_data_fits_files(oracle, tmp_path):
     assert np.sum(np.abs(data - ref["cts"]) > 1e-9 * scale) <= 4
     cards, shape, data = read_fits(tmp_path / "3_electron_x.fits")
     assert shape == [o.histogram(op, og, ["x"])["nbins"][0]] and cards["OBJECT"] == "hgram/density/x"
+
+
+def test_photon_r_and_chi_histograms(oracle):
+    """The accessors that read a photon's extras: r = hypot(y, z) and chi (mod.rs:393-395, 428-430) after a few
+    pushes through a field."""
+    import opal_amd as oa
+    o = oracle
+    nx, npc, dx = 40, 50, 1.0e-8
+    dt = 0.9 * dx / C
+    cell, x, kx, ky, kz, w = _state(nx, npc, 9)
+    g = oa.Grid.single(nx, 0.0, dx)
+    og = o.Grid.single(nx, 0.0, dx)
+    for grid in (g, og):
+        grid.set_raw("Ey", np.full(grid.len, 3.0e13))
+        grid.set_raw("Bz", np.full(grid.len, 2.0e4))
+    p = oa.Population(2, 2 * nx * npc)
+    p.track_extras(1)
+    p.upload(cell, x, 50 * kx, 50 * ky, 50 * kz, w, dx, dt)
+    op = o.Population.from_soa(2, cell, x, 50 * kx, 50 * ky, 50 * kz, w, dx, dt)
+    for _ in range(4):
+        p.advance(g, dt)
+        op.advance(og, dt)
+    for spec, names in (("r", ["r"]), ("chi", ["chi"]), ("x:chi", ["x", "chi"]), ("work", ["work"])):
+        h = p.histogram(g, spec)
+        ref = o.histogram(op, og, names)
+        assert h["nbins"][:len(names)] == ref["nbins"][:len(names)], spec
+        assert abs(h["total"] - ref["total"]) <= 1e-12 * abs(ref["total"])
+        for d in range(len(names)):
+            assert abs(h["min"][d] - ref["min"][d]) <= 1e-9 * max(abs(ref["max"][d]), 1e-300), (spec, d)
+        scale = np.max(ref["cts"])
+        assert np.sum(np.abs(h["cts"] - ref["cts"]) > 1e-9 * scale) <= 6, spec
