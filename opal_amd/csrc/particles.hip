@@ -1110,28 +1110,32 @@ bool pop_plan_split(opal_pop_t *p, const opal_grid_t *g)
 
 // electrons and ions of one step in a single launch (fused pass only); `part` selects the edge or the bulk
 // chunks of a step that pop_plan_split has split for BOTH species
-int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, int part = PART_ALL)
+int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, int part = PART_ALL,
+                  int mode = MODE_FUSED)
 {
     if (!pair_launch_possible(pe, pi, link)) {
         if (part != PART_ALL) {
             set_error("run_push_pair: a split step needs the paired launch");
             return OPAL_ERR_ARG;
         }
-        if (int rc = run_push(pe, link, g, dt, MODE_FUSED)) return rc;
-        return run_push(pi, link, g, dt, MODE_FUSED);
+        if (int rc = run_push(pe, link, g, dt, mode)) return rc;
+        return run_push(pi, link, g, dt, mode);
     }
     PushArgs ae, ai;
     unsigned ne, ni;
-    if (int rc = build_args(pe, link, g, dt, MODE_FUSED, ae, ne)) return rc;
-    if (int rc = build_args(pi, link, g, dt, MODE_FUSED, ai, ni)) return rc;
+    if (int rc = build_args(pe, link, g, dt, mode, ae, ne)) return rc;
+    if (int rc = build_args(pi, link, g, dt, mode, ai, ni)) return rc;
     PairPlan plan = {0, ne, 0, 0, 0, ni, 0, 0};
     if (part == PART_EDGES) plan = {0, pe->split_lo, pe->split_hi, ne - pe->split_hi, 0, pi->split_lo, pi->split_hi, ni - pi->split_hi};
     if (part == PART_BULK) plan = {pe->split_lo, pe->split_hi - pe->split_lo, 0, 0, pi->split_lo, pi->split_hi - pi->split_lo, 0, 0};
     unsigned total = plan.en0 + plan.en1 + plan.in0 + plan.in1;
     if (!total) return OPAL_OK;
-    prof_begin(KERNEL_FUSED, pe->stream);
-    k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    prof_end(KERNEL_FUSED, pe->stream);
+    int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
+    prof_begin(kid, pe->stream);
+    if (mode == MODE_FUSED) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    else if (mode == MODE_ADVANCE) k_push_pair<MODE_ADVANCE, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    else k_push_pair<MODE_DEPOSIT, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    prof_end(kid, pe->stream);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
 }
@@ -1812,6 +1816,26 @@ int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t 
     if (!link) return OPAL_OK;
     if (int rc = pack_leaver_extras(pe, link, g)) return rc;
     return pack_leaver_extras(pi, link, g);
+}
+// the reference's separate operators for both charged species of a lone subdomain, one launch each:
+// Population::advance x 2 (no exchange, no re-binning bookkeeping), then YeeGrid::deposit x 2
+int pops_advance_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt)
+{
+    for (opal_pop_t *p : {pe, pi}) {
+        const bool prev = p->keep_prev;
+        if (prev)
+            if (int rc = ensure_prev(p)) return rc;
+        p->prev_valid = prev;
+    }
+    return run_push_pair(pe, pi, nullptr, g, dt, PART_ALL, MODE_ADVANCE);
+}
+int pops_deposit_pair(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt)
+{
+    if (!pe->prev_valid || !pi->prev_valid) {
+        set_error("deposit: prev_x is not resident; advance (not the fused pass) first");
+        return OPAL_ERR_ARG;
+    }
+    return run_push_pair(pe, pi, nullptr, g, dt, PART_ALL, MODE_DEPOSIT);
 }
 // A fused step in two launches so that the neighbour exchange can overlap the second: true when this step of
 // both species can be split into edge chunks (everything that can leave or touch the halo cells) and bulk

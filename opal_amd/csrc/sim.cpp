@@ -26,6 +26,8 @@ int pop_push_advance_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
+int pops_advance_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt);
+int pops_deposit_pair(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt);
 int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right,
                        hipStream_t st);
 bool pops_plan_split(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, const opal_grid_t *g);
@@ -712,10 +714,18 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                     if (int rc = opal_pop_advance_deposit(s->ions, s->link, s->grid, s->dt)) return rc;
             }
         } else {
-            if (s->electrons)
-                if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) return rc;
-            if (s->ions)
-                if (int rc = opal_pop_advance(s->ions, s->link, s->grid, s->dt)) return rc;
+            // both charged species of a lone subdomain in one launch per operator (no extras involved)
+            const bool pair = !linked && s->electrons && s->ions && !s->photon_emission && s->current_deposition;
+            if (pair) {
+                if (int rc = pops_advance_pair_noexchange(s->electrons, s->ions, s->grid, s->dt)) return rc;
+                if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
+                if (int rc = pop_maybe_sort(s->ions, s->grid)) return rc;
+            } else {
+                if (s->electrons)
+                    if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) return rc;
+                if (s->ions)
+                    if (int rc = opal_pop_advance(s->ions, s->link, s->grid, s->dt)) return rc;
+            }
             if (s->photon_emission) {
                 if (s->photons)
                     if (int rc = opal_pop_advance(s->photons, s->link, s->grid, s->dt)) return rc;  // main.rs:242-244
@@ -727,10 +737,14 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
             if (s->current_deposition) {
                 if (int rc = opal_grid_clear(s->grid)) return rc;
-                if (s->electrons)
-                    if (int rc = opal_grid_deposit(s->grid, s->electrons, s->dt)) return rc;
-                if (s->ions)
-                    if (int rc = opal_grid_deposit(s->grid, s->ions, s->dt)) return rc;
+                if (pair) {
+                    if (int rc = pops_deposit_pair(s->electrons, s->ions, s->grid, s->dt)) return rc;
+                } else {
+                    if (s->electrons)
+                        if (int rc = opal_grid_deposit(s->grid, s->electrons, s->dt)) return rc;
+                    if (s->ions)
+                        if (int rc = opal_grid_deposit(s->grid, s->ions, s->dt)) return rc;
+                }
             }
         }
         s->step_index++;

@@ -184,3 +184,28 @@ def test_laser_plasma_yaml_steps(oracle, tmp_path):
         a, b = g.raw(comp), og.raw(comp)
         assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 1e-6, comp
     assert len(sim.electrons) == len(ope) and len(sim.ions) == len(opi)
+
+
+def test_unfused_driver_equals_fused(tmp_path):
+    """opal_sim_set_fused(0): the reference's operator order (advance, advance, clear, deposit, deposit) with both
+    charged species in one launch per operator, against the fused pass."""
+    import sys
+    import opal_amd as oa
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _gloo_hip_worker import YAML
+    out = {}
+    for fused in (True, False):
+        sim = oa.Simulation(yaml_text=YAML.format(nx=96, npc=24), output_dir=str(tmp_path))
+        sim.set_fused(fused)
+        sim.electrons.set_sort_interval(7)
+        sim.ions.set_sort_interval(7)
+        sim.step(30)
+        sim.sync()
+        out[fused] = {k: sim.grid.raw(k) for k in ("Ex", "Ey", "Ez", "By", "Bz", "jx", "rho")}
+        out[fused]["ke"] = sim.energies()
+        out[fused]["n"] = (len(sim.electrons), len(sim.ions))
+    assert out[True]["n"] == out[False]["n"] == (96 * 24, 96 * 24)
+    for k in ("Ex", "Ey", "Ez", "By", "Bz", "jx", "rho"):
+        a, b = out[False][k], out[True][k]
+        assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), k
+    assert np.allclose(out[False]["ke"], out[True]["ke"], rtol=1e-10)
