@@ -316,3 +316,62 @@ print("SELF-EXCHANGE OK")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OPAL_ROOT=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SELF-EXCHANGE OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_emission_state_travels_through_rccl(tmp_path, exact):
+    """Electrons with optical depths and ids, and photons, migrating through the native RCCL link (3 species
+    slots, 12 fields per particle; fixed-size and exact-size messages): a lone periodic subdomain in a strong
+    field made its own neighbour, against the in-place wrap.  Same emitters, same photons."""
+    import subprocess
+    from test_exchange_gloo import _free_port
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["OPAL_ROOT"])
+import opal_amd as oa
+from opal_amd.exchange import RcclLink
+exact = os.environ["OPAL_TEST_EXACT"] == "1"
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+C = 2.997925e8
+nx, n, dx = 48, 3000, 1.0e-8
+dt = 0.5 * dx / C
+rng = np.random.default_rng(3)
+cell = np.sort(rng.integers(0, nx, n)).astype(np.int32)
+x = rng.random(n)
+ux = -900.0 * (1 + 0.01 * rng.normal(size=n)); uy = 5.0 * rng.normal(size=n); uz = 5.0 * rng.normal(size=n)
+w = 1.0e3 * (1.0 + np.arange(n) * 1e-9)
+tau0 = rng.exponential(size=n) * 0.2
+out = {}
+for mode in ("wrap", "link"):
+    g = oa.Grid.single(nx, 0.0, dx)
+    g.set_raw("Ey", np.full(g.len, 2.0e14)); g.set_raw("Bz", np.full(g.len, -0.5 * 2.0e14 / C))
+    link = None
+    if mode == "link":
+        link = RcclLink(0, 1, dev, particle_capacity=2048, photon_emission=True, exact=exact)
+        g.set_self_exchange(True)
+    e = oa.Population(oa.ELECTRON, 4 * n); e.track_extras(2)
+    e.upload(cell, x, ux, uy, uz, w, dx, dt); e.set_emission_state(tau0, np.arange(n, dtype=np.uint64))
+    ph = oa.Population(oa.PHOTON, 256); ph.track_extras(1)
+    crossed = 0
+    for step in range(60):
+        e.advance(g, dt, link); ph.advance(g, dt, link)
+        oa.emit_radiation(e, ph, seed=5, step=step, t=step * dt, count=step % 2 == 0)
+    tau, ids = e.emission_state()
+    s = e.soa(); o = np.argsort(ids)
+    _, pid = ph.emission_state(); p = ph.soa(); po = np.lexsort((p["ux"], pid))
+    out[mode] = dict(ids=ids[o], tau=tau[o], ux=s["ux"][o], cell=s["cell"][o], chi=e.extras()["chi"][o],
+                     pid=pid[po], pux=p["ux"][po], pcell=p["cell"][po], px=p["x"][po])
+a, b = out["link"], out["wrap"]
+assert len(b["pid"]) > 500 and np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["pid"], b["pid"])
+assert np.array_equal(a["cell"], b["cell"]) and np.array_equal(a["pcell"], b["pcell"])
+# the beam moves half a cell per step for 60 steps on 48 cells: every electron has crossed the cut at least once
+for k in ("tau", "ux", "chi", "pux", "px"):
+    assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-12), k
+dist.destroy_process_group()
+print("EMISSION THROUGH RCCL OK", len(b["pid"]))
+'''
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OPAL_ROOT=ROOT,
+               OPAL_TEST_EXACT="1" if exact else "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "EMISSION THROUGH RCCL OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
