@@ -33,8 +33,8 @@ def main(argv):
         emission = oa.Config(path=argv[1]).read_bool("qed", "photon_emission")
         # room for the leavers of one step through one cut, per species (an overflow is reported as an error).
         # Messages normally have a fixed size -- all slots travel every step; OPAL_LINK_EXACT=1 sizes them to
-        # their content instead (two RCCL groups and a host synchronisation per step: worth it only for links
-        # that need a very large capacity, e.g. a dense beam crossing the cuts)
+        # their content instead (two RCCL groups and a host synchronisation per step, ~+13 % on a 0.35 ms step:
+        # worth it for links that need a very large capacity, e.g. a dense beam crossing the cuts)
         cap = int(os.environ.get("OPAL_LINK_CAPACITY", "65536"))
         stream = torch.cuda.current_stream().cuda_stream
         if backend == "nccl" and os.environ.get("OPAL_LINK", "rccl") == "rccl":
