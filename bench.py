@@ -68,6 +68,56 @@ constants:
 """
 
 
+# BASELINE configs[3]: examples/hole_boring.yaml's physics (a0 = 300 laser on an overdense electron-carbon slab,
+# laser + absorbing boundaries, balanced decomposition) with npc scaled; the whole 20 000-cell domain is divided
+# among the GPUs (strong scaling).  The pulse reaches the slab after ~21 000 steps: --warmup 21000 times the
+# interaction, the default warm-up the approach.
+LASER_PLASMA_YAML = """---
+control:
+ dx: micro / 1000
+ nx: 20000
+ xmin: -10*micro
+ start: -20.0e-6/c
+ end: 10.0e-6/c
+ current_deposition: true
+ n_outputs: 30
+ balance: true
+qed:
+ photon_emission: false
+ photon_absorption: false
+electrons:
+ npc: {npc}
+ ne: density * critical(omega) * step(x,xmin,xmax)
+ ux: sqrt(kT/(m*c^2)) * nrand
+ uy: sqrt(kT/(m*c^2)) * nrand
+ uz: sqrt(kT/(m*c^2)) * nrand
+ output: [x:px]
+ions:
+ name: carbon
+ npc: {npc}
+ Z: Z
+ A: A
+ ni: density * critical(omega) * step(x,xmin,xmax) / Z
+ ux: sqrt(kT/(A*mp*c^2)) * nrand
+ uy: sqrt(kT/(A*mp*c^2)) * nrand
+ uz: sqrt(kT/(A*mp*c^2)) * nrand
+ output: [x:px]
+laser:
+ Ey: (a0*me*c*omega/e) * gauss_pulse_re(t,x,omega,sigma)
+ Ez: (a0*me*c*omega/e) * gauss_pulse_im(t,x,omega,sigma)
+constants:
+ density: 100.0
+ a0: 300.0
+ omega: 2*pi*c/0.8e-6
+ sigma: pi * 4.0 / sqrt(ln(2.0))
+ xmin: 0.0 * micro
+ xmax: 5.0 * micro
+ Z: 6.0
+ A: 12.0
+ kT: 500 * eV
+"""
+
+
 def cpu_baseline(oa, target_seconds=12.0):
     """Times the oracle (OpenMP over particle chunks, one subdomain) on a bounded sample of the
     workload: same grid, same physics, 1/10 of the particles per cell, a few steps."""
@@ -115,6 +165,9 @@ def main():
     ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU,
                     help="other BASELINE configs, e.g. configs[2] on one GPU: --cells-per-gpu 32768 --npc 1526")
     ap.add_argument("--unfused", action="store_true", help="time the reference's operator sequence instead")
+    ap.add_argument("--workload", choices=["two_stream", "laser_plasma"], default="two_stream",
+                    help="two_stream (default; BASELINE configs[1] per GPU, weak scaling) or laser_plasma "
+                         "(configs[3]'s physics, --npc per cell in 5000 of 20000 cells, strong scaling)")
     ap.add_argument("--self-exchange", action="store_true",
                     help="N=1 rehearsal of the multi-GPU step: the lone periodic subdomain sends its halo and leavers "
                          "to itself through RCCL (pack kernels, torch.distributed P2P, unpack) instead of wrapping in place")
@@ -182,8 +235,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     cells_per_gpu = args.cells_per_gpu
     nx = cells_per_gpu * world
-    sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=args.npc), rank=rank, numtasks=world, link=link,
-                        stream=stream)
+    if args.workload == "laser_plasma":
+        nx = 20000
+        sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=args.npc), rank=rank, numtasks=world, link=link,
+                            stream=stream)
+    else:
+        sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=args.npc), rank=rank, numtasks=world, link=link,
+                            stream=stream)
     sim.set_fused(not args.unfused)
     if args.self_exchange and world == 1:
         sim.grid.set_self_exchange(True)
@@ -251,14 +309,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.workload == "two_stream" else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"two_stream, {args.npc} e- + {args.npc} e+ per cell, {cells_per_gpu} cells per GPU "
-                            + ("(BASELINE configs[1] per GPU)" if (cells_per_gpu, args.npc) == (CELLS_PER_GPU, NPC) else "")
-                            + ", periodic, push+deposit+field, no QED",
+                "workload": (f"two_stream, {args.npc} e- + {args.npc} e+ per cell, {cells_per_gpu} cells per GPU "
+                             + ("(BASELINE configs[1] per GPU)" if (cells_per_gpu, args.npc) == (CELLS_PER_GPU, NPC) else "")
+                             + ", periodic, push+deposit+field, no QED") if args.workload == "two_stream" else
+                            (f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]), {args.npc} e- + {args.npc} C6+ per "
+                             f"cell in 5000 of 20000 cells, laser + absorbing boundaries, t = {sim.t:.3e} s at the end of the "
+                             f"timed steps"),
                 "particles_total": n_total,
                 "cells_total": nx,
                 "path": "fused advance+deposit" if not args.unfused else "advance, clear, deposit (reference order)",
@@ -283,7 +344,7 @@ def main():
                 "other_kernels_avg_ms": {"field_solve": field_ms / max(field_launches, 1), "rebin": sort_ms / max(sort_launches, 1)},
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "two_stream":
             del sim
             out["cpu_baseline"] = cpu_baseline(oa)
         sys.stdout.flush()
