@@ -1333,12 +1333,14 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
         if (p->steps_since_sort >= p->sort_interval) return do_sort(p, g);
         return OPAL_OK;
     }
-    // adaptive ("rent or buy"): every few steps read the tile-miss counter (one 64-byte D2H copy).  A miss
-    // costs about 100 ns of kernel time (slow path + the workgroup it delays; tuned on the two-stream
-    // bench, scripts/sustained_probe.py); once the time lost to misses since the last re-binning exceeds
-    // what a re-binning costs, re-bin.
+    // adaptive ("rent or buy"): every few steps read the tile-miss counter (one 64-byte D2H copy); once the
+    // time lost to misses since the last re-binning exceeds what a re-binning costs, re-bin.
     constexpr int check_every = 4;
-    constexpr double miss_ns = 100.0;
+    // ns of kernel time per tile miss.  Measured by sweeping it: the two-stream bench is flat from 100 to 800
+    // (misses are rare there), the relativistic laser-plasma interaction is fastest at 800 (0.405 against
+    // 0.494 ms/step at 100): a miss costs far more than its own global atomics, because the workgroup it sits in
+    // finishes late
+    constexpr double miss_ns = 800.0;
     if (p->steps_since_sort % check_every != 0) return OPAL_OK;
     // The counters are copied to pinned memory asynchronously and read at the NEXT check, 8 steps later:
     // waiting for that older copy keeps the host at most ~16 steps ahead of the device (so the policy sees

@@ -62,7 +62,8 @@ for b in range(int(os.environ.get("NBLK", "9"))):
     sim.step(blk); sim.sync()
     el = time.perf_counter() - t0
     fe, ke, ki = sim.energies()
-    ce = sim.electrons.counters()
+    ce, ci = sim.electrons.counters(), sim.ions.counters()
     print("block", b, "t=%.3e" % sim.t, "ms/step %.3f" % (el * 1e3 / blk), "updates/s %.3e" % (n * blk / el),
-          "E_field %.3e KE_e %.3e KE_i %.3e" % (fe, ke, ki), "live_e", len(sim.electrons), "ppt", ce["ppt"],
+          "E_field %.3e KE_e %.3e KE_i %.3e" % (fe, ke, ki), "live_e", len(sim.electrons), "ppt", ce["ppt"], "nonempty cells e/i", ce["nonempty_cells"], ci["nonempty_cells"],
+          "misses since re-bin e/i", ce["tile_misses"], ci["tile_misses"], "steps since re-bin e/i", ce["steps_since_sort"], ci["steps_since_sort"],
           "fused (n, ms)", oa.prof_get("fused"), "sort (n, ms)", oa.prof_get("sort"), flush=True)
