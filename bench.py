@@ -342,6 +342,7 @@ def main():
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * per_launch_particles,
                 "other_kernels_avg_ms": {"field_solve": field_ms / max(field_launches, 1), "rebin": sort_ms / max(sort_launches, 1)},
+                "rebins_in_timed_region": oa.prof_seen("sort"),
             },
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "two_stream":

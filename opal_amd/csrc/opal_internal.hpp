@@ -107,6 +107,7 @@ struct opal_pop {
     opal::PopCounters *h_ctr_async;  // pinned target of the asynchronous copy used by the re-binning policy
     opal::PopCounters h_ctr_seen;
     hipEvent_t ctr_event;
+    hipEvent_t fetch_event;  // behind the synchronous counter read-backs
     bool ctr_pending;
     int sort_interval;         // 0 never, >0 fixed, <0 adaptive
     int steps_since_sort;

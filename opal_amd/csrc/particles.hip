@@ -825,11 +825,23 @@ int check_pop(const opal_pop_t *p)
     return OPAL_OK;
 }
 
+// Waits on the step path poll the event instead of sleeping in hipEventSynchronize / hipStreamSynchronize: the
+// interrupt-driven wake-up can take long on a loaded host, and while the host is late the device runs dry.
+int spin_wait(hipEvent_t ev)
+{
+    for (;;) {
+        hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return OPAL_OK;
+        if (q != hipErrorNotReady) OPAL_HIP(q);
+    }
+}
+
 int fetch_counters(const opal_pop_t *p)
 {
     OPAL_HIP(hipMemcpyAsync(p->h_ctr, p->d_ctr, sizeof(PopCounters), hipMemcpyDeviceToHost, p->stream));
-    OPAL_HIP(hipStreamSynchronize(p->stream));
-    return OPAL_OK;
+    if (!p->fetch_event) OPAL_HIP(hipEventCreateWithFlags(const_cast<hipEvent_t *>(&p->fetch_event), hipEventDisableTiming));
+    OPAL_HIP(hipEventRecord(p->fetch_event, p->stream));
+    return spin_wait(p->fetch_event);
 }
 
 int check_pop_err(opal_pop_t *p)
@@ -1347,7 +1359,7 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
     // recent counts) while the device still has 8 queued steps to run and never idles.
     bool fresh = false;
     if (p->ctr_pending) {
-        OPAL_HIP(hipEventSynchronize(p->ctr_event));
+        if (int rc = spin_wait(p->ctr_event)) return rc;
         fresh = true;
         p->h_ctr_seen = *p->h_ctr_async;
         p->ctr_pending = false;
@@ -1427,6 +1439,7 @@ int opal_pop_free(opal_pop_t *p)
     hipHostFree(p->h_ctr);
     hipHostFree(p->h_ctr_async);
     if (p->ctr_event) hipEventDestroy(p->ctr_event);
+    if (p->fetch_event) hipEventDestroy(p->fetch_event);
     delete p;
     return OPAL_OK;
 }
