@@ -4,6 +4,7 @@ the rate_* tests of photon_emission.rs:296-336 are in test_oracle_kat.py) and, s
 spectrum tests are commented out (photon_emission.rs:338-410), by direct quadrature of the emission rate.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -334,3 +335,25 @@ def test_rate_table_is_the_integral_of_the_spectrum():
     # chi -> 0: h -> 5 pi / 3
     assert O.rate(1e-6, 10.0) * (2.0 * math.pi * 10.0 * 1.28808867e-21) / (math.sqrt(3.0) * 7.29735257e-3 * 1e-6) \
         == pytest.approx(5.0 * math.pi / 3.0, rel=1e-5)
+
+
+def test_committed_tables_are_what_the_generator_writes(tmp_path, monkeypatch):
+    """opal_amd/csrc/qed_tables.inc is generated data: running tools/make_qed_tables.py again must reproduce the
+    committed file (same scipy -> byte for byte; otherwise to 1e-9 in every number)."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_qed_tables", os.path.join(root, "tools", "make_qed_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "opal_amd" / "csrc")
+    mod.main()
+    fresh = open(tmp_path / "opal_amd" / "csrc" / "qed_tables.inc").read()
+    committed = open(os.path.join(root, "opal_amd", "csrc", "qed_tables.inc")).read()
+    if fresh == committed:
+        return
+    num = re.compile(r"-?\d\.\d+e[+-]\d+")
+    a, b = np.array(num.findall(fresh), dtype=float), np.array(num.findall(committed), dtype=float)
+    assert re.sub(num, "#", fresh) == re.sub(num, "#", committed)  # same structure
+    assert np.allclose(a, b, rtol=1e-9, atol=1e-300)
