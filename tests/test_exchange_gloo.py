@@ -101,3 +101,9 @@ def test_one_subdomain_equals_many(oracle):
     scale = np.max(np.abs(res[1]))
     assert scale > 0
     assert np.max(np.abs(res[1] - res[3])) / scale < 1e-10
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_output_time_collectives_over_gloo(world):
+    """exchange.TorchCollectives (the all-reduce and gather callbacks of opal_sim_set_collectives) on CPU."""
+    _launch("_gloo_collectives_worker.py", world, [])
