@@ -8,8 +8,9 @@
 // that emit (a fraction rate * dt of the population per step) into a list; a second, dense pass over the
 // list draws from a counter-based generator keyed by (seed, particle id, step) -- so the result does not
 // depend on how particles are laid out or scheduled, unlike the reference's per-thread jumped Xoshiro
-// streams (interactions.rs:58-67) -- samples, recoils, and takes a photon slot with one atomic.  The sampling tables (37 KB, generated by tools/make_qed_tables.py) sit
-// in device memory and stay cache-resident.
+// streams (interactions.rs:58-67) -- samples, recoils, and takes a photon slot with one atomic.  The sampling tables (37 KB: the
+// reference's numbers, transcribed as constant data by tools/transcribe_qed_tables.py) sit in device memory and
+// stay cache-resident.
 #include "opal_internal.hpp"
 #include "pic_device.hpp"
 #include "qed_device.hpp"
@@ -35,6 +36,13 @@ struct QedCdf {
 };
 #define QED_TABLE_QUAL __device__ const
 #include "qed_tables.inc"
+
+// The sampler below is compiled WITHOUT floating-point contraction: Brent's iteration in pwmci_invert
+// stops on a 1e-6 bracket and branches on comparisons of residuals, so a fused multiply-add can return a
+// different iterate than the reference's (Rust never fuses).  Unfused, the device differs from the CPU
+// restatement only by the last-ulp differences of log/exp/pow/acos, and tests/test_gpu_qed.py holds the
+// golden vectors of tests/golden/qed_sample_reference_tables.json to 1e-12.  k_radiate is 64 us of a step.
+#pragma clang fp contract(off)
 
 constexpr int RECURSION_LIMIT = 32;      // pwmci.rs:3
 constexpr double PRECISION_LIMIT = 1.0e-6;  // pwmci.rs:4
@@ -171,8 +179,8 @@ __device__ Sample classical_sample(double chi, double gamma, double rand1, doubl
     double z = zc * zc * zc;
     double ln_rand = log(rand1), x;
     if (ln_rand < QED_CLASSICAL_SPECTRUM[0][1]) {
-        // cdf -> A x^(5/3) below the table, A = (9 / (5 pi)) Gamma(1/3) 2^(-2/3); x = A^(-3/5) r^(3/5)
-        x = 1.0203772548972 * pow(rand1, 0.6);
+        // cdf -> A x^(5/3) below the table; the reference carries A^(-3/5) as a 10-digit literal (:275)
+        x = QED_CLASSICAL_SMALL_X_COEFF * pow(rand1, 0.6);
     } else {
         double ln_x;
         if (!pwmci_invert(ln_rand, QED_CLASSICAL_SPECTRUM, 41, ln_x)) ln_x = QED_CLASSICAL_SPECTRUM[40][0];

@@ -673,8 +673,11 @@ static double photon_ke(const Photon *p)
 }
 
 /* ------------------------------------------------------- photon emission */
-/* Sampling tables: generated from the emission rate by tools/make_qed_tables.py (the reference's
- * photon_emission_tables.rs plays this role; its numbers are not used). */
+/* Sampling tables: the reference's numbers (photon_emission_tables.rs:15,1371,1406 and
+ * photon_emission.rs:209), transcribed as constant data by tools/transcribe_qed_tables.py.  That this
+ * restatement + these numbers reproduce photon_emission::sample is pinned by tests/golden/
+ * qed_sample_reference_tables.json, written by an independent Python restatement that parses the
+ * reference's table file itself (tests/golden/make_golden_qed_sample.py). */
 typedef struct { double coeff, power; double table[31][2]; } QedCdf;
 #define QED_TABLE_QUAL const
 #include "qed_tables.inc"
@@ -828,8 +831,9 @@ static double from_linear_cdf_table(double global_zero, double local_zero, doubl
 }
 
 /* the small-x limit of the classical cdf, (3/pi) int_0^x t K_{1/3}(t) dt -> A x^(5/3) with
- * A = (9 / (5 pi)) Gamma(1/3) 2^(-2/3); photon_emission.rs:275 carries its inverse as a literal */
-#define CLASSICAL_SMALL_X_COEFF 1.0203772548972 /* A^(-3/5) */
+ * A = (9 / (5 pi)) Gamma(1/3) 2^(-2/3); photon_emission.rs:275 carries A^(-3/5) as the literal
+ * 1.020377255, which is what QED_CLASSICAL_SMALL_X_COEFF holds */
+#define CLASSICAL_SMALL_X_COEFF QED_CLASSICAL_SMALL_X_COEFF
 
 /* photon_emission.rs:264-292; out = omega/mc^2, theta, phi */
 void oracle_qed_classical_sample(double chi, double gamma, double rand1, double rand2, double rand3, double *out)

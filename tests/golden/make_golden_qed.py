@@ -3,9 +3,10 @@
 
 Like pic_step_vectors.json these are restatement-generated (the Rust reference cannot run here): they come
 from the CPU oracle, whose pwmci / vec3 / rate functions are pinned by the reference's known-answer tests
-and whose sampler is pinned to the emission rate by quadrature (tests/test_qed_oracle.py).  They freeze the
-oracle AND the generated sampling tables (opal_amd/csrc/qed_tables.inc), and give the GPU tests inputs and
-outputs that do not depend on the oracle.
+and whose sampler is pinned bit for bit by qed_sample_reference_tables.json (an independent restatement on the
+reference's own tables, make_golden_qed_sample.py).  They freeze the oracle and the transcribed sampling
+tables (opal_amd/csrc/qed_tables.inc), and give the GPU tests inputs and outputs that do not depend on the
+oracle at run time.
 
 Contents
   philox   : Random123's published known answers for philox4x32-10

@@ -111,21 +111,42 @@ def _cdf_z(z, u, chi):
 GAMMA = 1000.0
 
 
+def _physics():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_qed_tables", os.path.join(root, "tools", "make_qed_tables.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 @pytest.mark.filterwarnings("ignore")
 @pytest.mark.parametrize("chi", [0.0101, 0.05, 0.3, 1.0, 3.3, 20.0, 99.0])
 def test_quantum_energy_sampling_matches_the_rate(chi):
     """sample()'s photon energy for rand1 = q must be the q-quantile of dN/du: checked against quadrature
-    from deep in the power-law region (q = 1e-4) to the cut-off tail (1 - q = 1e-5)."""
+    from deep in the power-law region (q = 1e-4) into the tail.  Tolerances are what the REFERENCE's tables
+    deliver (they are the tables in use): 31 rows uniform in ln u give quantiles within 1 % of min(q, 1-q) in
+    the body; the tables stop at 1 - cdf between 2.5e-12 (chi = 0.01) and 2.4e-3 (chi = 100) and
+    photon_emission.rs:152,161 clips ln u to the last row beyond that, which is reproduced, not corrected."""
+    tabs = _physics().committed_tables()["quantum"]
+    pos = (math.log(chi) - math.log(0.01)) / (math.log(10.0) / 10.0)
+    k, w = int(pos), pos - int(pos)
+    u_clip = math.exp((1.0 - w) * tabs[k][2][-1, 0] + w * tabs[k + 1][2][-1, 0])
     for q in (1e-4, 0.01, 0.1, 0.3, 0.5, 0.7, 0.9, 0.99):
         om, _, _ = O.qed_sample(chi, GAMMA, q, 0.5, 0.3)
         f = om / GAMMA
         lo, hi = _cdf_u(f / (1.0 - f), chi)
-        assert abs(lo - q) < 5e-3 * min(q, 1.0 - q), (chi, q, lo)
+        assert abs(lo - q) < 1e-2 * min(q, 1.0 - q), (chi, q, lo)
     for tail in (1e-3, 1e-4, 1e-5):
         om, _, _ = O.qed_sample(chi, GAMMA, 1.0 - tail, 0.5, 0.3)
         f = om / GAMMA
-        lo, hi = _cdf_u(f / (1.0 - f), chi)
-        assert abs(hi - tail) < 0.15 * tail, (chi, tail, hi)
+        u = f / (1.0 - f)
+        lo, hi = _cdf_u(u, chi)
+        assert u <= u_clip * (1.0 + 1e-9)
+        if u > u_clip * (1.0 - 1e-4):
+            assert hi > 0.4 * tail, (chi, tail, hi)   # clipped at the table's end: the true quantile lies beyond
+        else:
+            assert abs(hi - tail) < 0.6 * tail, (chi, tail, hi)
 
 
 @pytest.mark.filterwarnings("ignore")
@@ -139,7 +160,7 @@ def test_quantum_angle_sampling_matches_the_rate(chi):
             assert ph == pytest.approx(2.0 * math.pi * 0.25)
             f = om / GAMMA
             z = (2.0 * GAMMA ** 2 * (1.0 - be * math.cos(th))) ** 1.5
-            assert abs(_cdf_z(z, f / (1.0 - f), chi) - q2) < 6e-3, (chi, q1, q2)
+            assert abs(_cdf_z(z, f / (1.0 - f), chi) - q2) < 8e-3, (chi, q1, q2)
 
 
 @pytest.mark.filterwarnings("ignore")
@@ -158,7 +179,8 @@ def test_classical_sampling_matches_the_classical_spectrum():
             x = 2.0 * (om / GAMMA) * z_want / (3.0 * chi)
             # below cdf(0.02) = 1.35e-3 the reference switches to the leading power law x^(5/3)
             # (photon_emission.rs:274-275), whose first correction is O(x^(2/3)): a few per cent there
-            tol = 0.08 if q1 < 1.3e-3 else (0.05 if q1 > 0.999 else 4e-3)
+            # and the reference's 41-row ln-ln table interpolates the far tail to ~13 % of 1 - cdf
+            tol = 0.08 if q1 < 1.3e-3 else (0.2 if q1 > 0.999 else 4e-3)
             assert abs(cdf_x(x) - q1) < tol * min(q1, 1 - q1) + 1e-9, (q1, q2)
     assert O.qed_classical_sample(chi, GAMMA, 0.5, 0.0, 0.0)[1] < 1e-4 / GAMMA  # z = 1 at r = 0: emitted straight ahead
 
@@ -337,23 +359,78 @@ def test_rate_table_is_the_integral_of_the_spectrum():
         == pytest.approx(5.0 * math.pi / 3.0, rel=1e-5)
 
 
-def test_committed_tables_are_what_the_generator_writes(tmp_path, monkeypatch):
-    """opal_amd/csrc/qed_tables.inc is generated data: running tools/make_qed_tables.py again must reproduce the
-    committed file (same scipy -> byte for byte; otherwise to 1e-9 in every number)."""
+def test_committed_tables_are_the_reference_numbers():
+    """opal_amd/csrc/qed_tables.inc is constant data transcribed from the reference: re-parse the reference's
+    table file (build container only) and compare number by number."""
     import importlib.util
-    import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("make_qed_tables", os.path.join(root, "tools", "make_qed_tables.py"))
+    spec = importlib.util.spec_from_file_location("ref_qed_tables", os.path.join(root, "tools", "ref_qed_tables.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    if not ref.available():
+        pytest.skip("the reference tree is not present on this machine")
+    want, got = ref.load(), _physics().committed_tables()
+    for name in ("quantum", "y"):
+        assert len(want[name]) == len(got[name])
+        for w, (coeff, power, rows) in zip(want[name], got[name]):
+            assert (w["coeff"], w["power"]) == (coeff, power)
+            assert np.array_equal(np.array(w["table"]), rows)
+    coeff, power, rows = got["y_inf"]
+    assert (want["y_inf"]["coeff"], want["y_inf"]["power"]) == (coeff, power)
+    assert np.array_equal(np.array(want["y_inf"]["table"]), rows)
+    assert np.array_equal(np.array(want["classical"]), got["classical"])
+
+
+@pytest.mark.filterwarnings("ignore")
+def test_reference_tables_agree_with_quadrature():
+    """Physics cross-check of the transcription (tools/make_qed_tables.py): a sample of the tables against
+    direct quadrature of what they tabulate.  9-digit tables: 2e-7 in ln cdf, plus the reference's ~5e-12
+    absolute noise floor in the far tail of the low-chi tables."""
+    phys = _physics()
+    t = phys.committed_tables()
+    for i in (0, 13, 27, 40):
+        coeff, power, rows = t["quantum"][i]
+        d = np.abs(phys.quantum_ln_cdf(0.01 * 10.0 ** (i / 10.0), rows[:, 0]) - rows[:, 1])
+        assert d.max() < 2e-7, (i, d.max())
+        assert power == 1.0 / 3.0
+        # the head continues the table: coeff * u0^(1/3) ~ cdf(u0) (the reference's coefficients sit 0.1-0.2 % high)
+        assert coeff * math.exp(rows[0, 0]) ** power == pytest.approx(math.exp(rows[0, 1]), rel=4e-3)
+    for j in (0, 11, 30):
+        coeff, power, rows = t["y"][j]
+        assert np.abs(phys.y_cdf(0.1 * 10.0 ** (j / 10.0), rows[:, 0]) - rows[:, 1]).max() < 5e-8, j
+        assert power == 2.0
+    coeff, power, rows = t["y_inf"]
+    assert np.abs(phys.y_cdf(np.inf, rows[:, 0]) - rows[:, 1]).max() < 1e-8 and power == 4.0 / 3.0
+    assert np.abs(phys.classical_ln_cdf(t["classical"][:, 0]) - t["classical"][:, 1]).max() < 5e-8
+
+
+def _golden_sample_cases():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qed_sample_reference_tables.json")
+    doc = json.load(open(path))
+    return doc, [(c["fn"], [float.fromhex(v) for v in c["in"]], [float.fromhex(v) for v in c["out"]]) for c in doc["cases"]]
+
+
+def test_oracle_sample_reproduces_the_reference_table_vectors_bit_for_bit():
+    """tests/golden/qed_sample_reference_tables.json: an independent Python restatement of
+    photon_emission::sample / classical_sample on tables parsed from the reference's own file
+    (tests/golden/make_golden_qed_sample.py).  The C oracle -- other code, other copy of the numbers -- must
+    give the same doubles: same libm, same operation order."""
+    doc, cases = _golden_sample_cases()
+    assert len(cases) > 600 and len(doc["branches_covered"]) >= 14
+    for fn, args, want in cases:
+        got = O.qed_sample(*args) if fn == "sample" else O.qed_classical_sample(*args)
+        assert list(got) == want, (fn, args)
+
+
+def test_golden_sample_vectors_are_what_the_generator_writes(tmp_path, monkeypatch):
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if not os.path.exists("/root/reference/src/qed/photon_emission_tables.rs"):
+        pytest.skip("the reference tree is not present on this machine")
+    spec = importlib.util.spec_from_file_location("make_golden_qed_sample", os.path.join(here, "make_golden_qed_sample.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    monkeypatch.setattr(mod, "ROOT", str(tmp_path))
-    os.makedirs(tmp_path / "opal_amd" / "csrc")
+    monkeypatch.setattr(mod, "HERE", str(tmp_path))
     mod.main()
-    fresh = open(tmp_path / "opal_amd" / "csrc" / "qed_tables.inc").read()
-    committed = open(os.path.join(root, "opal_amd", "csrc", "qed_tables.inc")).read()
-    if fresh == committed:
-        return
-    num = re.compile(r"-?\d\.\d+e[+-]\d+")
-    a, b = np.array(num.findall(fresh), dtype=float), np.array(num.findall(committed), dtype=float)
-    assert re.sub(num, "#", fresh) == re.sub(num, "#", committed)  # same structure
-    assert np.allclose(a, b, rtol=1e-9, atol=1e-300)
+    assert open(tmp_path / "qed_sample_reference_tables.json").read() == open(os.path.join(here, "qed_sample_reference_tables.json")).read()
