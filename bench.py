@@ -2,17 +2,30 @@
 """Headline benchmark: particle-updates/s of the per-timestep PIC loop on N MI355X.
 
 One "step" = one iteration of src/main.rs:238-267 (push + deposit of every charged species, halo/
-boundary synchronisation, field solve) on synthetic two-stream input already resident in HBM.
-Per GPU the workload is BASELINE.json configs[1]: 4096 cells, 2441 electrons + 2441 positrons per
-cell (2 x 9 998 336 macro-particles), periodic, current deposition on, no QED; with N GPUs the
-domain is N x 4096 cells split into N subdomains (weak scaling).
+boundary synchronisation, field solve) on synthetic input already resident in HBM.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused push+deposit
-pass; one launch covers both species): algorithmic bytes = 80 B per particle-update x
-particles per launch, divided by the kernel's mean duration measured with HIP events around a 1-in-5
-sample of its launches in the timed region.
-`cpu_baseline` times the CPU oracle (a port of the reference's algorithm, not the opal binary) on a
-bounded sample of the same workload on this box's host cores.
+Default workload = north_star's target configuration, BASELINE.json configs[2]: two-stream, 32 768 cells,
+1526 electrons + 1526 positrons per cell (100 007 936 macro-particles), periodic, current deposition on,
+no QED.  N = 1 holds it on one GPU (4.4 GB); N > 1 splits the SAME domain into N subdomains, one per GPU,
+with RCCL neighbour exchange (strong scaling: `value` at N GPUs over `value` at 1 GPU is the speed-up
+north_star asks for).  `--weak` gives every GPU its own `--cells-per-gpu` x `--npc` block instead
+(default configs[1]: 4096 cells, 2441 + 2441 per cell).  At N = 1 the line also carries configs[1] as
+`secondary`, measured the same way in the same process.
+
+`python bench.py --gpus N` needs no launcher: with WORLD_SIZE unset the parent -- which never touches a
+GPU -- starts N ranks of itself as child processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on
+127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank failed.  Under torch.distributed.run
+the same file is simply one rank.  With fewer GPUs than ranks (a 1-GPU box) the ranks share the card and
+exchange through host buffers (gloo): a rehearsal of the decomposed step, labelled as such in `config`.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused push+deposit pass; one
+launch covers both species): algorithmic bytes = 80 B per particle-update x particles per
+launch, divided by the kernel's mean duration measured with HIP events on the simulation's stream around a
+1-in-5 sample of its launches in the timed region.  `cpu_baseline` times the CPU oracle in its
+reference-algorithm mode (AoS structs, comparison sort every step, per-thread private current arrays +
+serial reduce, serial field solve; a port of the reference's algorithm, not the opal binary) on a bounded
+sample of the workload on this box's host cores, S subdomains x T threads = all physical cores (the
+reference's MPI x Rayon layout), plus the 1 x 1 point for BASELINE configs[0].
 """
 import argparse
 import json
@@ -24,10 +37,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CELLS_PER_GPU = 4096
-NPC = 2441
+C3_CELLS, C3_NPC = 32768, 1526       # BASELINE configs[2] (north_star's 1e8-particle two-stream)
+C2_CELLS, C2_NPC = 4096, 2441        # BASELINE configs[1]
 BYTES_PER_UPDATE = 80.0   # read cell,x,u[3],w = 44 B; write cell,x,u[3] = 36 B
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PREHEAT_SECONDS = 0.3
 
 YAML = """---
 control:
@@ -67,6 +81,32 @@ constants:
  drift_u: 2.5e-24 / (me * c)
 """
 
+# BASELINE configs[0]: the parameters of the reference's examples/two_stream.yaml (1000 cells, 100 electrons
+# per cell, no ions) -- the reference's own CPU-runnable case, timed here on 1 subdomain x 1 thread
+C1_YAML = """---
+control:
+ dx: 500
+ nx: 1000
+ xmin: 0.0
+ start: 0.0
+ end: 0.1
+ current_deposition: true
+ n_outputs: 20
+qed:
+ photon_emission: false
+ photon_absorption: false
+electrons:
+ npc: 100
+ ne: 20.0
+ ux: drift_u * (1.0 + 0.001 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: 0.0
+ uz: 0.0
+ output: x:px
+ions:
+ npc: 0
+constants:
+ drift_u: 2.5e-24 / (me * c)
+"""
 
 # BASELINE configs[3]: examples/hole_boring.yaml's physics (a0 = 300 laser on an overdense electron-carbon slab,
 # laser + absorbing boundaries, balanced decomposition) with npc scaled; the whole 20 000-cell domain is divided
@@ -118,41 +158,156 @@ constants:
 """
 
 
-def cpu_baseline(oa, target_seconds=12.0):
-    """Times the oracle (OpenMP over particle chunks, one subdomain) on a bounded sample of the
-    workload: same grid, same physics, 1/10 of the particles per cell, a few steps."""
+def host_cpu():
+    """(model name, physical cores this process may run on, logical cpus it may run on)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur.get("processor") in allowed:
+                    cores.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = [s.strip() for s in line.split(":", 1)]
+            if k == "model name":
+                model = v
+            elif k in ("processor", "physical id", "core id"):
+                cur[k] = int(v)
+        if cur.get("processor") in allowed:
+            cores.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    return model, (len(cores) or len(allowed)), len(allowed)
+
+
+def _oracle_world(oa, o, yaml_text, dx, nx, S):
+    """Initial state from the product's loader, split into S in-process subdomains of AoS populations
+    (what GridDesign::unbalanced + Population::new give each MPI rank of the reference)."""
     import numpy as np
+    sim = oa.Simulation(yaml_text=yaml_text)
+    dt = sim.dt
+    se = sim.electrons.soa()
+    si = sim.ions.soa() if sim.ions is not None and len(sim.ions) else None
+    del sim
+    nxs, off = o.design_unbalanced(S, nx, dx)
+    grids, pes, pis = [], [], ([] if si is not None else None)
+    lo = 0
+    for r in range(S):
+        grids.append(o.Grid(r, S, o.BDY_INTERNAL, o.BDY_INTERNAL, 0.0, dx, nxs, off))
+        hi = lo + int(nxs[r])
+        for src, species, dst in ((se, o.ELECTRON, pes), (si, o.ION, pis)):
+            if src is None:
+                continue
+            m = (src["cell"] >= lo) & (src["cell"] < hi)
+            p = o.Population.from_soa(species, src["cell"][m].astype(np.int64) - lo, src["x"][m], src["ux"][m],
+                                      src["uy"][m], src["uz"][m], src["w"][m], dx, dt)
+            if species == o.ION:
+                p.set_charge_state(1.0, 1.0, 9.109383e-31 / 1.672622e-27)
+            dst.append(p)
+        lo = hi
+    return grids, pes, pis, dt
+
+
+def _time_oracle(o, grids, pes, pis, dt, threads, target_seconds, max_steps):
+    n = sum(len(p) for p in pes) + (sum(len(p) for p in pis) if pis else 0)
+    t0 = time.perf_counter()
+    bad = o.world_run_periodic(grids, pes, pis, True, 0.0, dt, 2, threads)
+    per_step = (time.perf_counter() - t0) / 2
+    steps = int(max(3, min(max_steps, target_seconds / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    bad += o.world_run_periodic(grids, pes, pis, True, 2 * dt, dt, steps, threads)
+    el = time.perf_counter() - t0
+    assert bad == 0
+    return n, steps, n * steps / el
+
+
+def cpu_baseline(oa, cells, npc, target_seconds=14.0):
+    """Times the oracle in reference-algorithm mode on a bounded sample of the workload: 4096 cells at the
+    FULL particles-per-cell (what one of configs[2]'s 8 ranks holds, or all of configs[1]) as S subdomains x
+    T threads = all physical cores (the reference's MPI x Rayon layout); then configs[0] on 1 x 1."""
     from oracle import oracle as o
 
     o.build()
-    npc_s = NPC // 10
-    sim = oa.Simulation(yaml_text=YAML.format(nx=CELLS_PER_GPU, npc=npc_s))
-    dx, dt = 500.0, sim.dt
-    se, si = sim.electrons.soa(), sim.ions.soa()
-    del sim
-    threads = max(1, min(o.max_threads(), len(os.sched_getaffinity(0)), 16))  # a 1-GPU box gets a 16-core share
-    grid = o.Grid.single(CELLS_PER_GPU, 0.0, dx)
-    pe = o.Population.from_soa(o.ELECTRON, se["cell"], se["x"], se["ux"], se["uy"], se["uz"], se["w"], dx, dt)
-    pi = o.Population.from_soa(o.ION, si["cell"], si["x"], si["ux"], si["uy"], si["uz"], si["w"], dx, dt)
-    pi.set_charge_state(1.0, 1.0, 9.109383e-31 / 1.672622e-27)
-    n = len(pe) + len(pi)
-    t0 = time.perf_counter()
-    o.world_run_periodic([grid], [pe], [pi], True, 0.0, dt, 2, threads)
-    per_step = (time.perf_counter() - t0) / 2
-    steps = int(max(3, min(200, target_seconds / max(per_step, 1e-6))))
-    t0 = time.perf_counter()
-    bad = o.world_run_periodic([grid], [pe], [pi], True, 2 * dt, dt, steps, threads)
-    el = time.perf_counter() - t0
-    assert bad == 0
+    o.set_sort_mode(1)   # comparison sort of the AoS structs every step, as the reference's par_sort_unstable_by_key
+    o.set_parallel_subdomains(True)
+    try:
+        model, phys, logical = host_cpu()
+        cores = max(1, min(o.max_threads(), phys))
+        S = 8 if cores >= 16 else 1
+        T = max(1, cores // S)
+        dx = 500.0
+        cells_s = min(cells, 4096)
+        grids, pes, pis, dt = _oracle_world(oa, o, YAML.format(nx=cells_s, npc=npc), dx, cells_s, S)
+        n, steps, rate = _time_oracle(o, grids, pes, pis, dt, T, target_seconds, 200)
+        del grids, pes, pis
+        g1, pe1, _, dt1 = _oracle_world(oa, o, C1_YAML, dx, 1000, 1)
+        n1, steps1, rate1 = _time_oracle(o, g1, pe1, None, dt1, 1, 5.0, 2000)
+    finally:
+        o.set_sort_mode(0)
+        o.set_parallel_subdomains(False)
     return {
-        "value": n * steps / el,
+        "value": rate,
         "unit": "particle-updates/s",
-        "cores": threads,
+        "cores": S * T,
         "kind": "port",
-        "sample": f"two_stream e-+e+, {CELLS_PER_GPU} cells, npc {npc_s}+{npc_s} ({n} particles), {steps} steps, "
-                  f"C oracle with OpenMP over {threads} particle chunks (per-step counting sort, per-chunk private "
-                  f"current arrays + serial reduce, serial field solve)",
+        "cpu_model": model,
+        "physical_cores": phys,
+        "logical_cpus": logical,
+        "S": S,
+        "T": T,
+        "sample": f"two_stream e-+e+, {cells_s} of {cells} cells at the full {npc}+{npc} per cell ({n} particles), "
+                  f"{steps} steps; CPU restatement of opal's algorithm (C oracle, not the opal binary): AoS structs, "
+                  f"parallel comparison sort by cell every step, per-thread private current arrays + serial reduce, "
+                  f"serial field solve per subdomain; {S} subdomains x {T} OpenMP threads (MPI x Rayon layout)",
+        "config0_1x1": {
+            "value": rate1,
+            "unit": "particle-updates/s",
+            "cores": 1,
+            "S": 1,
+            "T": 1,
+            "sample": f"BASELINE configs[0] (examples/two_stream.yaml's parameters: 1000 cells, {n1} electrons), "
+                      f"{steps1} steps, same restatement on 1 subdomain x 1 thread",
+        },
     }
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-rank run.  Makes no GPU call (imports neither torch nor the library)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.05)
+    if failed is None:
+        failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:      # the exact children started above, nothing else
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        print(f"[bench] rank {failed} exited with status {procs[failed].returncode}", file=sys.stderr)
+        return 1
+    line = procs[0].stdout.read().decode().strip().splitlines()
+    if not line:
+        print("[bench] rank 0 printed no result", file=sys.stderr)
+        return 1
+    print(line[-1], flush=True)
+    return 0
 
 
 def main():
@@ -161,17 +316,23 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--npc", type=int, default=NPC)
-    ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU,
-                    help="other BASELINE configs, e.g. configs[2] on one GPU: --cells-per-gpu 32768 --npc 1526")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] measurement of the N=1 line")
+    ap.add_argument("--cells", type=int, default=None, help="total cells of the (strong-scaling) two-stream domain")
+    ap.add_argument("--npc", type=int, default=None, help="macro-particles per cell and species")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: every GPU gets --cells-per-gpu cells")
+    ap.add_argument("--cells-per-gpu", type=int, default=None,
+                    help=f"implies --weak; default {C2_CELLS} (with npc {C2_NPC}: BASELINE configs[1] per GPU)")
     ap.add_argument("--unfused", action="store_true", help="time the reference's operator sequence instead")
     ap.add_argument("--workload", choices=["two_stream", "laser_plasma"], default="two_stream",
-                    help="two_stream (default; BASELINE configs[1] per GPU, weak scaling) or laser_plasma "
+                    help="two_stream (default; BASELINE configs[2], strong scaling) or laser_plasma "
                          "(configs[3]'s physics, --npc per cell in 5000 of 20000 cells, strong scaling)")
     ap.add_argument("--self-exchange", action="store_true",
                     help="N=1 rehearsal of the multi-GPU step: the lone periodic subdomain sends its halo and leavers "
-                         "to itself through RCCL (pack kernels, torch.distributed P2P, unpack) instead of wrapping in place")
+                         "to itself through RCCL (pack kernels, RCCL send/recv, unpack) instead of wrapping in place")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly one JSON line: everything else that libraries print there (RCCL's version banner
     # at communicator creation, for one) is sent to stderr
@@ -185,18 +346,35 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # OPAL_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the
-    # visible GPUs and exchange through host buffers.  The driver's runs use nccl (= RCCL over xGMI).
-    backend = os.environ.get("OPAL_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # Fewer GPUs than ranks (a 1-GPU box): the ranks share the card and exchange through host buffers over
+    # gloo -- a rehearsal of the decomposed step.  The driver's multi-GPU runs use nccl (= RCCL over xGMI).
+    backend = os.environ.get("OPAL_BENCH_BACKEND") or ("nccl" if ndev >= world else "gloo")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     oa.set_device(dev_index)
-    link_kind = os.environ.get("OPAL_BENCH_LINK", "rccl")
-    # leavers per species, neighbour and step that a message has room for: the two-stream flux through a cut is
-    # npc * <|v_x|> dt / dx ~ 2441 * 0.009 ~ 25 per step, so 1024 is 40x headroom (an overflow is reported, not
-    # silent); messages are fixed-size, 704 B + 2 species * 1024 * 52 B = 107 KB per neighbour per step
-    LINK_CAPACITY = 1024
+    link_kind = os.environ.get("OPAL_BENCH_LINK", "rccl") if backend == "nccl" else "gloo"
+
+    weak = args.weak or args.cells_per_gpu is not None
+    if args.workload == "laser_plasma":
+        npc = args.npc if args.npc is not None else 2000
+        nx = 20000
+        # a relativistic front carries ~0.95 npc particles per step and species through a cut
+        link_capacity = max(1024, 2 * npc)
+    else:
+        if weak:
+            cells_per_gpu = args.cells_per_gpu or C2_CELLS
+            npc = args.npc if args.npc is not None else C2_NPC
+            nx = cells_per_gpu * world
+        else:
+            nx = args.cells or C3_CELLS
+            npc = args.npc if args.npc is not None else C3_NPC
+        # two-stream flux through a cut: npc <|v_x|> dt / dx ~ 0.009 npc per step; 1024 is > 40x headroom
+        # up to npc = 2441 (an overflow is reported as an error, never silent)
+        link_capacity = max(1024, npc // 2)
 
     def make_link(r, w, device):
         """Neighbour transport over RCCL: native (the library issues the send/recv itself on the simulation's
@@ -207,154 +385,217 @@ def main():
             try:
                 if os.environ.get("OPAL_BENCH_EXACT"):  # diagnostic: big buffers, messages sized to their content
                     return RcclLink(r, w, device, particle_capacity=1 << 18, exact=True)
-                return RcclLink(r, w, device, particle_capacity=LINK_CAPACITY)
+                return RcclLink(r, w, device, particle_capacity=link_capacity)
             except Exception as e:  # e.g. no librccl to open: the torch.distributed transport does the same job
                 print(f"[bench] native RCCL link unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
                 link_kind = "torch"
-        return TorchLink(r, w, device, particle_capacity=LINK_CAPACITY)
+        return TorchLink(r, w, device, particle_capacity=link_capacity)
 
+    dist = None
     link = None
-    if args.self_exchange and world == 1:
+    if world > 1 or args.self_exchange:
         import torch.distributed as dist
-        from opal_amd.exchange import TorchLink
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
-        link = make_link(0, 1, torch.device("cuda", dev_index))
-    if world > 1:
-        import torch.distributed as dist
-        from opal_amd.exchange import TorchLink
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
             link = make_link(rank, world, torch.device("cuda", dev_index))
         else:
-            dist.init_process_group(backend)
-            link = TorchLink(rank, world, torch.device("cpu"))
+            from opal_amd.exchange import TorchLink
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=link_capacity)
     red_dev = "cuda" if backend == "nccl" else "cpu"
+    rccl_ranks = None
+    if link is not None and hasattr(link, "rccl_ranks"):
+        try:
+            rccl_ranks = link.rccl_ranks()
+        except Exception as e:
+            print(f"[bench] {e}", file=sys.stderr)
 
     stream = torch.cuda.current_stream().cuda_stream
-    cells_per_gpu = args.cells_per_gpu
-    nx = cells_per_gpu * world
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_sum(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def measure(sim, steps, warmup):
+        """Pre-heat (untimed, >= PREHEAT_SECONDS of steps so that clocks and caches are those of a running job),
+        W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
+        n_local = len(sim.electrons) + (len(sim.ions) if sim.ions is not None else 0)
+        barrier()
+        t0 = time.perf_counter()
+        sim.step(10)
+        sim.sync()
+        per_step = all_max((time.perf_counter() - t0) / 10)
+        preheat = 10
+        more = int(min(5000, max(0.0, PREHEAT_SECONDS - 10 * per_step) / max(per_step, 1e-7)))  # same on every rank
+        if more:
+            sim.step(more)
+            sim.sync()
+            preheat += more
+        sim.step(warmup)
+        sim.sync()
+        oa.prof_reset()
+        # HIP events around every 5th launch of each tracked kernel (an odd stride samples both species);
+        # timing every launch costs ~10 % of the step because each event record breaks back-to-back dispatch
+        oa.prof_enable(5)
+        barrier()
+        t0 = time.perf_counter()
+        sim.step(steps)
+        sim.sync()
+        barrier()
+        elapsed = all_max(time.perf_counter() - t0)
+        oa.prof_enable(0)
+        n_total = int(all_sum(n_local))
+        kname = "fused" if not args.unfused else "advance"
+        launches, total_ms = oa.prof_get(kname)
+        sort_launches, sort_ms = oa.prof_get("sort")
+        field_launches, field_ms = oa.prof_get("field")
+        # the dominant kernel covers this rank's particles once per step, in one launch (species paired) or two
+        launches_total = oa.prof_seen(kname)
+        per_launch = n_local * steps / max(launches_total, 1)
+        avg_ms = total_ms / max(launches, 1)
+        achieved = BYTES_PER_UPDATE * per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        value = n_total * steps / elapsed
+        roof = {
+            "bound": "hbm",
+            "kernel": "k_push_pair<fused>" if not args.unfused else "k_push_pair<advance>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "launches_timed": launches,
+            "launches_total": launches_total,
+            "avg_launch_ms": avg_ms,
+            "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * per_launch,
+            "other_kernels_avg_ms": {"field_solve": field_ms / max(field_launches, 1), "rebin": sort_ms / max(sort_launches, 1)},
+            "rebins_in_timed_region": oa.prof_seen("sort"),
+        }
+        # PMC-measured HBM bytes per particle-update: a separate rocprofv3 --pmc run of this command (the
+        # counters cannot be read from inside the process); the file names the profile it came from
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                roof["traffic"] = tj["hbm_bytes_per_particle_update"] * per_launch
+                roof["traffic_source"] = tj.get("source", "profiles/traffic.json") + " (separate rocprofv3 --pmc run; not measured in this process)"
+            except Exception:
+                roof["traffic"] = None
+        return {"value": value, "elapsed": elapsed, "n_total": n_total, "preheat": preheat, "roofline": roof}
+
     if args.workload == "laser_plasma":
-        nx = 20000
-        sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=args.npc), rank=rank, numtasks=world, link=link,
-                            stream=stream)
+        sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
     else:
-        sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=args.npc), rank=rank, numtasks=world, link=link,
-                            stream=stream)
+        sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
     sim.set_fused(not args.unfused)
     if args.self_exchange and world == 1:
         sim.grid.set_self_exchange(True)
     if os.environ.get("OPAL_BENCH_OVERLAP", "0") == "1":  # diagnostic: exchange on a second stream under the bulk push
         sim.set_overlap(True)
-    n_local = len(sim.electrons) + len(sim.ions)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    sim.step(args.warmup)
-    sim.sync()
-    oa.prof_reset()
-    # HIP events around every 5th launch of each tracked kernel (an odd stride samples both species);
-    # timing every launch costs ~10 % of the step because each event record breaks back-to-back dispatch
-    oa.prof_enable(5)
-    barrier()
-    t0 = time.perf_counter()
-    sim.step(args.steps)
-    sim.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    oa.prof_enable(0)
-
-    n_total = n_local
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        nn = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
-        n_total = int(nn.item())
-
-    kname = "fused" if not args.unfused else "advance"
-    launches, total_ms = oa.prof_get(kname)
-    sort_launches, sort_ms = oa.prof_get("sort")
-    field_launches, field_ms = oa.prof_get("field")
-    # the dominant kernel covers this rank's particles once per step, in one launch (species paired) or two
-    launches_total = oa.prof_seen(kname)
-    per_launch_particles = n_local * args.steps / max(launches_total, 1)
-    avg_ms = total_ms / max(launches, 1)
-    achieved = BYTES_PER_UPDATE * per_launch_particles / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            # PMC-measured HBM bytes per particle-update (profiles/r01_pmc_hbm.json) x updates per launch
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_particle_update") * per_launch_particles
-        except Exception:
-            traffic = None
+    m = measure(sim, args.steps, args.warmup)
+    t_end = sim.t
 
     if rank == 0:
-        value = n_total * args.steps / elapsed
+        if args.workload == "two_stream":
+            named = ("BASELINE configs[2]" if (nx, npc) == (C3_CELLS, C3_NPC) and not weak else
+                     "BASELINE configs[1] per GPU" if weak and (nx // world, npc) == (C2_CELLS, C2_NPC) else "custom size")
+            workload = (f"two_stream, {npc} e- + {npc} e+ per cell, {nx} cells"
+                        + (f" ({nx // world} per GPU, weak scaling)" if weak else f" split into {world} subdomain(s)")
+                        + f" ({named}), periodic, push+deposit+field, no QED")
+        else:
+            workload = (f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]), {npc} e- + {npc} C6+ per "
+                        f"cell in 5000 of 20000 cells, laser + absorbing boundaries, t = {t_end:.3e} s at the end of the "
+                        f"timed steps")
+        if link is None:
+            link_desc = "none (one periodic subdomain wraps in place)"
+        elif backend != "nccl":
+            link_desc = f"REHEARSAL: {world} ranks share {ndev} GPU(s), host-staged gloo exchange"
+        else:
+            link_desc = ("native RCCL send/recv on the simulation stream" if link_kind == "rccl" else "torch.distributed P2P (RCCL)") \
+                + (", self-exchange (multi-GPU step rehearsed on one GPU)" if args.self_exchange and world == 1 else "")
         out = {
             "metric": "particle-updates/sec",
-            "value": value,
+            "value": m["value"],
             "unit": "particle-updates/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "preheat_steps": m["preheat"],
+            "ms_per_step": 1e3 * m["elapsed"] / args.steps,
             "higher_is_better": True,
-            "scaling": "weak" if args.workload == "two_stream" else "strong",
+            "scaling": "weak" if (weak and args.workload == "two_stream") else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"two_stream, {args.npc} e- + {args.npc} e+ per cell, {cells_per_gpu} cells per GPU "
-                             + ("(BASELINE configs[1] per GPU)" if (cells_per_gpu, args.npc) == (CELLS_PER_GPU, NPC) else "")
-                             + ", periodic, push+deposit+field, no QED") if args.workload == "two_stream" else
-                            (f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]), {args.npc} e- + {args.npc} C6+ per "
-                             f"cell in 5000 of 20000 cells, laser + absorbing boundaries, t = {sim.t:.3e} s at the end of the "
-                             f"timed steps"),
-                "particles_total": n_total,
+                "workload": workload,
+                "particles_total": m["n_total"],
                 "cells_total": nx,
                 "path": "fused advance+deposit" if not args.unfused else "advance, clear, deposit (reference order)",
-                "parallelism": f"{world} subdomain(s), 1 per GPU"
-                               + (", self-exchange through RCCL (multi-GPU step rehearsed on one GPU)" if args.self_exchange else "")
-                               + (f", neighbour exchange: {'native RCCL send/recv' if link_kind == 'rccl' else 'torch.distributed P2P'}"
-                                  if link is not None and backend == "nccl" else ""),
-                "frac_of_hbm_roofline_whole_step": value * BYTES_PER_UPDATE / (world * HBM_PEAK_GBS * 1e9),
+                "parallelism": f"{world} subdomain(s), 1 per GPU" if backend == "nccl" or world == 1 else f"{world} subdomains on {ndev} GPU(s)",
+                "link": link_desc,
+                "link_particle_capacity": link_capacity if link is not None else None,
+                "rccl_ranks": rccl_ranks,
+                "frac_of_hbm_roofline_whole_step": m["value"] * BYTES_PER_UPDATE / (world * HBM_PEAK_GBS * 1e9),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_push<fused>" if not args.unfused else "k_push<advance>",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "launches_timed": launches,
-                "launches_total": launches_total,
-                "avg_launch_ms": avg_ms,
-                "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * per_launch_particles,
-                "other_kernels_avg_ms": {"field_solve": field_ms / max(field_launches, 1), "rebin": sort_ms / max(sort_launches, 1)},
-                "rebins_in_timed_region": oa.prof_seen("sort"),
-            },
+            "roofline": m["roofline"],
         }
+        del sim
+        if world == 1 and args.workload == "two_stream" and not weak and not args.no_secondary and not args.self_exchange \
+                and (nx, npc) == (C3_CELLS, C3_NPC):
+            sim2 = oa.Simulation(yaml_text=YAML.format(nx=C2_CELLS, npc=C2_NPC), stream=stream)
+            sim2.set_fused(not args.unfused)
+            m2 = measure(sim2, args.steps, args.warmup)
+            del sim2
+            out["secondary"] = {
+                "workload": f"two_stream, {C2_NPC} e- + {C2_NPC} e+ per cell, {C2_CELLS} cells (BASELINE configs[1]), 1 GPU",
+                "value": m2["value"],
+                "unit": "particle-updates/s",
+                "particles_total": m2["n_total"],
+                "steps": args.steps,
+                "preheat_steps": m2["preheat"],
+                "ms_per_step": 1e3 * m2["elapsed"] / args.steps,
+                "frac_of_hbm_roofline_whole_step": m2["value"] * BYTES_PER_UPDATE / (HBM_PEAK_GBS * 1e9),
+                "roofline": m2["roofline"],
+            }
         if not args.no_cpu_baseline and world == 1 and args.workload == "two_stream":
-            del sim
-            out["cpu_baseline"] = cpu_baseline(oa)
+            out["cpu_baseline"] = cpu_baseline(oa, nx, npc)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1 or args.self_exchange:
-        import torch.distributed as dist
+    else:
+        del sim
+    if dist is not None:
+        # success path only: a rank that failed above has already left with a non-zero status, and its peers
+        # are torn down by the launcher instead of waiting in a collective that can never match
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)   # no barrier, no destroy_process_group: let the launcher tear the peers down

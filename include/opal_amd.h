@@ -250,6 +250,9 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
 int opal_rccl_unique_id(const char *librccl_path, void *id128);
 int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle_capacity, int species_slots,
                           int fields_per_particle, const char *librccl_path, const void *unique_id, void *hip_stream);
+/* Ranks of the RCCL communicator behind a link made by opal_link_create_rccl (ncclCommCount): lets a caller
+ * report that the subdomains really are joined by one RCCL communicator. */
+int opal_link_rccl_ranks(const opal_link_t *l, int *out);
 /* on != 0: whole-message exchanges ship the 704-byte head first and then only the occupied part of every
  * column (one host synchronisation per exchange) instead of all `particle_capacity` slots: for links sized
  * for a large peak flux.  Off by default. */

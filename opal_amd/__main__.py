@@ -50,12 +50,18 @@ def main(argv):
             print(f"Running {world} task{'s' if world > 1 else ''} on {world} GPU{'s' if world > 1 else ''}...")
         sim.run()
     except oa.OpalError as e:
+        # No barrier here: the peers are still inside opal_sim_run issuing send/recv and all-reduces to this
+        # rank, so a collective entered from the error path could never match.  Leave with a non-zero status
+        # at once and let the launcher (torch.distributed.run) tear the other ranks down -- the reference's
+        # panics end an MPI job the same way.
         print(e, file=sys.stderr)
-        return 1
-    finally:
+        sys.stderr.flush()
         if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+            os._exit(1)
+        return 1
+    if world > 1:  # success path only
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

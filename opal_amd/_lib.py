@@ -92,6 +92,7 @@ SIGNATURES = {
     "opal_pop_write_data": (C.c_int, [vp, vp, C.c_char_p, sz, C.c_char_p, C.POINTER(C.c_char_p), sz]),
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),
     "opal_link_set_exact": (C.c_int, [vp, C.c_int]),
+    "opal_link_rccl_ranks": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "opal_rccl_unique_id": (C.c_int, [C.c_char_p, vp]),
     "opal_link_create_rccl": (C.c_int, [pp, C.c_int, C.c_int, sz, C.c_int, C.c_int, C.c_char_p, vp, vp]),
     "opal_link_create_layout": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.c_int, EXCHANGE_FN, vp, vp]),

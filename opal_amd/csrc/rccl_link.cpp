@@ -24,6 +24,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -43,6 +44,7 @@ int load_api(const char *path, RcclApi &api)
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
     api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
     api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
     api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
@@ -222,6 +224,25 @@ int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle
     }
     (*out)->user_free = rccl_free;
     (*out)->set_stream = [](void *user, hipStream_t s) { static_cast<RcclState *>(user)->stream = s; };
+    return OPAL_OK;
+}
+
+int opal_link_rccl_ranks(const opal_link_t *l, int *out)
+{
+    if (!l || !out || l->user_free != rccl_free) {
+        set_error("opal_link_rccl_ranks: not a link created with opal_link_create_rccl");
+        return OPAL_ERR_ARG;
+    }
+    const RcclState *st = static_cast<const RcclState *>(l->user);
+    if (!st->api.CommCount) {
+        set_error("this RCCL does not export ncclCommCount");
+        return OPAL_ERR_LINK;
+    }
+    ncclResult_t r = st->api.CommCount(st->comm, out);
+    if (r != ncclSuccess) {
+        set_error("ncclCommCount failed: %s", st->api.GetErrorString(r));
+        return OPAL_ERR_LINK;
+    }
     return OPAL_OK;
 }
 

@@ -164,6 +164,13 @@ class RcclLink:
             self._lib.opal_link_free(self.h)
             self.h = None
 
+    def rccl_ranks(self):
+        """ncclCommCount of the communicator the subdomains exchange through."""
+        n = C.c_int(0)
+        if self._lib.opal_link_rccl_ranks(self.h, C.byref(n)):
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        return n.value
+
 
 class TorchCollectives:
     """The output-time reductions of a decomposed run (opal_sim_set_collectives) on torch.distributed:

@@ -1167,6 +1167,91 @@ static inline void pshift(Population *p, void *store, size_t i, long delta)
     else ((Photon *)store)[i].cell += delta;
 }
 
+/* The reference sorts the AoS structs with rayon's par_sort_unstable_by_key (mod.rs:288): a parallel
+ * comparison sort, O(N log N) moves of 104-112 byte structs every step.  Sort mode 1 does that class of
+ * work, for bench.py's CPU baseline: qsort of one chunk per thread, then log2(T) rounds of pairwise
+ * merges, each merge split by key among the threads.  Mode 0 (default, what the parity tests use) is the
+ * stable counting sort below; the reference leaves tie order unspecified, so both are "its" result. */
+static int g_sort_mode = 0;
+void oracle_set_sort_mode(int mode) { g_sort_mode = mode; }
+/* S subdomains x T threads, the reference's MPI x Rayon layout, inside one process: with this on, the
+ * world_* loops over subdomains run one OpenMP thread per subdomain (the "ranks") and every subdomain's
+ * particle loops use `nthreads` nested threads (its Rayon pool).  Results do not depend on it. */
+static int g_parallel_subdomains = 0;
+void oracle_set_parallel_subdomains(int on)
+{
+    g_parallel_subdomains = on;
+#ifdef _OPENMP
+    omp_set_max_active_levels(on ? 2 : 1);
+#endif
+}
+
+static int cmp_cell(const void *a, const void *b)
+{
+    long x = *(const long *)a, y = *(const long *)b; /* `cell` is the first member of every species struct */
+    return (x > y) - (x < y);
+}
+/* first index in [lo, hi) whose cell is >= key */
+static size_t lower_bound_cell(const char *base, size_t sz, size_t lo, size_t hi, long key)
+{
+    while (lo < hi) {
+        size_t mid = lo + (hi - lo) / 2;
+        if (*(const long *)(base + mid * sz) < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+static void merge_runs(const char *src, char *dst, size_t sz, size_t a, size_t ae, size_t b, size_t be, size_t out)
+{
+    while (a < ae && b < be) {
+        if (*(const long *)(src + b * sz) < *(const long *)(src + a * sz)) memcpy(dst + (out++) * sz, src + (b++) * sz, sz);
+        else memcpy(dst + (out++) * sz, src + (a++) * sz, sz);
+    }
+    if (a < ae) memcpy(dst + out * sz, src + a * sz, (ae - a) * sz), out += ae - a;
+    if (b < be) memcpy(dst + out * sz, src + b * sz, (be - b) * sz);
+}
+static void comparison_sort(char *base, size_t num, size_t sz, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    size_t nchunk = (size_t)nthreads;
+    if (num < 4096 * nchunk) nchunk = 1;
+    size_t *lo = (size_t *)malloc((nchunk + 1) * sizeof(size_t));
+    for (size_t k = 0; k <= nchunk; k++) lo[k] = num / nchunk * k + (k == nchunk ? num % nchunk : 0);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (size_t k = 0; k < nchunk; k++) qsort(base + lo[k] * sz, lo[k + 1] - lo[k], sz, cmp_cell);
+    if (nchunk > 1) {
+        char *tmp = (char *)malloc(num * sz), *src = base, *dst = tmp;
+        for (size_t width = 1; width < nchunk; width *= 2) {
+            size_t npairs = (nchunk + 2 * width - 1) / (2 * width);
+            size_t split = ((size_t)nthreads + npairs - 1) / npairs; /* key ranges per merge */
+#pragma omp parallel for schedule(static) num_threads(nthreads) collapse(2)
+            for (size_t pr = 0; pr < npairs; pr++) {
+                for (size_t part = 0; part < split; part++) {
+                    size_t k = pr * 2 * width;
+                    size_t a = lo[k], m = lo[k + width < nchunk ? k + width : nchunk], b = lo[k + 2 * width < nchunk ? k + 2 * width : nchunk];
+                    if (a == b) continue;
+                    long kmin = *(const long *)(src + a * sz), kmax = *(const long *)(src + (m - 1) * sz);
+                    if (m < b) {
+                        long k2 = *(const long *)(src + m * sz), k3 = *(const long *)(src + (b - 1) * sz);
+                        if (k2 < kmin) kmin = k2;
+                        if (k3 > kmax) kmax = k3;
+                    }
+                    long span = kmax - kmin + 1;
+                    long key_lo = kmin + span * (long)part / (long)split, key_hi = kmin + span * (long)(part + 1) / (long)split;
+                    size_t a0 = part == 0 ? a : lower_bound_cell(src, sz, a, m, key_lo);
+                    size_t a1 = part + 1 == split ? m : lower_bound_cell(src, sz, a, m, key_hi);
+                    size_t b0 = part == 0 ? m : lower_bound_cell(src, sz, m, b, key_lo);
+                    size_t b1 = part + 1 == split ? b : lower_bound_cell(src, sz, m, b, key_hi);
+                    merge_runs(src, dst, sz, a0, a1, b0, b1, a + (a0 - a) + (b0 - m));
+                }
+            }
+            char *t = src; src = dst; dst = t;
+        }
+        if (src != base) memcpy(base, src, num * sz);
+        free(tmp);
+    }
+    free(lo);
+}
+
 /* particle/mod.rs:247-293: gather + push every particle, count leavers, sort
  * by cell, re-base right-leavers.  The sort is a stable counting sort (the
  * reference's par_sort_unstable_by_key leaves tie order unspecified).
@@ -1204,8 +1289,10 @@ size_t oracle_pop_push_and_sort(Population *p, const YeeGrid *grid, double dt, i
         if (c < 0) gl++;
         else if (c >= max) gr++;
     }
-    /* stable counting sort on cell in [-1, max] (anything outside is clamped into the end bins) */
-    if (num) {
+    if (num && g_sort_mode == 1) {
+        comparison_sort((char *)p->store, num, psize(p->species), nthreads);
+    } else if (num) {
+        /* stable counting sort on cell in [-1, max] (anything outside is clamped into the end bins) */
         size_t nb = (size_t)max + 2, sz = psize(p->species);
         size_t *count = (size_t *)calloc(nb + 1, sizeof(size_t));
         char *out = (char *)malloc(num * sz);
@@ -1267,6 +1354,7 @@ void oracle_pop_splice(Population *p, const YeeGrid *grid, const void *recv_left
 size_t oracle_world_pop_advance(Population **pops, YeeGrid **grids, int n, double dt, int nthreads)
 {
     size_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static, 1) num_threads(n) if (g_parallel_subdomains && n > 1)
     for (int r = 0; r < n; r++) bad += oracle_pop_push_and_sort(pops[r], grids[r], dt, nthreads);
     /* snapshot all send buffers first */
     void **sl = (void **)calloc((size_t)n, sizeof(void *)), **sr = (void **)calloc((size_t)n, sizeof(void *));
@@ -1278,6 +1366,7 @@ size_t oracle_world_pop_advance(Population **pops, YeeGrid **grids, int n, doubl
         memcpy(sl[r], oracle_pop_send_left(pops[r]), nl[r] * sz);
         memcpy(sr[r], oracle_pop_send_right(pops[r]), nr[r] * sz);
     }
+#pragma omp parallel for schedule(static, 1) num_threads(n) if (g_parallel_subdomains && n > 1)
     for (int r = 0; r < n; r++) {
         int L = oracle_grid_to_left(grids[r]), R = oracle_grid_to_right(grids[r]);
         /* from the left neighbour we get what it sent right; from the right one what it sent left */
@@ -1379,6 +1468,7 @@ size_t oracle_world_step(YeeGrid **grids, Population **pops_e, Population **pops
     if (pops_e) bad += oracle_world_pop_advance(pops_e, grids, n, dt, nthreads);
     if (pops_i) bad += oracle_world_pop_advance(pops_i, grids, n, dt, nthreads);
     if (current_deposition) {
+#pragma omp parallel for reduction(+ : bad) schedule(static, 1) num_threads(n) if (g_parallel_subdomains && n > 1)
         for (int r = 0; r < n; r++) {
             oracle_grid_clear(grids[r]);
             if (pops_e) bad += oracle_grid_deposit(grids[r], pops_e[r], dt, nthreads);
@@ -1386,6 +1476,7 @@ size_t oracle_world_step(YeeGrid **grids, Population **pops_e, Population **pops
         }
     }
     oracle_world_synchronize(grids, n, laser_y, laser_z, user, t, dt);
+#pragma omp parallel for schedule(static, 1) num_threads(n) if (g_parallel_subdomains && n > 1)
     for (int r = 0; r < n; r++) oracle_grid_advance(grids[r], dt);
     return bad;
 }

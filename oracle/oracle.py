@@ -131,6 +131,8 @@ def lib():
             "oracle_world_step": (C.c_size_t, [vp, vp, vp, C.c_int, C.c_int, FN2, FN2, vp, C.c_double, C.c_double, C.c_int]),
             "oracle_world_run_periodic": (C.c_size_t, [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t, C.c_int]),
             "oracle_max_threads": (C.c_int, []),
+            "oracle_set_sort_mode": (None, [C.c_int]),
+            "oracle_set_parallel_subdomains": (None, [C.c_int]),
             "oracle_pwmci_evaluate": (C.c_int, [C.c_double, vp, C.c_size_t, dp]),
             "oracle_pwmci_invert": (C.c_int, [C.c_double, vp, C.c_size_t, dp, C.POINTER(C.c_int)]),
             "oracle_qed_sample": (C.c_int, [C.c_double] * 5 + [vp]),
@@ -310,6 +312,18 @@ def world_run_periodic(grids, pops_e, pops_i, current_deposition, t0, dt, n_step
 
 def max_threads():
     return lib().oracle_max_threads()
+
+
+def set_parallel_subdomains(on):
+    """S subdomains x T threads (the reference's MPI x Rayon layout) in one process: subdomain loops of the
+    world_* functions run concurrently, each with its own nested `nthreads` team.  bench.py's CPU baseline."""
+    lib().oracle_set_parallel_subdomains(1 if on else 0)
+
+
+def set_sort_mode(mode):
+    """0: stable counting sort (default; parity tests).  1: parallel comparison sort of the AoS structs, the
+    class of work the reference's par_sort_unstable_by_key does every step (bench.py's CPU baseline)."""
+    lib().oracle_set_sort_mode(int(mode))
 
 
 class RNG:
