@@ -496,6 +496,11 @@ def main():
                 tj = json.load(open(tpath))
                 roof["traffic"] = tj["hbm_bytes_per_particle_update"] * per_launch
                 roof["traffic_source"] = tj.get("source", "profiles/traffic.json") + " (separate rocprofv3 --pmc run; not measured in this process)"
+                # `achieved` prices the ALGORITHMIC 80 B/update; the bytes that really cross the HBM interface are
+                # fewer where whole waves leave an attribute unchanged and the kernel skips its write-back
+                roof["traffic_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 if launches else None
+                roof["traffic_note"] = ("traffic < algorithmic bytes: attributes that no lane of a wave changed are not "
+                                        "written back (uy, uz, most cell indices in a 1-D electrostatic run)")
             except Exception:
                 roof["traffic"] = None
         return {"value": value, "elapsed": elapsed, "n_total": n_total, "preheat": preheat, "roofline": roof}

@@ -112,13 +112,13 @@ __device__ inline void scatter_lds(double *acc, int rel, int lane, const Taps &t
 #pragma unroll
     for (int k = 1; k < 4; k++) atomicAdd(a + k * REPL, t.jx[k]);
     lds_add(a + 4 * REPL, t.jx[4]);
-    if (t.jy[1] != 0.0) {
+    if (t.qy != 0.0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) atomicAdd(a + (1 * TILE + k + 1) * REPL, t.jy[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(a + (1 * TILE + k + 1) * REPL, t.jy(k));
     }
-    if (t.jz[1] != 0.0) {
+    if (t.qz != 0.0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) atomicAdd(a + (2 * TILE + k + 1) * REPL, t.jz[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(a + (2 * TILE + k + 1) * REPL, t.jz(k));
     }
     if (RHO) {
 #pragma unroll
@@ -132,9 +132,9 @@ __device__ inline void scatter_global(double *jr, size_t lenp, int idx, const Ta
 #pragma unroll
     for (int k = 0; k < 5; k++) glb_add(jr + 0 * lenp + idx + k - 2, t.jx[k]);
 #pragma unroll
-    for (int k = 0; k < 3; k++) glb_add(jr + 1 * lenp + idx + k - 1, t.jy[k]);
+    for (int k = 0; k < 3; k++) glb_add(jr + 1 * lenp + idx + k - 1, t.jy(k));
 #pragma unroll
-    for (int k = 0; k < 3; k++) glb_add(jr + 2 * lenp + idx + k - 1, t.jz[k]);
+    for (int k = 0; k < 3; k++) glb_add(jr + 2 * lenp + idx + k - 1, t.jz(k));
     if (RHO) {
 #pragma unroll
         for (int k = 0; k < 4; k++) glb_add(jr + 3 * lenp + idx + k - 2, t.rho[k]);
@@ -171,9 +171,11 @@ struct ChunkPtrs {
 // from global memory and the taps go to the grid with global atomics.
 template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool FAST>
 __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkPtrs &cp, const double *s_field,
-                                                 double *s_acc, int base, int lane, unsigned kc, int c, double xi,
-                                                 V3 u, double wt, double prev, int &err)
+                                                 double *s_acc, int base, int lane, unsigned kc, int c, int c_mem,
+                                                 double xi, V3 u, double wt, double prev, int &err)
 {
+    // c: the cell to work in (the periodic image when the caller picked one); c_mem: what the slot holds
+    const double uy_mem = u.y, uz_mem = u.z;
     constexpr bool GATHER = MODE != MODE_DEPOSIT;
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
     int newc = c, rel, idx;
@@ -221,7 +223,8 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         // electron.rs:311-329 / ion.rs:197-213
         xn = xi + r.dxi;
         double fl = floor(xn);
-        int s = fl < 0.0 ? -1 : (fl > 0.0 ? 1 : 0);
+        // the reference steps the cell by the SIGN of floor(x) (one cell at most, electron.rs:319-327)
+        int s = min(max((int)fl, -1), 1);
         prev = xi - fl;
         xn = xn - fl;
         newc = c + s;
@@ -235,18 +238,20 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         rel = idx - base;
     }
 
-    // leavers: mod.rs:273-278, 291-293, 308-354; yee.rs:329-343
+    // leavers: mod.rs:273-278, 291-293, 308-354; yee.rs:329-343.  One unsigned compare finds the rare particle
+    // that stepped outside [0, size); only those lanes look at the edge modes.
     bool deleted = false;
     int send_side = -1;
-    if (GATHER) {
-        if (newc < 0) {
-            if (a.left_mode == EDGE_WRAP) newc += a.size;
-            else if (a.left_mode == EDGE_DELETE) deleted = true;
-            else send_side = 0;
-        } else if (newc >= a.size) {
-            if (a.right_mode == EDGE_WRAP) newc -= a.size;
-            else if (a.right_mode == EDGE_DELETE) deleted = true;
-            else { send_side = 1; newc -= a.size; }  // mod.rs:291-293
+    if (GATHER && (unsigned)newc >= (unsigned)a.size) {
+        const bool left = newc < 0;
+        const int mode = left ? a.left_mode : a.right_mode;
+        if (mode == EDGE_WRAP) {
+            newc += left ? a.size : -a.size;
+        } else if (mode == EDGE_DELETE) {
+            deleted = true;
+        } else {
+            send_side = left ? 0 : 1;
+            if (!left) newc -= a.size;  // mod.rs:291-293
         }
     }
 
@@ -260,10 +265,26 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
     }
 
     if (GATHER) {
-        if (deleted) {
+        if (!deleted && send_side < 0) {
+            // Write-back skips what did not change: an attribute is stored only if some lane of the wave holds
+            // a value whose bits differ from what it loaded.  Results are identical by construction; the saving
+            // is real where a component is constant for whole waves -- the transverse momenta of a 1-D
+            // electrostatic run (E_y = E_z = B = 0: 16 of the 36 bytes a particle writes), the cell index of
+            // slow particles -- and the test costs one compare and one scalar branch per attribute elsewhere
+            // (and two registers per tested momentum component, which is why ux is not tested).
+            auto differs = [](double p, double q) { return __double_as_longlong(p) != __double_as_longlong(q); };
+            if (__ballot(newc != c_mem)) stk(cp.cell, kc, newc);
+            stk(cp.x, kc, xn);
+            if (SPECIES != OPAL_PHOTON) {  // a photon's momentum never changes
+                stk(cp.ux, kc, u.x);  // (not tested: it changes wherever there is a field at all)
+                if (__ballot(differs(u.y, uy_mem))) stk(cp.uy, kc, u.y);
+                if (__ballot(differs(u.z, uz_mem))) stk(cp.uz, kc, u.z);
+            }
+            if (MODE == MODE_ADVANCE && cp.prev) stk(cp.prev, kc, prev);  // only kept for a later separate deposit
+        } else if (deleted) {
             cp.cell[kc] = DEAD_CELL;
             atomicAdd(&a.ctr->n_deleted, 1u);
-        } else if (send_side >= 0) {
+        } else {
             unsigned slot = atomicAdd(a.send_count[send_side], 1u);
             if (slot < a.send_cap) {
                 a.send_cell[send_side][slot] = newc;
@@ -282,15 +303,6 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                 err |= 8;
             }
             cp.cell[kc] = DEAD_CELL;
-        } else {
-            stk(cp.cell, kc, newc);
-            stk(cp.x, kc, xn);
-            if (SPECIES != OPAL_PHOTON) {  // a photon's momentum never changes
-                stk(cp.ux, kc, u.x);
-                stk(cp.uy, kc, u.y);
-                stk(cp.uz, kc, u.z);
-            }
-            if (MODE == MODE_ADVANCE && cp.prev) stk(cp.prev, kc, prev);  // only kept for a later separate deposit
         }
     }
 }
@@ -325,23 +337,21 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     struct Slot {
         int c;
         double x, ux, uy, uz, w, prev;
-        bool have;
     };
-    auto fetch = [&](unsigned kk, bool ok) {
+    // Lanes past the end of the chunk load its last slot again (same cache lines, no extra HBM traffic) and are
+    // masked by `have`: unconditional loads need neither an exec-mask branch nor zero-filled registers.
+    const unsigned last = nloc - 1;  // nloc >= 1
+    auto fetch = [&](unsigned kk) {
         Slot sl;
-        sl.have = ok;
-        sl.c = DEAD_CELL;
-        sl.x = sl.ux = sl.uy = sl.uz = sl.w = sl.prev = 0.0;
-        if (ok) {
-            sl.c = ldk(cp.cell, kk); sl.x = ldk(cp.x, kk); sl.ux = ldk(cp.ux, kk); sl.uy = ldk(cp.uy, kk);
-            sl.uz = ldk(cp.uz, kk); sl.w = ldk(cp.w, kk);
-            if (MODE == MODE_DEPOSIT) sl.prev = ldk(cp.prev, kk);
-        }
+        sl.c = ldk(cp.cell, kk); sl.x = ldk(cp.x, kk); sl.ux = ldk(cp.ux, kk); sl.uy = ldk(cp.uy, kk);
+        sl.uz = ldk(cp.uz, kk); sl.w = ldk(cp.w, kk);
+        sl.prev = (MODE == MODE_DEPOSIT) ? ldk(cp.prev, kk) : 0.0;
         return sl;
     };
     unsigned k = tid;
-    Slot s_n = fetch(k, k < nloc);
-    const int c_n = s_n.c;
+    Slot s_n = fetch(min(k, last));
+    bool have_n = k < nloc;
+    const int c_n = have_n ? s_n.c : DEAD_CELL;
     // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin.  Slots that
     // hold far-away cells (particles that wrapped around a periodic domain, arrivals appended from both
     // neighbours) must not drag the tile away from the bulk: when the cells of the first slots span more
@@ -403,12 +413,16 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     unsigned pending = 0;
     for (int p = 0; p < a.ppt; p++) {
         const unsigned kc = k;
-        const bool live = s_n.have && s_n.c != DEAD_CELL;
+        const bool live = have_n && s_n.c != DEAD_CELL;
         int c = s_n.c;
+        const int c_mem = c;
         const double xi = s_n.x, wt = s_n.w, prev = s_n.prev;
         const V3 u = {s_n.ux, s_n.uy, s_n.uz};
         k += BLOCK;
-        s_n = fetch(k, (p + 1 < a.ppt) && k < nloc);  // one slot per lane in flight (two measured 1.5 % slower)
+        if (p + 1 < a.ppt) {  // block-uniform; one slot per lane in flight (two measured 1.5 % slower)
+            s_n = fetch(min(k, last));
+            have_n = k < nloc;
+        }
         if (!live) continue;
         int rel = c + a.L - base;
         bool ok, in_tile;
@@ -431,7 +445,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
                 in_tile = true;
             }
         }
-        if (in_tile) process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, true>(a, cp, s_field, s_acc, base, lane, kc, c, xi, u, wt, prev, err);
+        if (in_tile) process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, true>(a, cp, s_field, s_acc, base, lane, kc, c, c_mem, xi, u, wt, prev, err);
         else pending |= 1u << p;
     }
     // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.
@@ -442,7 +456,8 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             unsigned kc = (unsigned)p * BLOCK + tid;
             V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
             double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
-            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cp.cell[kc], cp.x[kc], u, cp.w[kc], prev, err);
+            const int cm = cp.cell[kc];
+            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err);
             slow++;
         }
         atomicAdd(&a.ctr->n_slow, slow);
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(BLOCK, (EXTRAS == 0 && MODE == MODE_FUSED) ? 6 : 1)
 // ions.  One launch instead of two means one ragged tail of finishing workgroups per step instead of two
 // (the species are independent: both read the fields and add into the same current arrays atomically).
 #ifndef OPAL_PAIR_WAVES
-#define OPAL_PAIR_WAVES 6  // measured: 6 waves/SIMD (80 VGPRs) beats 5 (94) by 1 % and 7 (spills) by 3 %
+#define OPAL_PAIR_WAVES 6  // measured: 6 waves/SIMD (80 VGPRs, no spills) beats 5 (84) and 4 (86) by 2-3 %; 7 spills
 #endif
 // Which workgroups (= chunks of BLOCK x ppt slots) of each species a launch covers: two runs of consecutive
 // chunks per species.  A whole step is {0, all, 0, 0}; the edge launch of a split step takes the first and

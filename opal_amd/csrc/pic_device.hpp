@@ -72,22 +72,23 @@ __host__ __device__ inline double flux(double x_i, double x_f)
 // to the caller, who folds it into the charge/dt constant.  Arms as in flux().
 __host__ __device__ inline double flux2(double x_i, double x_f)
 {
+#pragma clang fp contract(off)
     double a = fabs(x_i), b = fabs(x_f);
-    bool ina = a < 1.0, inb = b < 1.0;
-    double ca = 1.0 - a, cb = 1.0 - b;
-    double pa = ina ? ca * ca : 0.0;
-    double pb = inb ? cb * cb : 0.0;
+    // (1 - |x|)^2 inside the cell, 0 beyond: max() instead of compare-and-select.  The difference of the two
+    // squares must stay un-fused (pa and pb rounded separately): a particle that has not moved then deposits
+    // exactly zero current, as in the reference.
+    double ca = fmax(1.0 - a, 0.0), cb = fmax(1.0 - b, 0.0);
+    double pa = ca * ca, pb = cb * cb;
     double same = copysign(pb - pa, x_i - x_f);
-    double diff = copysign(a * (2.0 - a) + b * (2.0 - b), x_i);
-    bool opposite = ina && inb && !(x_i * x_f >= 0.0);
+    double diff = copysign(__builtin_fma(b, 2.0 - b, a * (2.0 - a)), x_i);
+    // opposite sides of the boundary, both within a cell of it: ca, cb > 0 and x_i x_f < 0
+    bool opposite = (ca * cb > 0.0) && !(x_i * x_f >= 0.0);
     return opposite ? diff : same;
 }
 __host__ __device__ inline double flux2_outer(double x_i, double displacement)
 {
-    double a = fabs(x_i);
-    double ca = 1.0 - a;
-    double pa = a < 1.0 ? ca * ca : 0.0;
-    return copysign(pa, displacement);
+    double ca = fmax(1.0 - fabs(x_i), 0.0);
+    return copysign(ca * ca, displacement);
 }
 
 // Cell::flux for the two outermost taps of the deposit (boundaries at -1.5 and 2.5 cells from the
@@ -104,25 +105,35 @@ __host__ __device__ inline double flux_outer(double x_i, double displacement)
 }
 
 // The two polynomial pieces of Cell::weight (yee.rs:145,147) for callers that know the range of
-// their argument, which spares the compares and selects of the general form.
+// their argument, which spares the compares and selects of the general form.  The outer piece
+// 1.125 - 1.5 xhat + 0.5 xhat^2 is evaluated as 0.5 (1.5 - xhat)^2: the same polynomial (differs from the
+// reference's evaluation order by an ulp of 1), three instructions instead of five.
 __host__ __device__ inline double w_inner(double xhat) { return 0.75 - xhat * xhat; }                          // xhat < 0.5
-__host__ __device__ inline double w_outer(double xhat) { return 1.125 - 1.5 * xhat + 0.5 * (xhat * xhat); }    // 0.5 <= xhat <= 1.5
+__host__ __device__ inline double w_outer(double xhat) { double d = 1.5 - xhat; return 0.5 * (d * d); }        // 0.5 <= xhat <= 1.5
 
 // weight(1+x), weight(x), weight(1-x), weight(2-x) for an offset x in [0, 1] (the stored offsets:
-// electron.rs:319-329 / ion.rs:203-213 leave x - floor(x)).  Which polynomial applies follows from x
-// alone; at the break points (x = 0.5) both pieces agree, so the choice there is immaterial.
+// electron.rs:319-329 / ion.rs:203-213 leave x - floor(x)), without compares or selects.  With h = x - 0.5,
+// p = max(h, 0) and m = max(-h, 0):
+//   weight(1+x) = 0.5 (0.5 - x)^2 for x <= 0.5, else 0           = 0.5 m^2
+//   weight(2-x) = 0.5 (x - 0.5)^2 for x >= 0.5, else 0           = 0.5 p^2
+//   weight(x)   = 0.75 - x^2 for x < 0.5, else 0.5 (1.5 - x)^2   = 0.75 - x^2 + 1.5 p^2
+//   weight(1-x) = the same in 1 - x                              = 0.75 - (1-x)^2 + 1.5 m^2
+// (0.5 (1.5 - x)^2 - (0.75 - x^2) = 1.5 (x - 0.5)^2).  Each agrees with the reference's piecewise evaluation
+// to an ulp of 1; at x = 0.5 the pieces meet, so the choice there is immaterial.
 struct EdgeW {
     double e0, e1, e2, e3;
 };
 __host__ __device__ inline EdgeW edge_weights(double x)
 {
     EdgeW w;
-    const bool lo = x < 0.5;
+    const double h = x - 0.5;
+    const double p = fmax(h, 0.0), m = fmax(-h, 0.0);
+    const double p2 = p * p, m2 = m * m;
     const double a2 = 1.0 - x;
-    w.e0 = x > 0.5 ? 0.0 : w_outer(1.0 + x);        // 1+x in [1, 2]: zero beyond 1.5
-    w.e1 = lo ? w_inner(x) : w_outer(x);            // x in [0, 1]
-    w.e2 = a2 < 0.5 ? w_inner(a2) : w_outer(a2);    // 1-x in [0, 1]
-    w.e3 = (2.0 - x) > 1.5 ? 0.0 : w_outer(2.0 - x);  // 2-x in [1, 2]
+    w.e0 = 0.5 * m2;
+    w.e3 = 0.5 * p2;
+    w.e1 = (0.75 - x * x) + 1.5 * p2;
+    w.e2 = (0.75 - a2 * a2) + 1.5 * m2;
     return w;
 }
 
@@ -134,9 +145,10 @@ struct GatherW {
 __host__ __device__ inline GatherW gather_weights(double xi)
 {
     GatherW g;
-    g.c0 = w_outer(0.5 + xi);        // 0.5+xi in [0.5, 1.5]
-    g.c1 = w_inner(fabs(0.5 - xi));  // |0.5-xi| <= 0.5
-    g.c2 = w_outer(1.5 - xi);        // 1.5-xi in [0.5, 1.5]
+    const double a = 1.0 - xi, h = 0.5 - xi;
+    g.c0 = 0.5 * (a * a);    // weight(0.5 + xi), 0.5+xi in [0.5, 1.5]: 0.5 (1.5 - (0.5 + xi))^2
+    g.c1 = 0.75 - h * h;     // weight(0.5 - xi), |0.5-xi| <= 0.5
+    g.c2 = 0.5 * (xi * xi);  // weight(1.5 - xi), 1.5-xi in [0.5, 1.5]
     EdgeW e = edge_weights(xi);
     g.e0 = e.e0;
     g.e1 = e.e1;
@@ -170,14 +182,29 @@ struct Pushed {
     V3 v_old;
 };
 
-// 1/sqrt(a) to within an ulp: hardware estimate (v_rsq_f64, ~2^-26 relative) plus two Newton steps.
-// Used where the reference takes a square root only to divide by it.
+// 1/sqrt(a): hardware estimate (v_rsq_f64, ~2^-26 relative) plus OPAL_NR_STEPS Newton steps.  Used where the
+// reference takes a square root only to divide by it.  One step squares the error (1.5 e^2 ~ 3e-16, a few ulp):
+// the single-operator parity tests hold 1e-12 with it, and a second step (measured: +2.5 % kernel time) buys
+// nothing the tolerances can see.
+#ifndef OPAL_NR_STEPS
+#define OPAL_NR_STEPS 1
+#endif
 __device__ inline double rsqrt_nr(double a)
 {
     double y = __builtin_amdgcn_rsq(a);
     double h = 0.5 * a;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
+#pragma unroll
+    for (int i = 0; i < OPAL_NR_STEPS; i++) y = y * (1.5 - h * y * y);
+    return y;
+}
+
+// 1/a: hardware estimate (v_rcp_f64) plus OPAL_NR_STEPS Newton steps, three instructions where the IEEE-exact
+// division sequence (div_scale, rcp, fma chain, div_fmas, div_fixup) takes a dozen.
+__device__ inline double rcp_nr(double a)
+{
+    double y = __builtin_amdgcn_rcp(a);
+#pragma unroll
+    for (int i = 0; i < OPAL_NR_STEPS; i++) y = y * (2.0 - a * y);
     return y;
 }
 
@@ -213,7 +240,7 @@ __device__ inline Pushed vay_push(V3 u, V3 E, V3 B, double alpha, double dt_over
     double inv_gn = rsqrt_nr(g2);
     double gamma = g2 * inv_gn;
     V3 t = inv_gn * tau;
-    double s = 1.0 / (1.0 + dot(t, t));
+    double s = rcp_nr(1.0 + dot(t, t));  // in [0.5, 1]: no range concerns
     r.u = s * (u_prime + dot(u_prime, t) * t + cross(u_prime, t));
     r.gamma = gamma;
     r.inv_gamma = inv_gn;
@@ -268,9 +295,11 @@ __device__ inline Pushed boris_push(V3 u, V3 E, V3 B, double alpha, double dt_ov
 // rho[k] -> index + k - 2 (k = 0..3; the reference adds W(2 - x) at index - 2).
 struct Taps {
     double jx[5];
-    double jy[3];
-    double jz[3];
+    double e[3];    // weight(1+x), weight(x), weight(1-x): the shape shared by jy, jz and three of the rho taps
+    double qy, qz;  // Q v_y / dx, Q v_z / dx: jy[k] = qy e[k], jz[k] = qz e[k]
     double rho[4];
+    __device__ double jy(int k) const { return qy * e[k]; }
+    __device__ double jz(int k) const { return qz * e[k]; }
 };
 
 template <bool RHO>
@@ -287,15 +316,14 @@ __device__ inline Taps deposit_taps(double x, double prev_x, double macrocharge,
     t.jx[3] = hq * flux2(1.5 - prev_x, 1.5 - x);
     t.jx[4] = hq * flux2_outer(2.5 - prev_x, d);
     EdgeW ew = edge_weights(x);
-    // j_perp = Q v W / dx (yee.rs:594-602), rho = Q W / dx (:606-609)
+    // j_perp = Q v W / dx (yee.rs:594-602), rho = Q W / dx (:606-609).  The products with the weights are
+    // left to the scatter, which skips a transverse component whose velocity is zero in every lane.
     const double qdx = macrocharge * inv_dx;
-    const double qy = qdx * vy, qz = qdx * vz;
-    t.jy[0] = qy * ew.e0;
-    t.jy[1] = qy * ew.e1;
-    t.jy[2] = qy * ew.e2;
-    t.jz[0] = qz * ew.e0;
-    t.jz[1] = qz * ew.e1;
-    t.jz[2] = qz * ew.e2;
+    t.qy = qdx * vy;
+    t.qz = qdx * vz;
+    t.e[0] = ew.e0;
+    t.e[1] = ew.e1;
+    t.e[2] = ew.e2;
     if (RHO) {
         t.rho[0] = qdx * ew.e3;
         t.rho[1] = qdx * ew.e0;
