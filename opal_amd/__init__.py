@@ -213,13 +213,14 @@ class Population:
         _check(self._lib.opal_pop_len(self.h, C.byref(n)))
         return n.value
 
-    def soa(self, prev_x=False):
+    def soa(self, prev_x=False, fields=("x", "ux", "uy", "uz", "w")):
+        """Live particles in slot order; `fields` limits what is copied back (cell always is)."""
         n = len(self)
         cell = np.empty(n, dtype=np.int32)
-        out = {k: np.empty(n) for k in ("x", "ux", "uy", "uz", "w")}
+        out = {k: np.empty(n) for k in fields}
         px = np.empty(n) if prev_x else None
-        _check(self._lib.opal_pop_download_soa(self.h, _ptr(cell), _ptr(out["x"]), _ptr(px), _ptr(out["ux"]),
-                                               _ptr(out["uy"]), _ptr(out["uz"]), _ptr(out["w"])))
+        _check(self._lib.opal_pop_download_soa(self.h, _ptr(cell), _ptr(out.get("x")), _ptr(px), _ptr(out.get("ux")),
+                                               _ptr(out.get("uy")), _ptr(out.get("uz")), _ptr(out.get("w"))))
         out["cell"] = cell
         if prev_x:
             out["prev_x"] = px

@@ -35,7 +35,8 @@ struct PopCounters {
     unsigned int n_nonempty;   // non-empty cells at last sort
     unsigned int n_emit;       // electrons whose optical depth ran out in the last push (photon emission)
     unsigned int n_lost;       // photons that found no free slot (capacity is checked by the host first: stays 0)
-    unsigned int pad[6];
+    unsigned int n_dead;       // slots vacated (deleted or sent away) since the last re-binning
+    unsigned int pad[5];
 };
 
 enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, NEX = 6 };
@@ -88,6 +89,9 @@ struct opal_pop {
     double *d_ex_alt[opal::NEX];  // re-binning targets, allocated on first use
     unsigned int *d_emit_list;    // slots of this step's emitters (photon emission), emit_list_cap entries
     size_t emit_list_cap;
+    bool emit_list_valid;         // the last push left the list of emitters (and d_ctr->n_emit) behind; nothing has
+                                  // moved or re-armed a slot since (re-binning, uploads, an emission pass)
+    double dead_cost;             // bytes streamed for vacated slots since the last re-binning (photon policy)
     // where each cell's particles ended up at the last re-binning (or sorted upload): slot index one past the last
     // particle of cell c, for c < n_cell_end; host copy, used to tell which slots can reach a subdomain edge
     unsigned int *h_cell_end;

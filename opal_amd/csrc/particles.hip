@@ -80,6 +80,7 @@ struct PushArgs {
     double *send_f[2];  // x ux uy uz w prev_x, 6 x send_cap
     unsigned send_cap;
     unsigned send_nextra;  // extras carried behind the 6 base fields (0 for a plain link)
+    unsigned *emit_list;   // EXTRAS == 2: slots whose optical depth ran out in this push (count in ctr->n_emit)
 };
 
 struct LdsFields {
@@ -172,7 +173,7 @@ struct ChunkPtrs {
 template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool FAST>
 __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkPtrs &cp, const double *s_field,
                                                  double *s_acc, int base, int lane, unsigned kc, int c, int c_mem,
-                                                 double xi, V3 u, double wt, double prev, int &err)
+                                                 double xi, V3 u, double wt, double prev, int &err, bool &emits)
 {
     // c: the cell to work in (the periodic image when the caller picked one); c_mem: what the slot holds
     const double uy_mem = u.y, uz_mem = u.z;
@@ -202,7 +203,11 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                     a.ex[EX_Y][i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
                     a.ex[EX_Z][i] += r.v_old.z * a.dt;
                 }
-                if (EXTRAS == 2) a.ex[EX_TAU][i] -= qed_rate(r.chi, r.gamma_half) * a.dt;  // electron.rs:284-288
+                if (EXTRAS == 2) {  // electron.rs:284-288
+                    const double tau = a.ex[EX_TAU][i] - qed_rate(r.chi, r.gamma_half) * a.dt;
+                    a.ex[EX_TAU][i] = tau;
+                    emits = tau < 0.0;  // electron.rs:209; dropped below if the particle leaves this subdomain
+                }
             }
         } else if (SPECIES == OPAL_PHOTON) {
             r = photon_push<EXTRAS != 0>(u, E, B, a.dt_over_dx);
@@ -255,6 +260,8 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         }
     }
 
+    if (EXTRAS == 2 && (deleted || send_side >= 0)) emits = false;  // it radiates where it arrives (or nowhere)
+
     if (DEPOSIT && !deleted) {
         double macrocharge = wt * a.charge;
         const double cig = SPEED_OF_LIGHT * inv_g;
@@ -284,7 +291,9 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         } else if (deleted) {
             cp.cell[kc] = DEAD_CELL;
             atomicAdd(&a.ctr->n_deleted, 1u);
+            atomicAdd(&a.ctr->n_dead, 1u);
         } else {
+            atomicAdd(&a.ctr->n_dead, 1u);
             unsigned slot = atomicAdd(a.send_count[send_side], 1u);
             if (slot < a.send_cap) {
                 a.send_cell[send_side][slot] = newc;
@@ -410,7 +419,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // alone.  Only particles whose stencil lies inside the LDS tile are processed here; the others are
     // remembered in a bit mask and taken in the second loop, which keeps every global access of this
     // loop a streaming one (precise vmcnt waits, no drain of the prefetch).
-    unsigned pending = 0;
+    unsigned pending = 0, emit_mask = 0;
     for (int p = 0; p < a.ppt; p++) {
         const unsigned kc = k;
         const bool live = have_n && s_n.c != DEAD_CELL;
@@ -445,8 +454,13 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
                 in_tile = true;
             }
         }
-        if (in_tile) process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, true>(a, cp, s_field, s_acc, base, lane, kc, c, c_mem, xi, u, wt, prev, err);
-        else pending |= 1u << p;
+        if (in_tile) {
+            bool emits = false;
+            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, true>(a, cp, s_field, s_acc, base, lane, kc, c, c_mem, xi, u, wt, prev, err, emits);
+            if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
+        } else {
+            pending |= 1u << p;
+        }
     }
     // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.
     if (pending) {
@@ -457,12 +471,45 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
             double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
             const int cm = cp.cell[kc];
-            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err);
+            bool emits = false;
+            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err, emits);
+            if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
             slow++;
         }
         atomicAdd(&a.ctr->n_slow, slow);
     }
     if (err) atomicOr(&a.ctr->err, err);
+
+    if (EXTRAS == 2 && SPECIES == OPAL_ELECTRON && GATHER) {
+        // The electrons that will radiate this step (interactions.rs:45-107 runs after the pushes) are known
+        // here, with tau still in registers: compact their slots into the emitter list now -- an exclusive
+        // prefix over the workgroup and ONE atomic on the list length -- instead of streaming cell and tau
+        // again in a pass of their own.  s_min / s_max are free after the prologue.
+        unsigned *s_cnt = reinterpret_cast<unsigned *>(s_max);
+        unsigned *s_base = reinterpret_cast<unsigned *>(s_min);
+        const int wl = tid & 63, wave = tid >> 6;
+        unsigned mine = __popc(emit_mask), incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned v = __shfl_up(incl, o);
+            if (wl >= o) incl += v;
+        }
+        if (wl == 63) s_cnt[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < BLOCK / 64; w2++) {
+            if (w2 < wave) before += s_cnt[w2];
+            total += s_cnt[w2];
+        }
+        if (total) {  // block-uniform
+            if (tid == 0) s_base[0] = atomicAdd(&a.ctr->n_emit, total);
+            __syncthreads();
+            unsigned at = s_base[0] + before + incl - mine;
+            for (int p = 0; p < a.ppt; p++)
+                if (emit_mask & (1u << p)) a.emit_list[at++] = (unsigned)(chunk0 + (size_t)p * BLOCK + tid);
+        }
+    }
 
     if (DEPOSIT) {
         __syncthreads();
@@ -519,6 +566,86 @@ __global__ __launch_bounds__(BLOCK, OPAL_PAIR_WAVES) void k_push_pair(PushArgs a
         b = b < plan.in0 ? plan.i0 + b : plan.i1 + (b - plan.in0);
         push_body<OPAL_ION, MODE, RHO, 0, false>(ai, b, s_field, s_acc, s_min, s_max);
     }
+}
+
+// Photon::push without the machinery a photon does not need (photon.rs:150-183 with no chi / y / z tracked):
+// a photon moves in a straight line at c, so the push reads cell, x and k (36 B), writes x and -- only where
+// some lane of the wave changed cell -- cell (12 B at most), and touches neither the fields, nor an LDS tile,
+// nor the weight.  Leavers are handled as in process_particle (deleted at open edges, packed into the link's
+// message towards a neighbour: only then is the weight read).  No tile, so no tile misses: photons are
+// re-binned only to squeeze out vacated slots (maybe_sort).
+constexpr int PHOTON_PPT = 8;
+template <bool SENDX>
+__global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
+{
+    const unsigned n = a.ctr->n_slots;
+    const size_t chunk0 = (size_t)blockIdx.x * BLOCK * PHOTON_PPT;
+    if (chunk0 >= n) return;
+    int *cellp = a.cell + chunk0;
+    double *xp = a.x + chunk0;
+    const double *kxp = a.ux + chunk0, *kyp = a.uy + chunk0, *kzp = a.uz + chunk0;
+    const unsigned nloc = (unsigned)min((size_t)BLOCK * PHOTON_PPT, (size_t)n - chunk0);
+    int err = 0;
+#pragma unroll
+    for (int p = 0; p < PHOTON_PPT; p++) {
+        const unsigned kc = (unsigned)p * BLOCK + threadIdx.x;
+        if (kc >= nloc) break;
+        const int c = ldk(cellp, kc);
+        const double xi = ldk(xp, kc);
+        const V3 k = {ldk(kxp, kc), ldk(kyp, kc), ldk(kzp, kc)};
+        if (c == DEAD_CELL) continue;
+        if ((unsigned)c >= (unsigned)a.size) {  // yee.rs:501-502 (fields_at is still called by the reference)
+            err |= 2;
+            continue;
+        }
+        const V3 none = {0.0, 0.0, 0.0};
+        const Pushed r = photon_push<false>(k, none, none, a.dt_over_dx);
+        if (!(r.dxi < 1.0)) err |= 1;  // photon.rs:169
+        double xn = xi + r.dxi;
+        const double fl = floor(xn);
+        const int s = min(max((int)fl, -1), 1);
+        xn -= fl;
+        int newc = c + s;
+        bool deleted = false;
+        int send_side = -1;
+        if ((unsigned)newc >= (unsigned)a.size) {
+            const bool left = newc < 0;
+            const int mode = left ? a.left_mode : a.right_mode;
+            if (mode == EDGE_WRAP) {
+                newc += left ? a.size : -a.size;
+            } else if (mode == EDGE_DELETE) {
+                deleted = true;
+            } else {
+                send_side = left ? 0 : 1;
+                if (!left) newc -= a.size;
+            }
+        }
+        if (!deleted && send_side < 0) {
+            if (__ballot(newc != c)) stk(cellp, kc, newc);
+            stk(xp, kc, xn);
+        } else if (deleted) {
+            cellp[kc] = DEAD_CELL;
+            atomicAdd(&a.ctr->n_deleted, 1u);
+            atomicAdd(&a.ctr->n_dead, 1u);
+        } else {
+            atomicAdd(&a.ctr->n_dead, 1u);
+            unsigned slot = atomicAdd(a.send_count[send_side], 1u);
+            if (slot < a.send_cap) {
+                a.send_cell[send_side][slot] = newc;
+                double *f = a.send_f[send_side];
+                f[0 * (size_t)a.send_cap + slot] = xn;
+                f[1 * (size_t)a.send_cap + slot] = k.x;
+                f[2 * (size_t)a.send_cap + slot] = k.y;
+                f[3 * (size_t)a.send_cap + slot] = k.z;
+                f[4 * (size_t)a.send_cap + slot] = a.w[chunk0 + kc];
+                if (SENDX) f[6 * (size_t)a.send_cap + slot] = (double)(chunk0 + kc);
+            } else {
+                err |= 8;
+            }
+            cellp[kc] = DEAD_CELL;
+        }
+    }
+    if (err) atomicOr(&a.ctr->err, err);
 }
 
 // ------------------------------------------------------------------ re-binning
@@ -667,6 +794,7 @@ __global__ void k_sort_finish(PopCounters *ctr)
 {
     ctr->n_slots = ctr->n_live;
     ctr->n_slow = 0;
+    ctr->n_dead = 0;
 }
 
 // ------------------------------------------------------------- kinetic energy
@@ -754,6 +882,7 @@ struct UnpackArgs {
     PopCounters *ctr;
     unsigned pop_cap;
     int my_size;
+    unsigned *emit_list;  // electrons of an emission run: arrivals whose optical depth has run out join the list
 };
 
 // up to three species per launch (blocks 2 s and 2 s + 1 belong to species s); the first workgroup also
@@ -805,6 +934,10 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
 #pragma unroll
         for (int q = 0; q < NEX; q++)
             if (a.ex[q]) a.ex[q][base + k] = q < (int)a.nextra ? rf[(size_t)(6 + q) * a.link_cap + k] : 0.0;
+        // an electron that crossed over with its optical depth already below zero radiates here (the reference
+        // migrates before emit_radiation, main.rs:240-252): rare, one atomic each
+        if (a.emit_list && a.nextra > EX_TAU && rf[(size_t)(6 + EX_TAU) * a.link_cap + k] < 0.0)
+            a.emit_list[atomicAdd(&a.ctr->n_emit, 1u)] = base + k;
     }
 }
 
@@ -953,6 +1086,7 @@ int grow(opal_pop_t *p, size_t new_cap)
         }
     }
     p->cap = new_cap;
+    p->emit_list_valid = false;  // the list is sized with the arrays (run_push re-allocates it)
     return OPAL_OK;
 }
 
@@ -1073,12 +1207,29 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     return OPAL_OK;
 }
 
+int ensure_emit_list(opal_pop_t *p)
+{
+    if (p->emit_list_cap >= p->cap && p->d_emit_list) return OPAL_OK;
+    if (p->d_emit_list) hipFree(p->d_emit_list);
+    p->d_emit_list = nullptr;
+    OPAL_HIP(hipMalloc(&p->d_emit_list, sizeof(unsigned) * p->cap));
+    p->emit_list_cap = p->cap;
+    return OPAL_OK;
+}
+
 int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode)
 {
     if (p->n_upper == 0) return OPAL_OK;
     PushArgs a;
     unsigned nblk;
     if (int rc = build_args(p, link, g, dt, mode, a, nblk)) return rc;
+    if (p->species == OPAL_ELECTRON && p->extras == 2 && p->d_ex[EX_TAU] && mode != MODE_DEPOSIT) {
+        // the push compacts this step's emitters as it goes (see push_body): start an empty list
+        if (int rc = ensure_emit_list(p)) return rc;
+        OPAL_HIP(hipMemsetAsync(&p->d_ctr->n_emit, 0, sizeof(unsigned), p->stream));
+        a.emit_list = p->d_emit_list;
+        p->emit_list_valid = true;
+    }
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, p->stream);
     // which variant of the kernel: 2 runs down the optical depth, 1 touches chi / work / y / z, 0 neither
@@ -1093,7 +1244,14 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
             set_error("photons are not deposited (photon.rs:199-201: charge 0)");
             return OPAL_ERR_ARG;
         }
-        launch_push<OPAL_PHOTON, MODE_ADVANCE>(a, nblk, ex, p->stream);
+        if (ex == 0) {
+            // nothing tracked that needs the fields (chi, y, z): the field-free push
+            const unsigned nb = (unsigned)((p->n_upper + (size_t)BLOCK * PHOTON_PPT - 1) / ((size_t)BLOCK * PHOTON_PPT));
+            if (a.send_nextra) k_push_photon<true><<<nb, BLOCK, 0, p->stream>>>(a);
+            else k_push_photon<false><<<nb, BLOCK, 0, p->stream>>>(a);
+        } else {
+            launch_push<OPAL_PHOTON, MODE_ADVANCE>(a, nblk, ex, p->stream);
+        }
     } else {
         if (mode == MODE_FUSED) launch_push<OPAL_ION, MODE_FUSED>(a, nblk, 0, p->stream);
         else if (mode == MODE_ADVANCE) launch_push<OPAL_ION, MODE_ADVANCE>(a, nblk, 0, p->stream);
@@ -1205,6 +1363,8 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     u.ctr = p->d_ctr;
     u.pop_cap = (unsigned)p->cap;
     u.my_size = (int)g->size;
+    u.emit_list = (p->emit_list_valid && p->emit_list_cap >= p->cap) ? p->d_emit_list : nullptr;
+    if (!u.emit_list) p->emit_list_valid = false;  // arrivals the list does not know about
     p->n_upper += incoming;
     p->added_since_snapshot += incoming;
     return OPAL_OK;
@@ -1340,6 +1500,8 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
         p->upper_pending = false;
     }
     p->steps_since_sort = 0;
+    p->emit_list_valid = false;  // slots moved
+    p->dead_cost = 0.0;
     if (p->ctr_pending) {
         hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
         p->ctr_pending = false;
@@ -1369,9 +1531,10 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
     // finishes late
     constexpr double miss_ns = 800.0;
     if (p->steps_since_sort % check_every != 0) return OPAL_OK;
-    // The counters are copied to pinned memory asynchronously and read at the NEXT check, 8 steps later:
-    // waiting for that older copy keeps the host at most ~16 steps ahead of the device (so the policy sees
-    // recent counts) while the device still has 8 queued steps to run and never idles.
+    // The counters are copied to pinned memory asynchronously and read at the NEXT check, check_every steps
+    // later: waiting for that older copy keeps the host at most ~2 check intervals ahead of the device (so the
+    // policy sees recent counts) while the device still has a check interval of queued steps to run and never
+    // idles.
     bool fresh = false;
     if (p->ctr_pending) {
         if (int rc = spin_wait(p->ctr_event)) return rc;
@@ -1388,8 +1551,21 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
     }
     if (!fresh) return OPAL_OK;
     const PopCounters seen = p->h_ctr_seen;  // snapshot taken when the copy was found complete
-    double lost_ms = (double)seen.n_slow * miss_ns * 1e-6;
     double sort_ms = 0.06 * (double)seen.n_slots * 1e-6 + 0.05;  // ~100 B per particle at ~2 TB/s + launches
+    if (p->species == OPAL_PHOTON && !p->extras) {
+        // The field-free photon push has no tile to miss: order does not matter to it.  What a re-binning buys
+        // is the slots that photons vacated at the open edges (or by migrating): each is still streamed, 36 B
+        // per step, until it is squeezed out.  Rent or buy on that: accumulate the bytes spent on vacated slots
+        // since the last re-binning (n_dead is sampled every check_every steps) and re-bin once they exceed
+        // what the re-binning itself moves (~100 B per slot).
+        p->dead_cost += (double)seen.n_dead * 36.0 * check_every;
+        if (p->dead_cost > 100.0 * (double)seen.n_slots && seen.n_dead > 0) {
+            p->dead_cost = 0.0;
+            return do_sort(p, g);
+        }
+        return OPAL_OK;
+    }
+    double lost_ms = (double)seen.n_slow * miss_ns * 1e-6;
     if (lost_ms > sort_ms) return do_sort(p, g);
     return OPAL_OK;
 }
@@ -1492,6 +1668,8 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     }
     p->added_since_snapshot = 0;
     p->steps_since_sort = 0;
+    p->emit_list_valid = false;
+    p->dead_cost = 0.0;
     p->dx_last = dx;
     {   // where each cell's particles are, if the caller's order is by cell (the loader's is)
         free(p->h_cell_end);
@@ -1605,6 +1783,7 @@ int opal_pop_track_fields(opal_pop_t *p, unsigned fields)
         any |= need[q];
     }
     p->extras = !any ? 0 : need[EX_TAU] ? 2 : 1;
+    p->emit_list_valid = false;
     if (any_fresh) {
         // start the new arrays as T::create does for every slot (arrays tracked before keep their values)
         double *keep[NEX];
@@ -1711,6 +1890,7 @@ int opal_pop_upload_emission_state(opal_pop_t *p, size_t n, const double *tau, c
     if (!n) return OPAL_OK;
     if (tau) OPAL_HIP(hipMemcpyAsync(p->d_ex[EX_TAU], tau, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
     if (id) OPAL_HIP(hipMemcpyAsync(p->d_ex[EX_ID], id, sizeof(uint64_t) * n, hipMemcpyHostToDevice, p->stream));
+    p->emit_list_valid = false;  // optical depths changed behind the push's back
     OPAL_HIP(hipStreamSynchronize(p->stream));
     return OPAL_OK;
 }
@@ -1922,6 +2102,12 @@ int pop_reserve(opal_pop_t *p, size_t extra)
 }
 // the arrivals of every species of a fused linked step in one launch, then each one's re-binning policy;
 // also resets the send messages' leaver counts, so the next step needs no link_begin
+// the unpack alone: a step with photon emission runs emit_radiation between it and the re-binning policy, so
+// that the emitter list the push left behind (slot indices) is still good when it is consumed
+int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g)
+{
+    return unpack_arrivals(pops, npops, link, g, true);
+}
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g)
 {
     if (int rc = unpack_arrivals(pops, npops, link, g, true)) return rc;

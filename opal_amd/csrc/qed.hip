@@ -302,7 +302,10 @@ struct RadiateArgs {
     double min_energy, max_angle, max_formation_length;  // < 0: no limit
 };
 
-// Pass 1: the slots whose optical depth has run out (electron.rs:209), compacted into a list.  Only a
+// Pass 1 -- normally done by the electron push itself (particles.hip, push_body: the emitters are compacted
+// where tau is computed); this kernel is the fallback for callers that changed optical depths or moved particles
+// between the push and the emission.  The slots whose optical depth has run out (electron.rs:209), compacted into
+// a list.  Only a
 // fraction rate * dt of the electrons emits in a step; sampling straight from the particle arrays would
 // leave 63 of 64 lanes idle through the long table-inversion code, so the emitters are gathered first and
 // pass 2 runs with full waves.  A workgroup scans LIST_ITER x 256 consecutive slots, keeps its hits in a
@@ -471,16 +474,21 @@ int opal_emit_radiation(opal_pop_t *e, opal_pop_t *ph, uint64_t seed, uint32_t s
     // second pass sizes itself on the device, and the host's bound on the photon slots in use is tightened
     // from counter snapshots that arrive a step or two later.
     int k = e->cur;
-    if (e->emit_list_cap < e->cap) {
-        if (e->d_emit_list) hipFree(e->d_emit_list);
-        e->d_emit_list = nullptr;
-        OPAL_HIP(hipMalloc(&e->d_emit_list, sizeof(unsigned) * e->cap));
-        e->emit_list_cap = e->cap;
+    if (!e->emit_list_valid) {
+        // No list from the push (the caller moved particles or changed optical depths since, or asks a second
+        // time in one step): scan for the emitters.  The time loop never comes here: its pushes leave the list.
+        if (e->emit_list_cap < e->cap || !e->d_emit_list) {
+            if (e->d_emit_list) hipFree(e->d_emit_list);
+            e->d_emit_list = nullptr;
+            OPAL_HIP(hipMalloc(&e->d_emit_list, sizeof(unsigned) * e->cap));
+            e->emit_list_cap = e->cap;
+        }
+        OPAL_HIP(hipMemsetAsync(&e->d_ctr->n_emit, 0, sizeof(unsigned), e->stream));
+        unsigned nblk = (unsigned)((e->n_upper + 256 * LIST_ITER - 1) / (256 * LIST_ITER));
+        k_list_emitters<<<nblk, 256, 0, e->stream>>>(e->d_cell[k], e->d_ex[EX_TAU], e->d_ctr, e->d_emit_list);
+        OPAL_HIP(hipGetLastError());
     }
-    OPAL_HIP(hipMemsetAsync(&e->d_ctr->n_emit, 0, sizeof(unsigned), e->stream));
-    unsigned nblk = (unsigned)((e->n_upper + 256 * LIST_ITER - 1) / (256 * LIST_ITER));
-    k_list_emitters<<<nblk, 256, 0, e->stream>>>(e->d_cell[k], e->d_ex[EX_TAU], e->d_ctr, e->d_emit_list);
-    OPAL_HIP(hipGetLastError());
+    e->emit_list_valid = false;  // consumed below: every listed electron draws a new optical depth
     size_t emitters;
     if (n_emitted) {
         if (int rc = pop_check_err(e)) return rc;  // copies the counters to e->h_ctr and synchronises

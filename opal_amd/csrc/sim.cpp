@@ -24,6 +24,7 @@ int pop_check_err(opal_pop_t *p);
 int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_push_advance_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
+int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
 int pops_advance_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt);
@@ -624,12 +625,16 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             if (!s->current_deposition)
                 if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
             if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, st)) return rc;
-            if (int rc = pops_unpack_and_maybe_sort(pops, 3, s->link, g)) return rc;
+            if (int rc = pops_unpack(pops, 3, s->link, g)) return rc;
             if (s->photon_emission && s->electrons)  // main.rs:250-252
                 if (int rc = opal_emit_radiation(s->electrons, s->photons, s->emission_seed, (uint32_t)s->step_index, s->t,
                                                  s->photon_energy_min, s->photon_angle_max, s->max_formation_length,
                                                  nullptr))
                     return rc;
+            // re-binning only now: the emission consumed the list of emitters (slot numbers) the push left
+            for (opal_pop_t *p : pops)
+                if (p)
+                    if (int rc = pop_maybe_sort(p, g)) return rc;
             if (s->current_deposition) {  // main.rs:254-258
                 if (int rc = opal_grid_clear(g)) return rc;
                 if (s->electrons)
@@ -721,19 +726,29 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
                 if (int rc = pop_maybe_sort(s->ions, s->grid)) return rc;
             } else {
-                if (s->electrons)
-                    if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) return rc;
+                if (s->electrons) {
+                    // with emission on, the electrons' re-binning waits until the emission has consumed the list of
+                    // emitters their push leaves behind (a lone subdomain: Population::advance is push + policy)
+                    if (s->photon_emission && !linked) {
+                        if (int rc = pop_push_advance_noexchange(s->electrons, nullptr, s->grid, s->dt)) return rc;
+                    } else if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) {
+                        return rc;
+                    }
+                }
                 if (s->ions)
                     if (int rc = opal_pop_advance(s->ions, s->link, s->grid, s->dt)) return rc;
             }
             if (s->photon_emission) {
                 if (s->photons)
                     if (int rc = opal_pop_advance(s->photons, s->link, s->grid, s->dt)) return rc;  // main.rs:242-244
-                if (s->electrons)  // main.rs:250-252
+                if (s->electrons) {  // main.rs:250-252
                     if (int rc = opal_emit_radiation(s->electrons, s->photons, s->emission_seed, (uint32_t)s->step_index,
                                                      s->t, s->photon_energy_min, s->photon_angle_max,
                                                      s->max_formation_length, nullptr))
                         return rc;
+                    if (!linked)
+                        if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
+                }
             }
             if (s->current_deposition) {
                 if (int rc = opal_grid_clear(s->grid)) return rc;

@@ -1,0 +1,313 @@
+"""BASELINE-size runs of the HIP path and the one check that shares nothing with the restatement.
+
+(1) Continuity.  The reference holds no test for `Cell::flux` / `deposit` (yee.rs:185-204, 551-641), so oracle
+and kernel could share a mis-reading and every oracle-vs-HIP test would still pass.  The continuity equation
+does not care how either was read: with the charge of a macro-particle spread as a triangle of half-width one
+cell (the shape whose motion `flux` integrates), the charge in the control volume of node i -- between the
+cell centres either side of it, where jx lives -- is
+
+    rho_i(X) = (Q / dx) [G(i + 1/2 - X) - G(i - 1/2 - X)],   G(s) = int_{-1}^{s} max(0, 1 - |t|) dt,
+
+and a charge-conserving deposit must satisfy, cell by cell and to rounding,
+
+    (rho_i(X_new) - rho_i(X_old)) / dt + (jx[i] - jx[i-1]) / dx = 0.
+
+rho is computed here in numpy from the particle positions before and after the step, straight from G (not
+from Cell::weight, not from the library's rho rows, which carry the reference's index quirk yee.rs:609); jx
+is what the HIP kernels deposited.
+
+(2) The BASELINE shapes on one GPU, both species through the paired launch: configs[1] (4096 cells,
+2441 + 2441 per cell), configs[2] (32 768 cells, 1526 + 1526 per cell, 1e8 particles) and configs[3]'s
+physics (20 000 cells, laser + absorber, 2000 + 2000 per cell in the slab), each checked through
+size-independent properties: particle counts, cells and offsets in range, neutrality, continuity, fused ==
+separate operators, energy bookkeeping.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+C = 2.997925e8
+QE = -1.602177e-19
+EPS0 = 8.854188e-12
+A_POSITRON = 9.109383e-31 / 1.672622e-27
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import opal_amd
+    assert opal_amd.device_count() >= 1
+    return opal_amd
+
+
+def G(s):
+    """Cumulative triangle: 0 below -1, 1 above 1."""
+    s = np.clip(s, -1.0, 1.0)
+    return np.where(s < 0.0, 0.5 * (1.0 + s) ** 2, 1.0 - 0.5 * (1.0 - s) ** 2)
+
+
+def node_charge(cell, x, qw, nx, periodic=True, chunk=1 << 24):
+    """sum over particles of qw [G(i + 1/2 - X) - G(i - 1/2 - X)] on nodes i = 0..nx-1 (X = cell + x), from the
+    offsets x directly so that no digits are lost to the cell index.  Nodes cell-1 .. cell+2 can be non-zero."""
+    out = np.zeros(nx + 8)
+    for lo in range(0, len(cell), chunk):
+        c = cell[lo:lo + chunk].astype(np.int64)
+        xx = x[lo:lo + chunk]
+        q = qw[lo:lo + chunk] if np.ndim(qw) else qw
+        for k in (-1, 0, 1, 2):
+            wgt = G(k + 0.5 - xx) - G(k - 0.5 - xx)
+            out += np.bincount(c + k + 4, weights=q * wgt, minlength=nx + 8)
+    if periodic:
+        body = out[4:4 + nx].copy()
+        body[-4:] += out[:4]
+        body[:4] += out[4 + nx:]
+        return body
+    return out[4:4 + nx]
+
+
+def continuity_residual(rho_old, rho_new, jx_int, dt, dx, periodic=True):
+    """(rho' - rho)/dt + (jx[i] - jx[i-1])/dx on the interior nodes; rho_* are charges per node (not yet / dx)."""
+    djx = jx_int - (np.roll(jx_int, 1) if periodic else np.concatenate([[0.0], jx_int[:-1]]))
+    return (rho_new - rho_old) / (dt * dx) + djx / dx
+
+
+def _interior(g, name):
+    a = g.raw(name)
+    return a[g.left_bdy_size:g.left_bdy_size + g.size]
+
+
+# ------------------------------------------------------------------------------ continuity, small but nasty
+@pytest.mark.parametrize("umax", [0.3, 20.0])
+def test_continuity_cell_by_cell(oa, umax):
+    """Random relativistic electrons and C6+ ions in random fields, periodic: every tap of the stencil is live
+    (cell crossings in both directions, wrap-around at both ends), fused and separate-operator deposits."""
+    nx, npc, dx = 96, 300, 1.0e-8
+    dt = 0.95 * dx / C
+    rng = np.random.default_rng(5)
+    for fused in (True, False):
+        g = oa.Grid.single(nx, 0.0, dx)
+        for comp, amp in (("Ex", 2e12), ("Ey", 2e12), ("Ez", 2e12), ("Bx", 5e3), ("By", 5e3), ("Bz", 5e3)):
+            g.set_raw(comp, amp * rng.standard_normal(g.len))
+        g.synchronize(None, None, 0.0, 0.0)
+        pops = []
+        for species, zstar, amass, seed in ((oa.ELECTRON, 1.0, 1.0, 1), (oa.ION, 6.0, 12.0, 2)):
+            r = np.random.default_rng(seed)
+            n = nx * npc
+            cell = np.repeat(np.arange(nx, dtype=np.int32), npc)
+            x = r.random(n)
+            u = umax * r.standard_normal((3, n))
+            w = 1.0e3 * (0.5 + r.random(n))
+            p = oa.Population.from_soa(species, cell, x, u[0], u[1], u[2], w, dx, dt)
+            p.set_sort_interval(0)
+            if species == oa.ION:
+                p.set_charge_state(zstar, zstar, amass)
+            pops.append((p, QE if species == oa.ELECTRON else -QE * zstar))
+        for step in range(3):
+            before = [(p.soa(), q) for p, q in pops]
+            g.clear()
+            if fused:
+                for p, _ in pops:
+                    p.advance_deposit(g, dt)
+            else:
+                for p, _ in pops:
+                    p.advance(g, dt)
+                for p, _ in pops:
+                    g.deposit(p, dt)
+            g.synchronize(None, None, 0.0, dt)
+            jx = _interior(g, "jx")
+            rho_old = sum(node_charge(s["cell"], s["x"], q * s["w"], nx) for s, q in before)
+            after = [(p.soa(), q) for p, q in pops]
+            rho_new = sum(node_charge(s["cell"], s["x"], q * s["w"], nx) for s, q in after)
+            res = continuity_residual(rho_old, rho_new, jx, dt, dx)
+            scale = abs(QE) * 1.0e3 * npc * 7 / (dt * dx)   # charge of a cell's particles moving a cell per step
+            assert np.max(np.abs(res)) < 1e-12 * scale, (fused, step, np.max(np.abs(res)) / scale)
+            assert np.max(np.abs(jx)) > 1e-3 * scale * dx   # there was a current to check
+            g.advance(dt)
+
+
+# ------------------------------------------------------------------------------ the BASELINE shapes
+TWO_STREAM = """---
+control:
+ dx: 500
+ nx: {nx}
+ xmin: 0.0
+ start: 0.0
+ end: 1.0
+ current_deposition: true
+ n_outputs: 20
+ balance: false
+qed:
+ photon_emission: false
+ photon_absorption: false
+electrons:
+ npc: {npc}
+ ne: 20.0
+ ux: drift_u * (1.0 + 0.001 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: 0.0
+ uz: 0.0
+ output: x:px
+ions:
+ name: positron
+ npc: {npc}
+ Z: 1.0
+ A: me/mp
+ ni: 20.0
+ ux: drift_u * (1.0 + 0.001 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)
+ uy: 0.0
+ uz: 0.0
+ output: x:px
+constants:
+ drift_u: 2.5e-24 / (me * c)
+"""
+
+
+def _two_stream_checks(oa, nx, npc, steps, check_unfused):
+    dx = 500.0
+    sim = oa.Simulation(yaml_text=TWO_STREAM.format(nx=nx, npc=npc))
+    dt = sim.dt
+    n_e, n_i = nx * npc, nx * npc
+    assert (len(sim.electrons), len(sim.ions)) == (n_e, n_i)
+    f0, ke0, ki0 = sim.energies()
+    s_e, s_i = sim.electrons.soa(fields=("x", "w")), sim.ions.soa(fields=("x", "w"))
+    w_e, w_i = s_e["w"][0], s_i["w"][0]
+    assert np.all(s_e["w"] == w_e) and np.all(s_i["w"] == w_i)       # uniform density: one weight per species
+    rho_old = node_charge(s_e["cell"], s_e["x"], QE * w_e, nx) + node_charge(s_i["cell"], s_i["x"], -QE * w_i, nx)
+    del s_e, s_i
+    sim.step(1)                       # electrons and positrons in ONE launch (k_push_pair), then sync + solve
+    sim.sync()
+    a_e, a_i = sim.electrons.soa(fields=("x", "uy", "uz")), sim.ions.soa(fields=("x", "uy", "uz"))
+    for s, n in ((a_e, n_e), (a_i, n_i)):
+        assert len(s["cell"]) == n                                   # periodic: nobody is lost
+        assert s["cell"].min() >= 0 and s["cell"].max() < nx
+        assert np.all((s["x"] >= 0.0) & (s["x"] < 1.0))
+        assert np.all(s["uy"] == 0.0) and np.all(s["uz"] == 0.0)     # electrostatic: nothing to bend them
+    rho_new = node_charge(a_e["cell"], a_e["x"], QE * w_e, nx) + node_charge(a_i["cell"], a_i["x"], -QE * w_i, nx)
+    # the currents of that step are still in the grid's (double-buffered) j rows
+    jx = _interior(sim.grid, "jx")
+    scale = abs(QE) * w_e * npc / (dt * dx)
+    res = continuity_residual(rho_old, rho_new, jx, dt, dx)
+    assert np.max(np.abs(res)) < 1e-9 * scale, np.max(np.abs(res)) / scale
+    # neutral plasma: the library's own rho rows (reference taps) sum to zero, and to +-Q N per species in jx terms
+    rho_lib = _interior(sim.grid, "rho")
+    assert abs(np.sum(rho_lib)) * dx < 1e-9 * abs(QE) * w_e * n_e
+    del a_e, a_i
+    sim.step(steps - 1)
+    sim.sync()
+    f1, ke1, ki1 = sim.energies()
+    assert len(sim.electrons) == n_e and len(sim.ions) == n_i
+    # the two-stream instability has barely started: total energy is conserved to the scheme's accuracy
+    tot0, tot1 = f0 + ke0 + ki0, f1 + ke1 + ki1
+    assert abs(tot1 - tot0) / tot0 < 1e-6
+    assert f1 > 0.0
+    if check_unfused:
+        sim2 = oa.Simulation(yaml_text=TWO_STREAM.format(nx=nx, npc=npc))
+        sim2.set_fused(False)         # the reference's operator order: advance, advance, clear, deposit, deposit
+        sim2.step(steps)
+        sim2.sync()
+        f2, ke2, ki2 = sim2.energies()
+        assert abs(f2 - f1) / f1 < 1e-9 and abs(ke2 - ke1) / ke1 < 1e-12 and abs(ki2 - ki1) / ki1 < 1e-12
+        ex1, ex2 = _interior(sim.grid, "Ex"), _interior(sim2.grid, "Ex")
+        assert np.max(np.abs(ex1 - ex2)) < 1e-9 * np.max(np.abs(ex1))
+
+
+def test_configs1_both_species_full_size(oa):
+    """BASELINE configs[1]: 4096 cells, 2441 e- + 2441 e+ per cell (2 x 9 998 336), the paired launch."""
+    _two_stream_checks(oa, 4096, 2441, steps=12, check_unfused=True)
+
+
+def test_configs2_shape_on_one_gpu(oa):
+    """BASELINE configs[2] / north_star's 1e8-particle two-stream: 32 768 cells, 1526 + 1526 per cell, one GPU."""
+    _two_stream_checks(oa, 32768, 1526, steps=6, check_unfused=False)
+
+
+LASER_PLASMA = """---
+control:
+ dx: micro / 1000
+ nx: 20000
+ xmin: -10*micro
+ start: -20.0e-6/c
+ end: 10.0e-6/c
+ current_deposition: true
+ n_outputs: 30
+ balance: true
+qed:
+ photon_emission: false
+ photon_absorption: false
+electrons:
+ npc: {npc}
+ ne: density * critical(omega) * step(x,xmin,xmax)
+ ux: sqrt(kT/(m*c^2)) * nrand
+ uy: sqrt(kT/(m*c^2)) * nrand
+ uz: sqrt(kT/(m*c^2)) * nrand
+ output: [x:px]
+ions:
+ name: carbon
+ npc: {npc}
+ Z: Z
+ A: A
+ ni: density * critical(omega) * step(x,xmin,xmax) / Z
+ ux: sqrt(kT/(A*mp*c^2)) * nrand
+ uy: sqrt(kT/(A*mp*c^2)) * nrand
+ uz: sqrt(kT/(A*mp*c^2)) * nrand
+ output: [x:px]
+laser:
+ Ey: (a0*me*c*omega/e) * gauss_pulse_re(t,x,omega,sigma)
+ Ez: (a0*me*c*omega/e) * gauss_pulse_im(t,x,omega,sigma)
+constants:
+ density: 100.0
+ a0: 300.0
+ omega: 2*pi*c/0.8e-6
+ sigma: pi * 4.0 / sqrt(ln(2.0))
+ xmin: 0.0 * micro
+ xmax: 5.0 * micro
+ Z: 6.0
+ A: 12.0
+ kT: 500 * eV
+"""
+
+
+def test_configs3_shape_laser_plasma(oa):
+    """BASELINE configs[3]'s physics on one GPU: examples/hole_boring.yaml's parameters (a0 = 300 pulse on an
+    overdense electron-carbon slab, laser + 200-cell absorber), 2000 + 2000 macro-particles per cell in the
+    5000-cell slab (2e7 particles).  Run until the pulse is boring into the slab, then check continuity cell by
+    cell over a step in which relativistic electrons cross cells and the transverse currents are live."""
+    npc, nx = 2000, 20000
+    sim = oa.Simulation(yaml_text=LASER_PLASMA.format(npc=npc))
+    dt, dx = sim.dt, sim.grid.dx
+    n0 = len(sim.electrons)
+    assert n0 == len(sim.ions) == 5000 * npc
+    f0, ke0, ki0 = sim.energies()
+    sim.step(21500)                  # the pulse reaches the slab after ~21 000 steps
+    sim.sync()
+    f1, ke1, ki1 = sim.energies()
+    assert f1 > 1e3 * max(f0, 1e-300) and ke1 > 50.0 * ke0     # the laser is in, the electrons are hot
+    s_e, s_i = sim.electrons.soa(), sim.ions.soa()
+    q_e, q_i = QE, -QE * 6.0
+    rho_old = node_charge(s_e["cell"], s_e["x"], q_e * s_e["w"], nx, periodic=False) \
+        + node_charge(s_i["cell"], s_i["x"], q_i * s_i["w"], nx, periodic=False)
+    g_e = np.sqrt(1.0 + s_e["ux"] ** 2 + s_e["uy"] ** 2 + s_e["uz"] ** 2)
+    assert g_e.max() > 20.0                                       # relativistic: cell crossings every step
+    n_e0, n_i0 = len(s_e["cell"]), len(s_i["cell"])
+    w_e = s_e["w"].max()
+    del s_e, s_i, g_e
+    sim.step(1)
+    sim.sync()
+    a_e, a_i = sim.electrons.soa(fields=("x", "w")), sim.ions.soa(fields=("x", "w"))
+    for s in (a_e, a_i):
+        assert s["cell"].min() >= 0 and s["cell"].max() < nx and np.all((s["x"] >= 0.0) & (s["x"] < 1.0))
+    assert len(a_e["cell"]) <= n_e0 and len(a_i["cell"]) <= n_i0  # open boundaries only ever lose particles
+    rho_new = node_charge(a_e["cell"], a_e["x"], q_e * a_e["w"], nx, periodic=False) \
+        + node_charge(a_i["cell"], a_i["x"], q_i * a_i["w"], nx, periodic=False)
+    jx = _interior(sim.grid, "jx")
+    res = continuity_residual(rho_old, rho_new, jx, dt, dx, periodic=False)
+    scale = abs(QE) * w_e * npc / (dt * dx)
+    # away from the two cells next to the open edges (particles deleted there deposit nothing: they left)
+    assert np.max(np.abs(res[4:-4])) < 1e-9 * scale, np.max(np.abs(res[4:-4])) / scale
+    assert np.max(np.abs(jx)) > 1e-2 * scale * dx and np.max(np.abs(_interior(sim.grid, "jy"))) > 0.0
+    # the pulse keeps heating the slab
+    sim.step(300)
+    sim.sync()
+    f2, ke2, ki2 = sim.energies()
+    assert (ke2 + ki2) > (ke1 + ki1)

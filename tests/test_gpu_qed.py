@@ -249,6 +249,32 @@ def test_emit_radiation_event_parity(oa, oracle):
     assert oa.emit_radiation(p, ph, seed=42, step=8, t=0.0) == 0
 
 
+def test_emitter_list_from_the_push_equals_a_scan(oa, oracle):
+    """The electron push compacts the slots whose optical depth ran out while tau is in registers (push_body);
+    emit_radiation consumes that list.  Re-uploading the (unchanged) optical depths makes the library distrust the
+    list and scan for the emitters instead (k_list_emitters): both must radiate exactly the same photons."""
+    o = oracle
+    nx, n, dx = 64, 6000, 1.0e-8
+    dt = 0.5 * dx / C
+    _, _, p1, _, ph1, _ = _prepared_pair(oa, o, nx, n, dx, dt, 23)
+    _, _, p2, _, ph2, _ = _prepared_pair(oa, o, nx, n, dx, dt, 23)
+    tau, ids = p2.emission_state()
+    p2.set_emission_state(tau, ids)            # same values: only the list's validity changes
+    n1 = oa.emit_radiation(p1, ph1, seed=5, step=3, t=0.0)
+    n2 = oa.emit_radiation(p2, ph2, seed=5, step=3, t=0.0)
+    assert n1 == n2 and 0.3 * n < n1 < 0.7 * n
+    a, b = ph1.soa(), ph2.soa()
+    (_, ia), (_, ib) = ph1.emission_state(), ph2.emission_state()
+    oa_, ob_ = np.argsort(ia, kind="stable"), np.argsort(ib, kind="stable")
+    assert np.array_equal(ia[oa_], ib[ob_])
+    for c in ("cell", "x", "ux", "uy", "uz", "w"):
+        assert np.array_equal(a[c][oa_], b[c][ob_]), c
+    t1, _ = p1.emission_state()
+    t2, _ = p2.emission_state()
+    assert np.array_equal(t1, t2) and np.all(t1 > 0.0)
+    assert oa.emit_radiation(p1, ph1, seed=5, step=4, t=0.0) == 0   # nothing left to emit: the list was consumed
+
+
 def test_new_optical_depths_are_exponential_draws(oa, oracle):
     o = oracle
     nx, n, dx = 32, 2000, 1.0e-8
@@ -326,6 +352,37 @@ def test_photon_push_matches_oracle(oa, oracle):
     assert ph.total_kinetic_energy() == pytest.approx(oph.total_kinetic_energy(), rel=1e-13)
     with pytest.raises(oa.OpalError):
         ph.advance_deposit(g, dt)  # photons carry no charge (photon.rs:199-201) and are never deposited
+
+
+def test_field_free_photon_push_matches_oracle(oa, oracle):
+    """Photons that track no chi / y / z go through the push that never touches the fields (k_push_photon:
+    36 B read, at most 12 B written per photon): same cells and offsets as the reference's Photon::push
+    (photon.rs:150-183), periodic wrap included; momenta and weights are never rewritten."""
+    o = oracle
+    nx, n, dx = 48, 6000, 1.0e-8
+    dt = 0.9 * dx / C
+    g, og = _strong_field_pair(oa, o, nx, dx, ey=3.0e13, bz_frac=0.3)
+    rng = np.random.default_rng(47)
+    cell = np.sort(rng.integers(0, nx, n)).astype(np.int32)
+    x = rng.random(n)
+    k = rng.normal(size=(3, n)) * 50.0
+    k[:, :10] = [[1e3], [0.0], [0.0]]  # straight along +x: |dxi| = c dt / dx
+    w = 1.0e3 * (1.0 + np.arange(n) * 1e-9)
+    ph = oa.Population(PHOTON, 2 * n)
+    ph.upload(cell, x, k[0], k[1], k[2], w, dx, dt)   # no track_extras: nothing that needs the fields
+    oph = o.Population.from_soa(PHOTON, cell, x, k[0], k[1], k[2], w, dx, dt)
+    for _ in range(9):
+        ph.advance(g, dt)
+        oph.advance(og, dt)
+    a, b = ph.soa(), oph.soa()
+    ia, ib = np.argsort(a["w"], kind="stable"), np.argsort(b["w"], kind="stable")
+    assert len(ia) == len(ib) == n
+    assert np.array_equal(a["cell"][ia], b["cell"][ib])
+    assert np.max(np.abs(a["x"][ia] - b["x"][ib])) < 1e-12
+    for c in ("ux", "uy", "uz", "w"):
+        assert np.array_equal(a[c][ia], b[c][ib])
+    assert ph.total_kinetic_energy() == pytest.approx(oph.total_kinetic_energy(), rel=1e-13)
+    assert ph.counters()["tile_misses"] == 0  # no tile, no misses: photons never drive the re-binning policy
 
 
 def test_photons_leave_through_open_boundaries(oa, oracle):
