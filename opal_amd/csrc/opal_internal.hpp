@@ -115,7 +115,16 @@ struct opal_pop {
     bool ctr_pending;
     int sort_interval;         // 0 never, >0 fixed, <0 adaptive
     int steps_since_sort;
-    int ppt;                   // particles per thread in the push kernels
+    int ppt;                   // particles per thread in the push kernels (uniform chunks: before the first
+                               // re-binning, and for slots appended since the last one)
+    // Chunk table, rebuilt by every re-binning: the push workgroups' slot ranges, cut both every 256 x 8 slots and
+    // every CHUNK_CELLS cells, so that no workgroup's particles span more cells than its LDS tile can serve however
+    // sparse the plasma is there.  tab_slot[i] .. tab_slot[i+1] are chunk i's slots; slots >= n_sorted (arrivals
+    // appended since) are taken in uniform chunks behind the table.
+    unsigned int *d_tab_slot;
+    unsigned int *h_tab_slot;  // host copy of d_tab_slot (pop_plan_split)
+    size_t tab_cap;
+    unsigned int n_tab, n_sorted;
     unsigned int *d_count;     // sort scratch: ncells + 2
     size_t count_cap;
     double *d_partial;

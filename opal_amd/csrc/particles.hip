@@ -81,6 +81,10 @@ struct PushArgs {
     unsigned send_cap;
     unsigned send_nextra;  // extras carried behind the 6 base fields (0 for a plain link)
     unsigned *emit_list;   // EXTRAS == 2: slots whose optical depth ran out in this push (count in ctr->n_emit)
+    // chunk table of the last re-binning (see opal_pop): workgroups [0, n_tab) take tab_slot[b] .. tab_slot[b+1],
+    // the rest uniform chunks of BLOCK x ppt slots from n_sorted on.  n_tab = 0: uniform chunks throughout.
+    const unsigned *tab_slot;
+    unsigned n_tab, n_sorted;
 };
 
 struct LdsFields {
@@ -329,9 +333,20 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
     const int tid = threadIdx.x;
     const int lane = tid & (REPL - 1);
-    const unsigned n = a.ctr->n_slots;
-    const size_t chunk0 = (size_t)block * BLOCK * a.ppt;
-    if (chunk0 >= n) return;
+    size_t chunk0;
+    unsigned nloc;
+    const bool tabled = block < a.n_tab;  // block-uniform
+    if (tabled) {
+        chunk0 = a.tab_slot[block];
+        nloc = a.tab_slot[block + 1] - (unsigned)chunk0;
+        if (nloc == 0) return;
+    } else {
+        const unsigned n = a.ctr->n_slots;
+        chunk0 = (size_t)a.n_sorted + (size_t)(block - a.n_tab) * BLOCK * a.ppt;
+        if (chunk0 >= n) return;
+        nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
+    }
+    const int iters = (int)((nloc + BLOCK - 1) / BLOCK);  // <= OPAL_MAX_PPT
 
     ChunkPtrs cp;
     cp.cell = a.cell + chunk0;
@@ -339,7 +354,6 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     cp.w = a.w + chunk0;
     cp.prev = (MODE != MODE_FUSED && a.prev_x) ? a.prev_x + chunk0 : nullptr;
     cp.chunk0 = chunk0;
-    const unsigned nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
 
     // The first slots' loads go out before anything else: the first cell also decides the tile base, and
     // the other values are in flight while the tile is set up.  One slot per lane stays in flight.
@@ -400,7 +414,12 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         int votes = s_max[0] + s_max[1] + s_max[2] + s_max[3];
         if (votes > 0) cmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
     }
-    const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - TILE_MARGIN;  // array index of tile cell 0
+    // Room for drift: a chunk of the table spans up to CHUNK_CELLS cells, so its tile is centred on the cells its
+    // first slots hold NOW (a bunch that moves together takes its tile along); uniform chunks keep the fixed margin
+    // below their lowest cell.
+    const int span = (cmin == 0x7fffffff || cmax - cmin > TILE_HI - TILE_LO) ? 0 : cmax - cmin;
+    const int margin = tabled ? (TILE - span) / 2 : TILE_MARGIN;
+    const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - margin;  // array index of tile cell 0
     if (GATHER) {
         for (int q = tid; q < 6 * TILE; q += BLOCK) {
             int comp = q / TILE, j = base + (q % TILE);
@@ -420,7 +439,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // remembered in a bit mask and taken in the second loop, which keeps every global access of this
     // loop a streaming one (precise vmcnt waits, no drain of the prefetch).
     unsigned pending = 0, emit_mask = 0;
-    for (int p = 0; p < a.ppt; p++) {
+    for (int p = 0; p < iters; p++) {
         const unsigned kc = k;
         const bool live = have_n && s_n.c != DEAD_CELL;
         int c = s_n.c;
@@ -428,7 +447,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         const double xi = s_n.x, wt = s_n.w, prev = s_n.prev;
         const V3 u = {s_n.ux, s_n.uy, s_n.uz};
         k += BLOCK;
-        if (p + 1 < a.ppt) {  // block-uniform; one slot per lane in flight (two measured 1.5 % slower)
+        if (p + 1 < iters) {  // block-uniform; one slot per lane in flight (two measured 1.5 % slower)
             s_n = fetch(min(k, last));
             have_n = k < nloc;
         }
@@ -465,7 +484,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.
     if (pending) {
         unsigned slow = 0;
-        for (int p = 0; p < a.ppt; p++) {
+        for (int p = 0; p < iters; p++) {
             if (!(pending & (1u << p))) continue;
             unsigned kc = (unsigned)p * BLOCK + tid;
             V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
@@ -506,7 +525,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             if (tid == 0) s_base[0] = atomicAdd(&a.ctr->n_emit, total);
             __syncthreads();
             unsigned at = s_base[0] + before + incl - mine;
-            for (int p = 0; p < a.ppt; p++)
+            for (int p = 0; p < iters; p++)
                 if (emit_mask & (1u << p)) a.emit_list[at++] = (unsigned)(chunk0 + (size_t)p * BLOCK + tid);
         }
     }
@@ -790,6 +809,37 @@ __global__ __launch_bounds__(256) void k_sort_scatter(SortArgs a, const PopCount
     }
 }
 
+// Chunk table (see opal_pop): the sorted merge of two monotone boundary lists, B1_k = min(k * chunk, N), k = 1..K1
+// (every 256 x 8 slots) and B2_j = cell_end[min(W j, ncells) - 1], j = 1..K2 (every W cells), computed in parallel:
+// a boundary's place in the merged list is its own index plus the number of boundaries of the other list in front
+// of it (ties: B1 first).  cell_end[c] is one past the last slot of cell c, as the scatter's cursors stand.
+constexpr int CHUNK_CELLS = 24;  // a chunk spans at most this many cells: (TILE - CHUNK_CELLS) / 2 - 3 = 17 cells of
+                                 // drift relative to the chunk's bulk, either way, before a particle misses the tile
+__device__ inline unsigned b2_at(const unsigned *cell_end, int ncells, unsigned j)
+{
+    return cell_end[min((int)(CHUNK_CELLS * j), ncells) - 1];
+}
+__global__ void k_chunk_table(const unsigned *__restrict__ cell_end, int ncells, unsigned chunk, unsigned N, unsigned K1,
+                              unsigned K2, unsigned *__restrict__ tab)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) tab[0] = 0;
+    if (t < K1) {
+        const unsigned k = t + 1;
+        const unsigned b = k == K1 ? N : k * chunk;
+        unsigned lo = 1, hi = K2 + 1;  // number of j in [1, K2] with B2_j < b: B2 is non-decreasing in j
+        while (lo < hi) {
+            unsigned mid = (lo + hi) / 2;
+            if (b2_at(cell_end, ncells, mid) < b) lo = mid + 1; else hi = mid;
+        }
+        tab[k + (lo - 1)] = b;
+    } else if (t < K1 + K2) {
+        const unsigned j = t - K1 + 1;
+        const unsigned b = b2_at(cell_end, ncells, j);
+        const unsigned before = min(K1 - 1, b / chunk) + (b >= N ? 1u : 0u);  // number of k with B1_k <= b
+        tab[j + before] = b;
+    }
+}
 __global__ void k_sort_finish(PopCounters *ctr)
 {
     ctr->n_slots = ctr->n_live;
@@ -1203,7 +1253,11 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
         a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
-    nblk = (unsigned)((p->n_upper + per_block - 1) / per_block);
+    a.tab_slot = p->d_tab_slot;
+    a.n_tab = p->n_tab;
+    a.n_sorted = p->n_sorted;
+    const size_t behind = p->n_upper > p->n_sorted ? p->n_upper - p->n_sorted : 0;  // appended since the re-binning
+    nblk = p->n_tab + (unsigned)((behind + per_block - 1) / per_block);
     return OPAL_OK;
 }
 
@@ -1282,11 +1336,24 @@ bool pop_plan_split(opal_pop_t *p, const opal_grid_t *g)
     if (!p->h_cell_end || p->n_cell_end != size) return false;
     const size_t W = (size_t)p->steps_since_sort + 7;
     if (2 * W + 16 >= size) return false;
-    const size_t chunk = (size_t)BLOCK * p->ppt;
     const size_t left_end = p->h_cell_end[W - 1];             // slots of cells [0, W)
     const size_t right_begin = p->h_cell_end[size - W - 1];   // slots of cells [size - W, size) start here
-    const size_t lo = (left_end + chunk - 1) / chunk, hi = right_begin / chunk;
-    const size_t all = (p->n_upper + chunk - 1) / chunk;
+    const size_t per_block = (size_t)BLOCK * p->ppt;
+    const size_t behind = p->n_upper > p->n_sorted ? p->n_upper - p->n_sorted : 0;
+    const size_t all = p->n_tab + (behind + per_block - 1) / per_block;
+    size_t lo, hi;
+    if (p->n_tab && p->h_tab_slot) {
+        // chunk i holds slots [tab[i], tab[i+1]): the chunks that start below left_end are edge chunks, and so is
+        // every chunk from the one that holds slot right_begin on (the uniform chunks behind the table included)
+        const unsigned *tab = p->h_tab_slot;
+        lo = std::lower_bound(tab, tab + p->n_tab, (unsigned)left_end) - tab;
+        hi = std::upper_bound(tab, tab + p->n_tab + 1, (unsigned)right_begin) - tab;
+        hi = hi ? hi - 1 : 0;
+        if (hi > p->n_tab) hi = p->n_tab;
+    } else {
+        lo = (left_end + per_block - 1) / per_block;
+        hi = right_begin / per_block;
+    }
     if (lo >= hi || hi > all || (hi - lo) * 2 < all) return false;  // the bulk must be worth a launch of its own
     p->split_lo = (unsigned)lo;
     p->split_hi = (unsigned)hi;
@@ -1506,7 +1573,30 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
         hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
         p->ctr_pending = false;
     }
-    // size the per-workgroup chunk so that it spans at most about a quarter of the tile
+    // the chunk table: slot ranges of the push workgroups, cut every 2048 slots and every CHUNK_CELLS cells
+    {
+        const unsigned N = (unsigned)p->n_upper, chunk = BLOCK * OPAL_MAX_PPT;
+        const unsigned K1 = (N + chunk - 1) / chunk, K2 = (unsigned)((ncells + CHUNK_CELLS - 1) / CHUNK_CELLS);
+        const unsigned M = N ? K1 + K2 : 0;
+        if (M + 1 > p->tab_cap) {
+            if (p->d_tab_slot) hipFree(p->d_tab_slot);
+            free(p->h_tab_slot);
+            p->d_tab_slot = nullptr; p->h_tab_slot = nullptr;
+            p->tab_cap = (size_t)M + 1 + M / 4;
+            OPAL_HIP(hipMalloc(&p->d_tab_slot, sizeof(unsigned) * p->tab_cap));
+            p->h_tab_slot = (unsigned *)malloc(sizeof(unsigned) * p->tab_cap);
+        }
+        if (M) {
+            k_chunk_table<<<(M + 255) / 256, 256, 0, p->stream>>>(p->d_count, (int)ncells, chunk, N, K1, K2, p->d_tab_slot);
+            OPAL_HIP(hipGetLastError());
+            if (p->h_tab_slot)
+                OPAL_HIP(hipMemcpyAsync(p->h_tab_slot, p->d_tab_slot, sizeof(unsigned) * (M + 1), hipMemcpyDeviceToHost, p->stream));
+            OPAL_HIP(hipStreamSynchronize(p->stream));
+        }
+        p->n_tab = M;
+        p->n_sorted = N;
+    }
+    // uniform chunks (slots appended behind the table): at most about a quarter of the tile
     unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
     double per_cell = (double)p->h_ctr->n_live / ne;
     int ppt = (int)((TILE / 4) * per_cell / BLOCK);
@@ -1524,12 +1614,19 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
     }
     // adaptive ("rent or buy"): every few steps read the tile-miss counter (one 64-byte D2H copy); once the
     // time lost to misses since the last re-binning exceeds what a re-binning costs, re-bin.
-    constexpr int check_every = 4;
-    // ns of kernel time per tile miss.  Measured by sweeping it: the two-stream bench is flat from 100 to 800
-    // (misses are rare there), the relativistic laser-plasma interaction is fastest at 800 (0.405 against
-    // 0.494 ms/step at 100): a miss costs far more than its own global atomics, because the workgroup it sits in
-    // finishes late
-    constexpr double miss_ns = 800.0;
+#ifndef OPAL_CHECK_EVERY
+#define OPAL_CHECK_EVERY 2  // measured: the laser-plasma interaction is 6 % faster at 2 than at 4; two-stream does not care
+#endif
+    constexpr int check_every = OPAL_CHECK_EVERY;
+    // ns of kernel time per tile miss.  Measured by sweeping it: the two-stream bench is flat (misses are rare
+    // there); the relativistic laser-plasma interaction runs at 0.494 ms/step at 100, 0.405 at 800 and, with the
+    // chunk table, 0.36 at 2000 and 5000 against 0.385 at 800: a miss costs far more than its own global atomics,
+    // because the workgroup it sits in finishes late, and misses arrive in bursts (a bunch outruns its tile), so
+    // a high price just triggers the re-binning one check earlier
+#ifndef OPAL_MISS_NS
+#define OPAL_MISS_NS 2000.0
+#endif
+    constexpr double miss_ns = OPAL_MISS_NS;
     if (p->steps_since_sort % check_every != 0) return OPAL_OK;
     // The counters are copied to pinned memory asynchronously and read at the NEXT check, check_every steps
     // later: waiting for that older copy keeps the host at most ~2 check intervals ahead of the device (so the
@@ -1622,6 +1719,8 @@ int opal_pop_free(opal_pop_t *p)
     }
     if (p->d_count) hipFree(p->d_count);
     if (p->d_emit_list) hipFree(p->d_emit_list);
+    if (p->d_tab_slot) hipFree(p->d_tab_slot);
+    free(p->h_tab_slot);
     free(p->h_cell_end);
     if (p->upper_event) hipEventDestroy(p->upper_event);
     if (p->h_upper) hipHostFree(p->h_upper);
@@ -1670,6 +1769,8 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     p->steps_since_sort = 0;
     p->emit_list_valid = false;
     p->dead_cost = 0.0;
+    p->n_tab = 0;     // no re-binning yet: uniform chunks
+    p->n_sorted = 0;
     p->dx_last = dx;
     {   // where each cell's particles are, if the caller's order is by cell (the loader's is)
         free(p->h_cell_end);
