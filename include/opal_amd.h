@@ -170,8 +170,10 @@ int opal_pop_counters(const opal_pop_t *p, uint32_t *out);
  * level 2 (electrons): also the optical depth and id that photon emission needs; 0 = off (default) */
 int opal_pop_track_extras(opal_pop_t *p, int on);
 /* the same by field, so that a run carries only what its outputs read (each costs 8-16 B of HBM traffic per
- * particle-update): OPAL_TRACK_EMISSION = optical depth + id (+ chi), OPAL_TRACK_ID = a photon's parent id */
-enum { OPAL_TRACK_CHI = 1, OPAL_TRACK_WORK = 2, OPAL_TRACK_YZ = 4, OPAL_TRACK_EMISSION = 8, OPAL_TRACK_ID = 16 };
+ * particle-update): OPAL_TRACK_EMISSION = optical depth + id (+ chi), OPAL_TRACK_ID = a photon's parent id,
+ * OPAL_TRACK_ABSORPTION (photons) = optical depths against absorption and stimulated emission + birth time */
+enum { OPAL_TRACK_CHI = 1, OPAL_TRACK_WORK = 2, OPAL_TRACK_YZ = 4, OPAL_TRACK_EMISSION = 8, OPAL_TRACK_ID = 16,
+       OPAL_TRACK_ABSORPTION = 32 };
 int opal_pop_track_fields(opal_pop_t *p, unsigned fields);
 /* opal_pop_advance stores prev_x for a later opal_grid_deposit (default); 0 = the caller never deposits this
  * population (photons; any species when current_deposition is off), so the 8 B per update are saved */
@@ -191,6 +193,37 @@ int opal_pop_upload_emission_state(opal_pop_t *p, size_t n, const double *tau, c
  * n_emitted (optional) receives the number of electrons that emitted. */
 int opal_emit_radiation(opal_pop_t *electrons, opal_pop_t *photons, uint64_t seed, uint32_t step, double t,
                         double min_energy, double max_angle, double max_formation_length, size_t *n_emitted);
+/* ------------------------------------------------------------------ Photon absorption
+ * absorb (particle/interactions.rs:145-340): every photon meets the electrons of its own cell in turn
+ * (Photon::interacts_with, photon.rs:312-362), running down its optical depths against one-photon absorption
+ * (qed/photon_absorption.rs:16-34) and stimulated emission (qed/stimulated_emission.rs:16-37; Airy function
+ * qed/special_functions/airy.rs:19-69) by w_e (c dt / dx) sigma per electron, and stops at the first that falls
+ * below zero: an absorbed photon is removed and gives the electron its momentum (Electron::kick,
+ * electron.rs:256-262); a stimulated emission appends a photon of the same momentum with the electron's weight
+ * and takes that momentum from the electron.  max_displacement [m, transverse distance travelled since birth]
+ * and stop_time [s since birth]: negative = no limit.  The electrons are re-binned by cell first (the
+ * reference requires both populations sorted; the photons' order does not matter here).  Needs electrons that
+ * track chi and ids (OPAL_TRACK_EMISSION or OPAL_TRACK_CHI | OPAL_TRACK_ID) and photons that track
+ * OPAL_TRACK_CHI | OPAL_TRACK_YZ | OPAL_TRACK_ID | OPAL_TRACK_ABSORPTION.  Random numbers: Philox4x32-10 keyed by
+ * (seed, photon's parent id and birth time, step).  n_absorbed / n_stimulated are optional. */
+int opal_absorb(opal_pop_t *electrons, opal_pop_t *photons, const opal_grid_t *grid, uint64_t seed, uint32_t step,
+                double t, double dt, double max_displacement, double stop_time, size_t *n_absorbed,
+                size_t *n_stimulated);
+/* A photon's optical depths against absorption / stimulated emission and its birth time, slot order (dead slots
+ * skipped); any pointer may be null.  The upload overwrites the first n slots (call right after
+ * opal_pop_upload_soa). */
+int opal_pop_download_absorption_state(const opal_pop_t *p, double *tau_abs, double *tau_st, double *birth_time);
+int opal_pop_upload_absorption_state(opal_pop_t *p, size_t n, const double *tau_abs, const double *tau_st,
+                                     const double *birth_time);
+/* chi of the first n slots (tests: a population that has not been pushed through a field yet) */
+int opal_pop_upload_chi(opal_pop_t *p, size_t n, const double *chi);
+/* the transverse coordinates y, z of the first n slots (electron.rs:18-19 / photon.rs:19-20), likewise */
+int opal_pop_upload_yz(opal_pop_t *p, size_t n, const double *y, const double *z);
+/* airy_ai_for_positive and the two scaled cross sections on the device for n inputs in host memory: k, p are
+ * n x 4 (normalised four-momenta of photon and electron); out_* receive NaN where the reference returns None */
+int opal_qed_airy_batch(size_t n, const double *x, double *out);
+int opal_qed_cross_sections_batch(size_t n, const double *k, const double *p, const double *chi_gamma,
+                                  const double *chi_e, double *out_absorption, double *out_stimulated);
 /* photon_emission::sample / classical_sample, the emission random numbers and photon_emission::rate
  * evaluated on the device for n inputs in host memory (out: 3n / 4n / n doubles). */
 int opal_qed_sample_batch(size_t n, const double *chi, const double *gamma, const double *r1, const double *r2,

@@ -292,6 +292,12 @@ class Population:
         _check(self._lib.opal_pop_download_emission_state(self.h, _ptr(tau) if tau is not None else None, _ptr(ids)))
         return tau, ids
 
+    def ids(self):
+        """The ids of the live particles in slot order (electrons: own id; photons: the parent electron's)."""
+        out = np.empty(len(self), dtype=np.uint64)
+        _check(self._lib.opal_pop_download_emission_state(self.h, None, _ptr(out)))
+        return out
+
     def set_emission_state(self, tau=None, ids=None):
         """Overwrite the optical depths / ids of the particles just uploaded (same order)."""
         t = np.ascontiguousarray(tau, dtype=np.float64) if tau is not None else None
@@ -299,6 +305,30 @@ class Population:
         n = len(t) if t is not None else len(i)
         _check(self._lib.opal_pop_upload_emission_state(self.h, n, _ptr(t) if t is not None else None,
                                                         _ptr(i) if i is not None else None))
+
+    def track_fields(self, fields):
+        """Bit mask of TRACK_* flags: carry only what is named (opal_pop_track_fields)."""
+        _check(self._lib.opal_pop_track_fields(self.h, int(fields)))
+
+    def absorption_state(self):
+        """(tau_abs, tau_st, birth_time) of every photon in slot order (photon.rs:28-30)."""
+        n = len(self)
+        out = [np.empty(n) for _ in range(3)]
+        _check(self._lib.opal_pop_download_absorption_state(self.h, *[_ptr(a) for a in out]))
+        return tuple(out)
+
+    def set_absorption_state(self, tau_abs=None, tau_st=None, birth_time=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (tau_abs, tau_st, birth_time)]
+        n = max(len(a) for a in arrs if a is not None)
+        _check(self._lib.opal_pop_upload_absorption_state(self.h, n, *[_ptr(a) for a in arrs]))
+
+    def set_chi(self, chi):
+        chi = np.ascontiguousarray(chi, dtype=np.float64)
+        _check(self._lib.opal_pop_upload_chi(self.h, len(chi), _ptr(chi)))
+
+    def set_yz(self, y, z):
+        y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in (y, z))
+        _check(self._lib.opal_pop_upload_yz(self.h, len(y), _ptr(y), _ptr(z)))
 
     def extras(self):
         n = len(self)
@@ -316,6 +346,37 @@ def emit_radiation(electrons, photons, seed, step, t, min_energy=None, max_angle
     _check(_lib.load().opal_emit_radiation(electrons.h, photons.h, seed, step, t, f(min_energy), f(max_angle),
                                            f(max_formation_length), C.byref(n) if count else None))
     return n.value if count else None
+
+
+TRACK_CHI, TRACK_WORK, TRACK_YZ, TRACK_EMISSION, TRACK_ID, TRACK_ABSORPTION = 1, 2, 4, 8, 16, 32
+
+
+def absorb(electrons, photons, grid, seed, step, t, dt, max_displacement=None, stop_time=None):
+    """absorb (particle/interactions.rs:145-340); returns (photons absorbed, emissions stimulated)."""
+    f = lambda v: -1.0 if v is None else float(v)
+    na, ns = C.c_size_t(), C.c_size_t()
+    _check(_lib.load().opal_absorb(electrons.h, photons.h, grid.h, seed, step, t, dt, f(max_displacement), f(stop_time),
+                                   C.byref(na), C.byref(ns)))
+    return na.value, ns.value
+
+
+def qed_airy(x):
+    """airy_ai_for_positive on the device; NaN where the reference returns None."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(len(x))
+    _check(_lib.load().opal_qed_airy_batch(len(x), _ptr(x), _ptr(out)))
+    return out
+
+
+def qed_cross_sections(k, p, chi_gamma, chi_e):
+    """(absorption, stimulated emission) scaled cross sections on the device for n pairs; k, p are (n, 4)."""
+    k = np.ascontiguousarray(k, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    cg = np.ascontiguousarray(chi_gamma, dtype=np.float64)
+    ce = np.ascontiguousarray(chi_e, dtype=np.float64)
+    a, b = np.empty(len(cg)), np.empty(len(cg))
+    _check(_lib.load().opal_qed_cross_sections_batch(len(cg), _ptr(k), _ptr(p), _ptr(cg), _ptr(ce), _ptr(a), _ptr(b)))
+    return a, b
 
 
 def qed_sample(chi, gamma, r1, r2, r3, classical=False):

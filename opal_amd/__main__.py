@@ -30,7 +30,8 @@ def main(argv):
     if world > 1:
         dist.init_process_group(backend, rank=rank, world_size=world,
                                 **({"device_id": device} if backend == "nccl" else {}))
-        emission = oa.Config(path=argv[1]).read_bool("qed", "photon_emission")
+        cfg = oa.Config(path=argv[1])
+        emission, absorption = cfg.read_bool("qed", "photon_emission"), cfg.read_bool("qed", "photon_absorption")
         # room for the leavers of one step through one cut, per species (an overflow is reported as an error).
         # Messages normally have a fixed size -- all slots travel every step; OPAL_LINK_EXACT=1 sizes them to
         # their content instead (two RCCL groups and a host synchronisation per step, ~+13 % on a 0.35 ms step:
@@ -38,11 +39,11 @@ def main(argv):
         cap = int(os.environ.get("OPAL_LINK_CAPACITY", "65536"))
         stream = torch.cuda.current_stream().cuda_stream
         if backend == "nccl" and os.environ.get("OPAL_LINK", "rccl") == "rccl":
-            link = RcclLink(rank, world, device, cap, photon_emission=emission, stream=stream,
+            link = RcclLink(rank, world, device, cap, photon_emission=emission, photon_absorption=absorption, stream=stream,
                             exact=os.environ.get("OPAL_LINK_EXACT", "0") == "1")  # native RCCL send/recv
         else:
             link = TorchLink(rank, world, device if backend == "nccl" else torch.device("cpu"), cap,
-                             photon_emission=emission, stream=stream)
+                             photon_emission=emission, photon_absorption=absorption, stream=stream)
     try:
         sim = oa.Simulation(yaml_path=argv[1], rank=rank, numtasks=world, link=link,
                             stream=torch.cuda.current_stream().cuda_stream)

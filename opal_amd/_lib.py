@@ -75,6 +75,13 @@ SIGNATURES = {
     "opal_pop_download_emission_state": (C.c_int, [vp, vp, vp]),
     "opal_pop_upload_emission_state": (C.c_int, [vp, sz, vp, vp]),
     "opal_emit_radiation": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
+    "opal_absorb": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, C.POINTER(sz), C.POINTER(sz)]),
+    "opal_pop_download_absorption_state": (C.c_int, [vp, vp, vp, vp]),
+    "opal_pop_upload_absorption_state": (C.c_int, [vp, sz, vp, vp, vp]),
+    "opal_pop_upload_chi": (C.c_int, [vp, sz, vp]),
+    "opal_pop_upload_yz": (C.c_int, [vp, sz, vp, vp]),
+    "opal_qed_airy_batch": (C.c_int, [sz, vp, vp]),
+    "opal_qed_cross_sections_batch": (C.c_int, [sz, vp, vp, vp, vp, vp, vp]),
     "opal_qed_sample_batch": (C.c_int, [sz, vp, vp, vp, vp, vp, C.c_int, vp]),
     "opal_qed_randoms_batch": (C.c_int, [sz, C.c_uint64, vp, C.c_uint32, vp]),
     "opal_qed_rate_batch": (C.c_int, [sz, vp, vp, vp]),

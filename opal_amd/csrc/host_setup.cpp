@@ -104,8 +104,8 @@ int design_balanced(int numtasks, size_t size, double xmin, double dx, size_t mi
 // Draw order per particle: x, then (urand, nrand) for ux, uy, uz, then the
 // species' optical depths (one Exp1 for electrons, electron.rs:168-172, kept
 // in out.tau: it only matters when photon emission is on; none for ions,
-// ion.rs:157-159; four for photons, photon.rs:126-133, which only absorption
-// reads: drawn to keep the stream aligned, then dropped).
+// ion.rs:157-159; four for photons, photon.rs:126-133: the last two, the depths
+// against absorption and stimulated emission, are kept in out.tau / out.tau2).
 void load_population(int species, size_t npc, const std::function<double(double)> &number_density,
                      const Fn3 &ux, const Fn3 &uy, const Fn3 &uz, double grid_xmin, double dx, size_t ncells,
                      Rng &rng, HostSoA &out)
@@ -125,8 +125,13 @@ void load_population(int species, size_t npc, const std::function<double(double)
             ur = rng.uniform(); nr = rng.normal();
             double vz = uz(real_x, ur, nr);
             if (species == 0) out.tau.push_back(rng.exp1());
-            if (species == 2)
-                for (int k = 0; k < 4; k++) (void)rng.exp1();
+            else if (species == 2) {
+                // photon.rs:126-133: tau[0], tau[1] (never read), tau_abs, tau_st
+                (void)rng.exp1();
+                (void)rng.exp1();
+                out.tau.push_back(rng.exp1());
+                out.tau2.push_back(rng.exp1());
+            }
             out.cell.push_back((int32_t)c);
             out.x.push_back(xf);
             out.ux.push_back(vx);

@@ -21,7 +21,9 @@ using Fn3 = std::function<double(double, double, double)>;
 struct HostSoA {
     std::vector<int32_t> cell;
     std::vector<double> x, ux, uy, uz, w;
-    std::vector<double> tau;  // electrons: the optical depth against emission drawn at load time (electron.rs:168-172)
+    std::vector<double> tau;  // electrons: the optical depth against emission drawn at load time (electron.rs:168-172);
+                              // photons: the one against absorption (photon.rs:131)
+    std::vector<double> tau2; // photons: the optical depth against stimulated emission (photon.rs:132)
     size_t size() const { return cell.size(); }
 };
 

@@ -10,6 +10,7 @@
 //       int32  cell[P]            re-based cell index in the receiver's frame (mod.rs:291-293, 366-368)
 //       double x[P] ux[P] uy[P] uz[P] w[P] prev_x[P]
 //       double chi[P] work[P] y[P] z[P] tau[P] id[P]     only when the link was created with 12 fields
+//       double tau_abs[P] tau_st[P] birth[P]              only with 15 fields (photon absorption)
 // S = 2 and 6 fields by default; runs with photon emission use S = 3 and 12 fields (the reference ships
 // whole structs, so optical depths and ids must travel with an electron that changes subdomain).
 // A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes; anything with particles moves
@@ -101,7 +102,7 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
                             void *hip_stream)
 {
     if (!out || !exchange || size < 1 || rank < 0 || rank >= size || species_slots < 2 || species_slots > 3
-        || (fields_per_particle != 6 && fields_per_particle != 12)) {
+        || (fields_per_particle != 6 && fields_per_particle != 12 && fields_per_particle != 15)) {
         set_error("opal_link_create: bad arguments");
         return OPAL_ERR_ARG;
     }

@@ -39,7 +39,9 @@ struct PopCounters {
     unsigned int pad[5];
 };
 
-enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, NEX = 6 };
+// EX_TAU_ABS, EX_TAU_ST, EX_BIRTH: a photon's optical depths against absorption / stimulated emission and its birth
+// time (photon.rs:28-30), carried only when photon absorption is on
+enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, EX_TAU_ABS = 6, EX_TAU_ST = 7, EX_BIRTH = 8, NEX = 9 };
 enum { KERNEL_FUSED = 0, KERNEL_ADVANCE = 1, KERNEL_DEPOSIT = 2, KERNEL_FIELD = 3, KERNEL_SORT = 4, KERNEL_COUNT = 5 };
 void prof_begin(int kernel, hipStream_t s);
 void prof_end(int kernel, hipStream_t s);
@@ -91,6 +93,8 @@ struct opal_pop {
     size_t emit_list_cap;
     bool emit_list_valid;         // the last push left the list of emitters (and d_ctr->n_emit) behind; nothing has
                                   // moved or re-armed a slot since (re-binning, uploads, an emission pass)
+    bool sorted_exact;            // slots are exactly in cell order and d_count holds the cell ends (set by a
+                                  // re-binning, cleared by anything that moves or adds particles)
     double dead_cost;             // bytes streamed for vacated slots since the last re-binning (photon policy)
     // where each cell's particles ended up at the last re-binning (or sorted upload): slot index one past the last
     // particle of cell c, for c < n_cell_end; host copy, used to tell which slots can reach a subdomain edge

@@ -1142,8 +1142,8 @@ int grow(opal_pop_t *p, size_t new_cap)
 
 // T::create's values for the extras of slots [first, first + n): chi = work = y = z = 0,
 // tau = +inf (electron.rs:98-99), id = id_base + slot
-__global__ void k_reset_extras(double *chi, double *work, double *y, double *z, double *tau, double *id, size_t first,
-                               size_t n, unsigned long long id_base)
+__global__ void k_reset_extras(double *chi, double *work, double *y, double *z, double *tau, double *id, double *tau_abs,
+                               double *tau_st, double *birth, size_t first, size_t n, unsigned long long id_base)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1154,6 +1154,9 @@ __global__ void k_reset_extras(double *chi, double *work, double *y, double *z, 
     if (z) z[i] = 0.0;
     if (tau) tau[i] = INFINITY;
     if (id) reinterpret_cast<unsigned long long *>(id)[i] = id_base + i;
+    if (tau_abs) tau_abs[i] = INFINITY;  // photon.rs:113-115
+    if (tau_st) tau_st[i] = INFINITY;
+    if (birth) birth[i] = -INFINITY;
 }
 
 int reset_extras(opal_pop_t *p, size_t first, size_t n)
@@ -1161,6 +1164,7 @@ int reset_extras(opal_pop_t *p, size_t first, size_t n)
     if (!n) return OPAL_OK;
     k_reset_extras<<<(unsigned)((n + 255) / 256), 256, 0, p->stream>>>(p->d_ex[EX_CHI], p->d_ex[EX_WORK], p->d_ex[EX_Y],
                                                                        p->d_ex[EX_Z], p->d_ex[EX_TAU], p->d_ex[EX_ID],
+                                                                       p->d_ex[EX_TAU_ABS], p->d_ex[EX_TAU_ST], p->d_ex[EX_BIRTH],
                                                                        first, n, p->id_base);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
@@ -1277,6 +1281,7 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     PushArgs a;
     unsigned nblk;
     if (int rc = build_args(p, link, g, dt, mode, a, nblk)) return rc;
+    if (mode != MODE_DEPOSIT) p->sorted_exact = false;
     if (p->species == OPAL_ELECTRON && p->extras == 2 && p->d_ex[EX_TAU] && mode != MODE_DEPOSIT) {
         // the push compacts this step's emitters as it goes (see push_body): start an empty list
         if (int rc = ensure_emit_list(p)) return rc;
@@ -1375,6 +1380,7 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     }
     PushArgs ae, ai;
     unsigned ne, ni;
+    if (mode != MODE_DEPOSIT) pe->sorted_exact = pi->sorted_exact = false;
     if (int rc = build_args(pe, link, g, dt, mode, ae, ne)) return rc;
     if (int rc = build_args(pi, link, g, dt, mode, ai, ni)) return rc;
     PairPlan plan = {0, ne, 0, 0, 0, ni, 0, 0};
@@ -1432,6 +1438,7 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     u.my_size = (int)g->size;
     u.emit_list = (p->emit_list_valid && p->emit_list_cap >= p->cap) ? p->d_emit_list : nullptr;
     if (!u.emit_list) p->emit_list_valid = false;  // arrivals the list does not know about
+    p->sorted_exact = false;
     p->n_upper += incoming;
     p->added_since_snapshot += incoming;
     return OPAL_OK;
@@ -1568,6 +1575,7 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     }
     p->steps_since_sort = 0;
     p->emit_list_valid = false;  // slots moved
+    p->sorted_exact = true;
     p->dead_cost = 0.0;
     if (p->ctr_pending) {
         hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
@@ -1768,6 +1776,7 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     p->added_since_snapshot = 0;
     p->steps_since_sort = 0;
     p->emit_list_valid = false;
+    p->sorted_exact = false;
     p->dead_cost = 0.0;
     p->n_tab = 0;     // no re-binning yet: uniform chunks
     p->n_sorted = 0;
@@ -1863,12 +1872,13 @@ int opal_pop_track_fields(opal_pop_t *p, unsigned fields)
 {
     if (int rc = check_pop(p)) return rc;
     if (p->species == OPAL_ION) return OPAL_OK;  // ion.rs has no chi / y / z; its `work` is not surfaced
-    bool need[NEX] = {false, false, false, false, false, false};
+    bool need[NEX] = {};
     need[EX_CHI] = fields & (OPAL_TRACK_CHI | OPAL_TRACK_EMISSION);  // emission reads the electron's chi
     need[EX_WORK] = (fields & OPAL_TRACK_WORK) && p->species == OPAL_ELECTRON;  // photon.rs:207-209: always 0
     need[EX_Y] = need[EX_Z] = fields & OPAL_TRACK_YZ;
     need[EX_TAU] = (fields & OPAL_TRACK_EMISSION) && p->species == OPAL_ELECTRON;
     need[EX_ID] = need[EX_TAU] || (fields & OPAL_TRACK_ID);
+    need[EX_TAU_ABS] = need[EX_TAU_ST] = need[EX_BIRTH] = (fields & OPAL_TRACK_ABSORPTION) && p->species == OPAL_PHOTON;
     bool fresh[NEX], any_fresh = false, any = false;
     for (int q = 0; q < NEX; q++) {
         fresh[q] = need[q] && !p->d_ex[q];
@@ -2164,6 +2174,13 @@ int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link,
     return run_push_pair(pe, pi, link, g, dt, edges ? PART_EDGES : PART_BULK);
 }
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
+// exact binning by cell now (photon absorption pairs every photon with the electrons of its cell): leaves
+// p->d_count[c] = one past the last slot of cell c
+int pop_sort_exact(opal_pop_t *p, const opal_grid_t *g)
+{
+    if (p->sorted_exact && p->d_count && p->n_cell_end == g->size) return OPAL_OK;  // nothing has moved since
+    return do_sort(p, g);
+}
 // The host's bound on the slots in use (n_upper) when particles are appended by the device without the host
 // knowing how many (photon emission): the true count is copied to pinned memory asynchronously after an
 // append; once a copy has landed, n_upper drops to that count plus whatever has been reserved since.

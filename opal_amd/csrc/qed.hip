@@ -235,37 +235,6 @@ __device__ bool quantum_sample(double chi, double gamma, double rand1, double ra
     return true;
 }
 
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11)
-__device__ inline void philox(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-__device__ inline double u53(uint32_t hi, uint32_t lo)
-{
-    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
-}
-// the four uniforms of one emission, in the order electron.rs:209-218 draws them: new optical depth,
-// rand1 (energy), rand2 (polar angle), rand3 (azimuth)
-__device__ inline void emission_randoms(uint64_t seed, uint64_t id, uint32_t step, double (&out)[4])
-{
-    uint32_t c[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 0u};
-    philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    out[0] = u53(c[0], c[1]);
-    out[1] = u53(c[2], c[3]);
-    uint32_t d[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 1u};
-    philox(d, (uint32_t)seed, (uint32_t)(seed >> 32));
-    out[2] = u53(d[0], d[1]);
-    out[3] = u53(d[2], d[3]);
-}
-
 // vec3.rs:115-138
 __device__ inline V3 normalize(V3 a) { return (1.0 / sqrt(dot(a, a))) * a; }
 __device__ inline V3 orthogonal(V3 a)
@@ -295,6 +264,8 @@ struct RadiateArgs {
     int *pcell;
     double *px, *pkx, *pky, *pkz, *pw;
     double *pchi, *py, *pz, *pid;  // photon extras, each may be null
+    double *ptau_abs, *ptau_st, *pbirth;  // with photon absorption on: the new photon's optical depths and birth time
+    double t;
     PopCounters *pctr;
     unsigned pcap;
     unsigned long long seed;
@@ -418,6 +389,13 @@ __device__ void radiate_one(const RadiateArgs &a, size_t i)
     if (a.py) a.py[slot] = 0.0;
     if (a.pz) a.pz[slot] = 0.0;
     if (a.pid) memcpy(&a.pid[slot], &id, sizeof id);
+    if (a.ptau_abs) {  // .with_optical_depths(rng).at_time(t), electron.rs:244-246
+        double od[2];
+        birth_randoms(a.seed, id, a.step, od);
+        a.ptau_abs[slot] = -log(1.0 - od[0]);
+        a.ptau_st[slot] = -log(1.0 - od[1]);
+        a.pbirth[slot] = a.t;
+    }
 }
 
 __global__ void k_sample_batch(int n, const double *chi, const double *gamma, const double *r1, const double *r2,
@@ -453,7 +431,6 @@ extern "C" {
 int opal_emit_radiation(opal_pop_t *e, opal_pop_t *ph, uint64_t seed, uint32_t step, double t, double min_energy,
                         double max_angle, double max_formation_length, size_t *n_emitted)
 {
-    (void)t;  // a photon's birth time is only read by the absorption module (out of scope)
     if (!e || !ph || e->species != OPAL_ELECTRON || ph->species != OPAL_PHOTON) {
         set_error("opal_emit_radiation: needs an electron and a photon population");
         return OPAL_ERR_ARG;
@@ -512,13 +489,16 @@ int opal_emit_radiation(opal_pop_t *e, opal_pop_t *ph, uint64_t seed, uint32_t s
     a.pw = ph->d_w[pk];
     if (ph->extras) {
         a.pchi = ph->d_ex[EX_CHI]; a.py = ph->d_ex[EX_Y]; a.pz = ph->d_ex[EX_Z]; a.pid = ph->d_ex[EX_ID];
+        a.ptau_abs = ph->d_ex[EX_TAU_ABS]; a.ptau_st = ph->d_ex[EX_TAU_ST]; a.pbirth = ph->d_ex[EX_BIRTH];
     }
+    a.t = t;
     a.pctr = ph->d_ctr;
     a.pcap = (unsigned)ph->cap;
     a.seed = seed; a.step = step;
     a.min_energy = min_energy; a.max_angle = max_angle; a.max_formation_length = max_formation_length;
     k_radiate<<<(unsigned)std::min<size_t>((emitters + 255) / 256, 2048), 256, 0, e->stream>>>(a);
     OPAL_HIP(hipGetLastError());
+    ph->sorted_exact = false;
     ph->n_upper += emitters;  // upper bound: the filters may have dropped some
     ph->prev_valid = false;   // Photon::create(.., dx = 0, dt = 0): prev_x is 0/0 until the first push
     if (n_emitted) {

@@ -3,6 +3,8 @@
 #pragma once
 #include "pic_device.hpp"
 
+#include <cstdint>
+
 namespace opal {
 
 constexpr double ALPHA_FINE = 7.29735257e-3;     // constants.rs
@@ -46,6 +48,62 @@ __device__ inline double qed_rate(double chi, double gamma)
         h = exp((1.0 - weight) * QED_LN_H[i] + weight * QED_LN_H[i + 1]);
     }
     return sqrt(3.0) * ALPHA_FINE * chi * h / (2.0 * M_PI * gamma * COMPTON_TIME);
+}
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11)
+__device__ inline void philox(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ inline double u53(uint32_t hi, uint32_t lo)
+{
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+// the four uniforms of one emission, in the order electron.rs:209-218 draws them: new optical depth,
+// rand1 (energy), rand2 (polar angle), rand3 (azimuth)
+__device__ inline void emission_randoms(uint64_t seed, uint64_t id, uint32_t step, double (&out)[4])
+{
+    uint32_t c[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 0u};
+    philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    out[0] = u53(c[0], c[1]);
+    out[1] = u53(c[2], c[3]);
+    uint32_t d[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 1u};
+    philox(d, (uint32_t)seed, (uint32_t)(seed >> 32));
+    out[2] = u53(d[0], d[1]);
+    out[3] = u53(d[2], d[3]);
+}
+
+// the optical depths a photon is born with (tau_abs, tau_st: photon.rs:126-133; tau[0..2] are never read): two more
+// uniforms of the stream keyed by (seed, parent electron id, step)
+__device__ inline void birth_randoms(uint64_t seed, uint64_t id, uint32_t step, double (&out)[2])
+{
+    uint32_t c[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 2u};
+    philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    out[0] = u53(c[0], c[1]);
+    out[1] = u53(c[2], c[3]);
+}
+// the three uniforms a photon may need in absorb(): the choice between absorption and stimulated emission when both
+// optical depths run out together, a new tau_abs, a new tau_st (photon.rs:341-357).  Keyed by the photon: parent id
+// and birth time (an electron emits at most one photon per step), and the step.
+__device__ inline void absorption_randoms(uint64_t seed, uint64_t id, double birth_time, uint32_t step, double (&out)[3])
+{
+    const uint64_t bt = (uint64_t)__double_as_longlong(birth_time);
+    const uint32_t k0 = (uint32_t)seed ^ (uint32_t)bt, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(bt >> 32);
+    uint32_t c[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 16u};
+    philox(c, k0, k1);
+    out[0] = u53(c[0], c[1]);
+    out[1] = u53(c[2], c[3]);
+    uint32_t d[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 17u};
+    philox(d, k0, k1);
+    out[2] = u53(d[0], d[1]);
 }
 
 }  // namespace opal

@@ -158,7 +158,8 @@ struct opal_sim {
     std::string ion_name;
     std::vector<std::string> electron_output, ion_output, photon_output;  // the `output:` lists (main.rs:117,134,156)
     // qed section (main.rs:78-83); limits < 0 = None
-    bool photon_emission = false;
+    bool photon_emission = false, photon_absorption = false;
+    double absorb_max_displacement = -1.0, absorb_stop_time = -1.0;  // main.rs:84-85,247 (see sim_setup)
     double photon_energy_min = -1.0, photon_angle_max = -1.0, max_formation_length = -1.0;
     uint64_t emission_seed = 0;
     size_t step_index = 0;
@@ -209,6 +210,9 @@ int track_for_outputs(opal_sim_t *s, opal_pop_t *p)
     if (mentions("work")) fields |= OPAL_TRACK_WORK;
     if (mentions("r")) fields |= OPAL_TRACK_YZ;
     if (s->photon_emission) fields |= p->species == OPAL_ELECTRON ? OPAL_TRACK_EMISSION : OPAL_TRACK_ID;
+    if (s->photon_absorption)  // absorb() reads both species' chi, the photons' y, z, optical depths and birth times
+        fields |= p->species == OPAL_ELECTRON ? (OPAL_TRACK_CHI | OPAL_TRACK_ID)
+                                              : (OPAL_TRACK_CHI | OPAL_TRACK_YZ | OPAL_TRACK_ID | OPAL_TRACK_ABSORPTION);
     if (int rc = opal_pop_track_fields(p, fields)) return rc;
     // prev_x is only read by a separate deposit pass
     return opal_pop_keep_prev_x(p, s->current_deposition ? 1 : 0);
@@ -242,6 +246,8 @@ int load_species(opal_sim_t *s, const char *section, const char *density_key, in
         return rc;
     if (s->photon_emission && species == OPAL_ELECTRON)  // Population::new ... .with_optical_depths(rng), mod.rs:193
         return opal_pop_upload_emission_state(*out, soa.size(), soa.tau.data(), nullptr);
+    if (s->photon_absorption && species == OPAL_PHOTON && soa.size())
+        return opal_pop_upload_absorption_state(*out, soa.size(), soa.tau.data(), soa.tau2.data(), nullptr);
     return OPAL_OK;
 }
 
@@ -260,16 +266,15 @@ int sim_setup(opal_sim_t *s)
     if (!in.read_bool("control", "current_deposition", s->current_deposition, ce)) return config_fail(ce);
     if (!in.read_usize("control", "n_outputs", s->n_outputs, ce)) return config_fail(ce);
     if (!in.read_bool("control", "balance", s->balance, ce)) s->balance = true;  // main.rs:76
-    bool photon_absorption;
     if (!in.read_bool("qed", "photon_emission", s->photon_emission, ce)) return config_fail(ce);
-    if (!in.read_bool("qed", "photon_absorption", photon_absorption, ce)) return config_fail(ce);
-    if (photon_absorption) {
-        set_error("qed.photon_absorption is outside this build's scope (SURVEY.md 8f-4)");
-        return OPAL_ERR_CONFIG;
-    }
-    {  // main.rs:80-83: all optional
+    if (!in.read_bool("qed", "photon_absorption", s->photon_absorption, ce)) return config_fail(ce);
+    {  // main.rs:80-85: all optional
         ConfigError ignored;
         double v;
+        // main.rs:247 hands `disable_qed_after` to absorb() as max_displacement and `disable_absorption_after` as
+        // stop_time (interactions.rs:145): reproduced as called, whatever the key names suggest
+        if (in.read_f64("qed", "disable_qed_after", v, ignored)) s->absorb_max_displacement = v;
+        if (in.read_f64("qed", "disable_absorption_after", v, ignored)) s->absorb_stop_time = v;
         if (in.read_f64("qed", "max_formation_length", v, ignored)) s->max_formation_length = v;
         if (in.read_f64("qed", "photon_energy_min", v, ignored)) s->photon_energy_min = 1.0e-6 * v / 1.602177e-19;  // J -> MeV
         if (in.read_f64("qed", "photon_angle_max", v, ignored)) s->photon_angle_max = v;
@@ -325,7 +330,7 @@ int sim_setup(opal_sim_t *s)
         if (int rc = load_species(s, "ions", "ni", OPAL_ION, ipc, rng, &s->ions)) return rc;
         if (int rc = opal_pop_set_charge_state(s->ions, z, z, a)) return rc;  // main.rs:142-147
     }
-    if (s->photon_emission) {  // main.rs:153-170
+    if (s->photon_emission || s->photon_absorption) {  // main.rs:153-170
         size_t ppc;
         if (!in.read_usize("photons", "npc", ppc, ce)) return config_fail(ce);
         if (!in.read_strings("photons", "output", s->photon_output, ce)) return config_fail(ce);
@@ -591,11 +596,20 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         set_error("%d subdomains need a link", s->numtasks);
         return OPAL_ERR_ARG;
     }
-    if (linked && s->photon_emission && (s->link->nslots < 3 || s->link->nfields < 12)) {
-        set_error("photon emission across subdomains needs a link created with 3 species slots and 12 fields per "
-                  "particle (opal_link_create_layout): optical depths, ids and photons migrate too");
+    // photons and the QED state of every particle migrate too (the reference ships whole structs)
+    const bool qed = s->photon_emission || s->photon_absorption;
+    if (linked && qed && (s->link->nslots < 3 || s->link->nfields < (s->photon_absorption ? 15 : 12))) {
+        set_error("photon emission / absorption across subdomains needs a link created with 3 species slots and 12 (15 "
+                  "with absorption) fields per particle (opal_link_create_layout): optical depths, ids and photons "
+                  "migrate too");
         return OPAL_ERR_LINK;
     }
+    // absorb (main.rs:246-248), between the pushes and the emission
+    auto absorb_now = [&]() -> int {
+        if (!s->photon_absorption || !s->electrons || !s->photons) return OPAL_OK;
+        return opal_absorb(s->electrons, s->photons, s->grid, s->emission_seed, (uint32_t)s->step_index, s->t, s->dt,
+                           s->absorb_max_displacement, s->absorb_stop_time, nullptr, nullptr);
+    };
     // yee.rs:456-462: the laser is injected by rank 0 at one cell, at the pre-increment time
     auto laser_now = [&](double &ly, double &lz) {
         ly = lz = 0.0;
@@ -608,14 +622,14 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         }
     };
     for (size_t k = 0; k < n; k++) {
-        if (linked && !(s->fused && s->current_deposition && !s->photon_emission)) {
+        if (linked && !(s->fused && s->current_deposition && !qed)) {
             // The reference's operator order across subdomains (main.rs:240-267) with the leavers of every
             // species in ONE message per neighbour.  Without current deposition the halo does not depend on
             // the particles and rides along (one exchange per step); with it the halo follows the deposit in
             // a second, 704-byte exchange.
             opal_grid_t *g = s->grid;
             hipStream_t st = (hipStream_t)s->stream;
-            opal_pop_t *pops[3] = {s->electrons, s->ions, s->photon_emission ? s->photons : nullptr};
+            opal_pop_t *pops[3] = {s->electrons, s->ions, qed ? s->photons : nullptr};
             const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
             if (int rc = link_begin(s->link, st)) return rc;
             for (opal_pop_t *p : pops)
@@ -626,6 +640,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
             if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, st)) return rc;
             if (int rc = pops_unpack(pops, 3, s->link, g)) return rc;
+            if (int rc = absorb_now()) return rc;
             if (s->photon_emission && s->electrons)  // main.rs:250-252
                 if (int rc = opal_emit_radiation(s->electrons, s->photons, s->emission_seed, (uint32_t)s->step_index, s->t,
                                                  s->photon_energy_min, s->photon_angle_max, s->max_formation_length,
@@ -651,7 +666,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             s->step_index++;
             continue;
         }
-        if (linked && s->fused && s->current_deposition && !s->photon_emission) {
+        if (linked && s->fused && s->current_deposition && !qed) {
             // One exchange per step: leavers of both species and the halo travel in the same message.
             // Leavers have already deposited into this subdomain's ghost cells, which the halo overlay
             // hands to the neighbour (yee.rs:424-452), so migration need not precede deposition.
@@ -704,7 +719,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         // With photon emission on, the reference's order is advance -> emit -> deposit (main.rs:240-258) and
         // the deposit's transverse currents use the velocity after the recoil, so the fused push+deposit
         // pass does not apply: the separate operators run in the reference's order.
-        if (s->fused && s->current_deposition && !s->photon_emission) {
+        if (s->fused && s->current_deposition && !qed) {
             // clear first, then one pass per species that pushes and deposits
             if (int rc = opal_grid_clear(s->grid)) return rc;
             if (s->electrons && s->ions && !linked) {
@@ -720,7 +735,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
         } else {
             // both charged species of a lone subdomain in one launch per operator (no extras involved)
-            const bool pair = !linked && s->electrons && s->ions && !s->photon_emission && s->current_deposition;
+            const bool pair = !linked && s->electrons && s->ions && !qed && s->current_deposition;
             if (pair) {
                 if (int rc = pops_advance_pair_noexchange(s->electrons, s->ions, s->grid, s->dt)) return rc;
                 if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
@@ -729,7 +744,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 if (s->electrons) {
                     // with emission on, the electrons' re-binning waits until the emission has consumed the list of
                     // emitters their push leaves behind (a lone subdomain: Population::advance is push + policy)
-                    if (s->photon_emission && !linked) {
+                    if (qed && !linked) {
                         if (int rc = pop_push_advance_noexchange(s->electrons, nullptr, s->grid, s->dt)) return rc;
                     } else if (int rc = opal_pop_advance(s->electrons, s->link, s->grid, s->dt)) {
                         return rc;
@@ -738,10 +753,13 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 if (s->ions)
                     if (int rc = opal_pop_advance(s->ions, s->link, s->grid, s->dt)) return rc;
             }
-            if (s->photon_emission) {
+            if (qed) {
                 if (s->photons)
                     if (int rc = opal_pop_advance(s->photons, s->link, s->grid, s->dt)) return rc;  // main.rs:242-244
-                if (s->electrons) {  // main.rs:250-252
+                if (int rc = absorb_now()) return rc;
+                if (s->electrons && !s->photon_emission)
+                    if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
+                if (s->electrons && s->photon_emission) {  // main.rs:250-252
                     if (int rc = opal_emit_radiation(s->electrons, s->photons, s->emission_seed, (uint32_t)s->step_index,
                                                      s->t, s->photon_energy_min, s->photon_angle_max,
                                                      s->max_formation_length, nullptr))

@@ -59,15 +59,17 @@ class TorchLink:
     photon_emission=True lays the messages out for three species with their extras (see link.cpp).
     """
 
-    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False):
+    def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False,
+                 photon_absorption=False):
         self._lib = _lib.load()
         self.transport = NeighbourTransport(rank, world, group)
         self.device = torch.device(device)
         device_buffers = 1 if self.device.type == "cuda" else 0
         self._cb = _lib.EXCHANGE_FN(self._exchange)  # keep alive
         h = C.c_void_p()
-        # runs with photon emission move a third species and the electrons' optical depths and ids
-        slots, fields = (3, 12) if photon_emission else (2, 6)
+        # runs with photon emission move a third species and the electrons' optical depths and ids; with
+        # absorption also the photons' optical depths and birth times
+        slots, fields = (3, 15) if photon_absorption else (3, 12) if photon_emission else (2, 6)
         rc = self._lib.opal_link_create_layout(C.byref(h), rank, world, device_buffers, particle_capacity, slots, fields,
                                                self._cb, None, stream)
         if rc:
@@ -130,7 +132,7 @@ class RcclLink:
     ranks (any backend), and by the output-time collectives."""
 
     def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False,
-                 exact=False):
+                 exact=False, photon_absorption=False):
         """exact: size every message to the leavers it holds (one host synchronisation per exchange) instead of
         shipping all particle_capacity slots: for links that must have room for a large peak flux."""
         self._lib = _lib.load()
@@ -147,7 +149,7 @@ class RcclLink:
             box = [uid.raw if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
             uid = C.create_string_buffer(box[0], 128)
-        slots, fields = (3, 12) if photon_emission else (2, 6)
+        slots, fields = (3, 15) if photon_absorption else (3, 12) if photon_emission else (2, 6)
         h = C.c_void_p()
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -93,10 +93,12 @@ typedef struct {
     int flag;
 } Ion;
 
-/* photon.rs:16-32 without the polarisation / absorption members (only used by `absorb`) */
+/* photon.rs:16-32 without the polarisation members (pol, basis: never set to anything but zero by the
+ * driver, read by nothing that is called) and the pair of optical depths `tau` (drawn, never read) */
 typedef struct {
     long cell;
     double prev_x, x, y, z, weight, k[3], chi, birth_time;
+    double tau_abs, tau_st; /* optical depths against one-photon absorption / stimulated emission */
     int flag;
     unsigned long id; /* id of the parent electron (test harness) */
 } Photon;
@@ -636,6 +638,7 @@ static Photon photon_create(long cell, double x, const double *u, double weight,
     p.x = x; p.y = 0.0; p.z = 0.0; p.weight = weight;
     p.k[0] = u[0]; p.k[1] = u[1]; p.k[2] = u[2];
     p.chi = 0.0; p.birth_time = -INFINITY; p.flag = 0; p.id = 0;
+    p.tau_abs = INFINITY; p.tau_st = INFINITY; /* photon.rs:113-114 */
     return p;
 }
 
@@ -933,6 +936,29 @@ void oracle_emission_randoms(uint64_t seed, uint64_t id, uint32_t step, double *
     oracle_philox(ctr, key, r);
     out[2] = u53(r[0], r[1]); out[3] = u53(r[2], r[3]);
 }
+/* the optical depths a photon is born with (tau_abs, tau_st): counter word 3 = 2 of (seed, parent id, step) */
+void oracle_birth_randoms(uint64_t seed, uint64_t id, uint32_t step, double *out)
+{
+    uint32_t c[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 2u}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    oracle_philox(c, key, r);
+    out[0] = u53(r[0], r[1]);
+    out[1] = u53(r[2], r[3]);
+}
+/* the three uniforms a photon may need in absorb(): choice between absorption and stimulated emission, new tau_abs,
+ * new tau_st.  Keyed by the photon: parent id and birth time (an electron emits at most one photon per step). */
+void oracle_absorption_randoms(uint64_t seed, uint64_t id, double birth_time, uint32_t step, double *out)
+{
+    uint64_t bt;
+    memcpy(&bt, &birth_time, sizeof bt);
+    uint32_t key[2] = {(uint32_t)seed ^ (uint32_t)bt, (uint32_t)(seed >> 32) ^ (uint32_t)(bt >> 32)}, r[4];
+    uint32_t c[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 16u};
+    oracle_philox(c, key, r);
+    out[0] = u53(r[0], r[1]);
+    out[1] = u53(r[2], r[3]);
+    uint32_t d[4] = {(uint32_t)id, (uint32_t)(id >> 32), step, 17u};
+    oracle_philox(d, key, r);
+    out[2] = u53(r[0], r[1]);
+}
 
 /* vec3.rs:115-122 */
 static Vec3 vnormalize(Vec3 a) { return vdivs(a, sqrt(vdot(a, a))); }
@@ -1060,9 +1086,13 @@ Population *oracle_pop_new(int species, size_t npc, fn1_t number_density, fn3_t 
             } else if (species == SPECIES_ION) {
                 ((Ion *)p->store)[p->n++] = ion_create(c, xf, u, weight, dx, dt);
             } else {
-                /* photon.rs:126-133: four optical depths, used by absorption only */
-                for (int k = 0; k < 4; k++) (void)oracle_rng_exp1(rng);
-                ((Photon *)p->store)[p->n++] = photon_create(c, xf, u, weight, dx, dt);
+                /* photon.rs:126-133: four optical depths; tau[0], tau[1] are never read */
+                Photon ph = photon_create(c, xf, u, weight, dx, dt);
+                (void)oracle_rng_exp1(rng); (void)oracle_rng_exp1(rng);
+                ph.tau_abs = oracle_rng_exp1(rng);
+                ph.tau_st = oracle_rng_exp1(rng);
+                ph.id = p->n;
+                ((Photon *)p->store)[p->n++] = ph;
             }
         }
     }
@@ -1682,6 +1712,11 @@ static int electron_radiate(Electron *e, uint64_t seed, uint32_t step, double t,
     /* Photon::create(cell, x, u, weight, 0.0, 0.0): dt/dx = 0/0, so prev_x starts as NaN in the
      * reference too; it is overwritten by the first push and photons are never deposited */
     *photon = photon_create(e->cell, e->x, kk, e->weight, 0.0, 0.0);
+    /* .with_optical_depths(rng) (electron.rs:245): two more uniforms of the same keyed stream */
+    double od[2];
+    oracle_birth_randoms(seed, e->id, step, od);
+    photon->tau_abs = -log(1.0 - od[0]);
+    photon->tau_st = -log(1.0 - od[1]);
     photon->birth_time = t;
     photon->id = e->id;
     return 1;
@@ -1737,4 +1772,242 @@ void oracle_pop_get_photon_extras(const Population *p, double *chi, double *y, d
         const Photon *e = &((const Photon *)p->store)[i];
         chi[i] = e->chi; y[i] = e->y; z[i] = e->z; birth_time[i] = e->birth_time; id[i] = e->id;
     }
+}
+
+void oracle_pop_get_photon_depths(const Population *p, double *tau_abs, double *tau_st)
+{
+    for (size_t i = 0; i < p->n; i++) {
+        const Photon *e = &((const Photon *)p->store)[i];
+        tau_abs[i] = e->tau_abs; tau_st[i] = e->tau_st;
+    }
+}
+/* any of the arrays may be null */
+void oracle_pop_set_photon_state(Population *p, const double *chi, const double *tau_abs, const double *tau_st,
+                                 const double *birth_time, const uint64_t *id, const double *y, const double *z)
+{
+    if (p->species != SPECIES_PHOTON) return;
+    for (size_t i = 0; i < p->n; i++) {
+        Photon *e = &((Photon *)p->store)[i];
+        if (chi) e->chi = chi[i];
+        if (tau_abs) e->tau_abs = tau_abs[i];
+        if (tau_st) e->tau_st = tau_st[i];
+        if (birth_time) e->birth_time = birth_time[i];
+        if (id) e->id = id[i];
+        if (y) e->y = y[i];
+        if (z) e->z = z[i];
+    }
+}
+void oracle_pop_set_electron_chi(Population *p, const double *chi)
+{
+    if (p->species != SPECIES_ELECTRON) return;
+    for (size_t i = 0; i < p->n; i++) ((Electron *)p->store)[i].chi = chi[i];
+}
+/* test harness: put the particles in the order given by `order` (new slot i takes old slot order[i]) */
+void oracle_pop_permute(Population *p, const size_t *order)
+{
+    size_t sz = psize(p->species);
+    char *out = (char *)malloc((p->n ? p->n : 1) * sz);
+    for (size_t i = 0; i < p->n; i++) memcpy(out + i * sz, (char *)p->store + order[i] * sz, sz);
+    free(p->store);
+    p->store = out;
+    p->cap = p->n ? p->n : 1;
+}
+
+/* ------------------------------------------------- photon absorption, stimulated emission
+ * Ai(x) for real x >= 0, qed/special_functions/airy.rs:19-69; returns 0 for None (x < 0 or x >= 50). */
+#define AIRY_TABLE_QUAL const
+#include "airy_tables.inc"
+
+/* llvm.powi: square-and-multiply, as compiler-rt's __powidf2 */
+static double powi_f64(double a, int b)
+{
+    double r = 1.0;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return r;
+}
+
+static double airy_quadrature(double x, const double *nodes, const double *weights, int n)
+{
+    double s = 2.0 * pow(x, 1.5) / 3.0;
+    double a = AIRY_SCALE * pow(s, -1.0 / 6.0) * exp(-s);
+    double integral = 0.0;
+    for (int i = 0; i < n; i++) integral += weights[i] * pow(2.0 + nodes[i] / s, -1.0 / 6.0);
+    return a * integral;
+}
+
+int oracle_airy_ai(double x, double *out)
+{
+    if (x < 0.0) return 0;
+    if (x < 1.0) {
+        double sum = 0.0;
+        for (int i = 0; i < AIRY_SERIES_USED; i++) sum += AIRY_SERIES_A[i] * powi_f64(x, AIRY_SERIES_N[i]);
+        *out = sum;
+    } else if (x < 2.0) *out = airy_quadrature(x, AIRY_GL40_X, AIRY_GL40_W, 40);
+    else if (x < 10.0) *out = airy_quadrature(x, AIRY_GL16_X, AIRY_GL16_W, 16);
+    else if (x < 50.0) *out = airy_quadrature(x, AIRY_GL4_X, AIRY_GL4_W, 4);
+    else return 0;
+    return 1;
+}
+
+#define CLASSICAL_ELECTRON_RADIUS 2.817940e-15 /* constants.rs:28 */
+
+/* qed/photon_absorption.rs:16-34 (stimulated = 0) and qed/stimulated_emission.rs:16-37 (stimulated = 1): the two
+ * differ only in chi_e +- chi_gamma and in the kinematic cut of the latter.  Returns 0 for None. */
+static int scaled_cross_section(const double *k, const double *p, double chi_gamma, double chi_e, int stimulated, double *out)
+{
+    if (stimulated) {
+        if (chi_gamma >= chi_e || k[0] >= p[0] || chi_e <= 0.0 || chi_gamma <= 0.0) return 0;
+    } else if (chi_e <= 0.0 || chi_gamma <= 0.0) {
+        return 0;
+    }
+    double denom = stimulated ? chi_e * (chi_e - chi_gamma) : chi_e * (chi_e + chi_gamma);
+    double g = 0.5 + 0.25 * (chi_gamma * chi_gamma) / denom;
+    double z = pow(chi_gamma / denom, 2.0 / 3.0);
+    double k_p = k[0] * p[0] - k[1] * p[1] - k[2] * p[2] - k[3] * p[3];
+    double zbar = 2.0 * z * chi_e * k_p / chi_gamma;
+    double zbar_z = 2.0 * p[0] * k_p / k[0];
+    double ai;
+    if (!oracle_airy_ai(zbar, &ai)) return 0;
+    double pre = 2.0 * PI * CLASSICAL_ELECTRON_RADIUS;
+    *out = (pre * pre) * chi_e * z * (4.0 * g * zbar_z - 1.0) * ai / (ALPHA_FINE * chi_gamma * k[0] * p[0]);
+    return 1;
+}
+int oracle_absorption_cross_section(const double *k, const double *p, double chi_gamma, double chi_e, double *out)
+{
+    return scaled_cross_section(k, p, chi_gamma, chi_e, 0, out);
+}
+int oracle_stimulated_cross_section(const double *k, const double *p, double chi_gamma, double chi_e, double *out)
+{
+    return scaled_cross_section(k, p, chi_gamma, chi_e, 1, out);
+}
+
+enum { INTERACTION_NONE = 0, INTERACTION_ABSORBED = 1, INTERACTION_STIMULATED = 2 };
+
+/* Photon::interacts_with, photon.rs:312-362.  rnd = the photon's three uniforms of this step (choice, new tau_abs,
+ * new tau_st); returns -1 where the reference's assert!(partial_prob >= 0) fires. */
+static int photon_interacts_with(Photon *ph, const Electron *e, double dt, double dx, const double *rnd)
+{
+    double k0 = sqrt(ph->k[0] * ph->k[0] + ph->k[1] * ph->k[1] + ph->k[2] * ph->k[2]);
+    double k[4] = {k0, ph->k[0], ph->k[1], ph->k[2]};
+    double p[4] = {e->gamma, e->u[0], e->u[1], e->u[2]};
+    double prob_abs = 0.0, prob_st = 0.0, sigma;
+    if (scaled_cross_section(k, p, ph->chi, e->chi, 0, &sigma)) {
+        double partial = e->weight * (SPEED_OF_LIGHT * dt / dx) * sigma;
+        if (!(partial >= 0.0)) return -1;
+        ph->tau_abs -= partial;
+        prob_abs = partial;
+    }
+    if (scaled_cross_section(k, p, ph->chi, e->chi, 1, &sigma)) {
+        double partial = e->weight * (SPEED_OF_LIGHT * dt / dx) * sigma;
+        if (!(partial >= 0.0)) return -1;
+        ph->tau_st -= partial;
+        prob_st = partial;
+    }
+    if (ph->tau_abs < 0.0 && ph->tau_st < 0.0) {
+        if (rnd[0] < prob_abs / (prob_abs + prob_st)) return INTERACTION_ABSORBED;
+        ph->tau_abs = -log(1.0 - rnd[1]);
+        ph->tau_st = -log(1.0 - rnd[2]);
+        return INTERACTION_STIMULATED;
+    } else if (ph->tau_abs < 0.0) {
+        return INTERACTION_ABSORBED;
+    } else if (ph->tau_st < 0.0) {
+        ph->tau_st = -log(1.0 - rnd[2]);
+        return INTERACTION_STIMULATED;
+    }
+    return INTERACTION_NONE;
+}
+
+/* absorb, interactions.rs:145-340, for one subdomain.  The electrons must be sorted by cell (they are after
+ * Population::advance); each photon meets the electrons of its cell in slot order and stops at the first
+ * event.  max_displacement / stop_time < 0 mean None.  Photons absorbed are removed (the survivors keep their
+ * order: the reference's swap_remove permutes them, and the next push sorts them anyway); photons whose emission
+ * was stimulated are appended behind, in photon order, with the emitting electron's weight and id, fresh
+ * optical depths and birth time t.  counts[0] = absorbed, counts[1] = stimulated.  Returns the number of
+ * reference asserts tripped. */
+size_t oracle_absorb(Population *e, Population *ph, uint64_t seed, uint32_t step, double t, double dt, double dx,
+                     double max_displacement, double stop_time, size_t *counts)
+{
+    const double PHOTON_E_ECRIT_CUTOFF = 1.0e-8;
+    counts[0] = counts[1] = 0;
+    if (e->n == 0 || ph->n == 0) return 0;
+    Electron *es = (Electron *)e->store;
+    Photon *ps = (Photon *)ph->store;
+    size_t nph = ph->n, bad = 0;
+    typedef struct { size_t electron; Photon photon; } Event;
+    Event *absorbed = (Event *)malloc(nph * sizeof(Event)), *emitted = (Event *)malloc(nph * sizeof(Event));
+    size_t na = 0, ne = 0;
+    for (size_t i = 0; i < nph; i++) {
+        Photon *photon = &ps[i];
+        double energy = sqrt(photon->k[0] * photon->k[0] + photon->k[1] * photon->k[1] + photon->k[2] * photon->k[2]) * ELECTRON_MASS_MEV;
+        if (photon->chi * ELECTRON_MASS_MEV / energy < PHOTON_E_ECRIT_CUTOFF) continue;
+        if (stop_time >= 0.0 && t - photon->birth_time > stop_time) continue;
+        if (max_displacement >= 0.0 && hypot(photon->y, photon->z) > max_displacement) continue;
+        long cell = photon->cell;
+        /* electrons of the same cell: [start, end) by bisection of the sorted cell indices */
+        size_t lo = 0, hi = e->n;
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (es[mid].cell < cell) lo = mid + 1; else hi = mid; }
+        size_t start = lo;
+        hi = e->n;
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (es[mid].cell <= cell) lo = mid + 1; else hi = mid; }
+        size_t end = lo;
+        if (start == end) continue;
+        double rnd[3];
+        oracle_absorption_randoms(seed, photon->id, photon->birth_time, step, rnd);
+        for (size_t j = start; j < end; j++) {
+            int state = photon_interacts_with(photon, &es[j], dt, dx, rnd);
+            if (state < 0) { bad++; break; }
+            if (state == INTERACTION_ABSORBED) {
+                photon->flag = 1;
+                absorbed[na].electron = j; absorbed[na].photon = *photon; na++;
+                break;
+            } else if (state == INTERACTION_STIMULATED) {
+                emitted[ne].electron = j; emitted[ne].photon = *photon; emitted[ne].photon.weight = es[j].weight; ne++;
+                break;
+            }
+        }
+    }
+    if (na) {
+        size_t o = 0;
+        for (size_t i = 0; i < nph; i++)
+            if (!ps[i].flag) ps[o++] = ps[i];
+        ph->n = o;
+    }
+    if (ne) {
+        pop_reserve(ph, ph->n + ne);
+        ps = (Photon *)ph->store;
+        for (size_t q = 0; q < ne; q++) {
+            Photon np = emitted[q].photon;
+            double od[2];
+            oracle_birth_randoms(seed, es[emitted[q].electron].id, step, od);  /* .with_optical_depths(rng).at_time(t) */
+            np.tau_abs = -log(1.0 - od[0]);
+            np.tau_st = -log(1.0 - od[1]);
+            np.birth_time = t;
+            np.id = es[emitted[q].electron].id;
+            np.flag = 0;
+            ps[ph->n++] = np;
+        }
+    }
+    /* Electron::kick, electron.rs:256-262: p -> p + r k, k in MeV, r = photon weight / electron weight */
+    for (size_t q = 0; q < na; q++) {
+        Electron *pt = &es[absorbed[q].electron];
+        const Photon *pp = &absorbed[q].photon;
+        double scale = pp->weight / pt->weight;
+        for (int c = 0; c < 3; c++) pt->u[c] += scale * (pp->k[c] * ELECTRON_MASS_MEV) / ELECTRON_MASS_MEV;
+        pt->gamma = sqrt(1.0 + (pt->u[0] * pt->u[0] + pt->u[1] * pt->u[1] + pt->u[2] * pt->u[2]));
+    }
+    for (size_t q = 0; q < ne; q++) {
+        Electron *pt = &es[emitted[q].electron];
+        const Photon *pp = &emitted[q].photon;
+        double scale = pt->weight / pt->weight;
+        for (int c = 0; c < 3; c++) pt->u[c] += scale * (-(pp->k[c] * ELECTRON_MASS_MEV)) / ELECTRON_MASS_MEV;
+        pt->gamma = sqrt(1.0 + (pt->u[0] * pt->u[0] + pt->u[1] * pt->u[1] + pt->u[2] * pt->u[2]));
+    }
+    counts[0] = na; counts[1] = ne;
+    free(absorbed); free(emitted);
+    return bad;
 }

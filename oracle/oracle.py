@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libopal_oracle.so")
 
 BDY_INTERNAL, BDY_LASER, BDY_ABSORBING, BDY_CONDUCTING = 0, 1, 2, 3
-ELECTRON, ION = 0, 1
+ELECTRON, ION, PHOTON = 0, 1, 2
 
 # src/constants.rs:4-27
 SPEED_OF_LIGHT = 2.997925e8
@@ -145,6 +145,16 @@ def lib():
             "oracle_pop_set_electron_state": (None, [vp, vp, vp]),
             "oracle_pop_get_electron_ids": (None, [vp, vp]),
             "oracle_pop_get_photon_extras": (None, [vp] + [vp] * 5),
+            "oracle_pop_get_photon_depths": (None, [vp, vp, vp]),
+            "oracle_pop_set_photon_state": (None, [vp] + [vp] * 7),
+            "oracle_pop_set_electron_chi": (None, [vp, vp]),
+            "oracle_pop_permute": (None, [vp, vp]),
+            "oracle_airy_ai": (C.c_int, [C.c_double, dp]),
+            "oracle_absorption_cross_section": (C.c_int, [vp, vp, C.c_double, C.c_double, dp]),
+            "oracle_stimulated_cross_section": (C.c_int, [vp, vp, C.c_double, C.c_double, dp]),
+            "oracle_birth_randoms": (None, [C.c_uint64, C.c_uint64, C.c_uint32, vp]),
+            "oracle_absorption_randoms": (None, [C.c_uint64, C.c_uint64, C.c_double, C.c_uint32, vp]),
+            "oracle_absorb": (C.c_size_t, [vp, vp, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
             "oracle_histogram": (C.c_size_t, [vp, vp, C.c_int, vp, C.c_int, C.c_size_t, C.c_double, C.c_int, vp, C.c_size_t, vp, vp]),
         }
         for name, (res, args) in sig.items():
@@ -422,6 +432,28 @@ class Population:
         out["id"] = ids
         return out
 
+    def photon_depths(self):
+        n = len(self)
+        a, b = np.empty(n), np.empty(n)
+        lib().oracle_pop_get_photon_depths(self.h, _ptr(a), _ptr(b))
+        return a, b
+
+    def set_photon_state(self, chi=None, tau_abs=None, tau_st=None, birth_time=None, ids=None, y=None, z=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        arrs = [f(chi), f(tau_abs), f(tau_st), f(birth_time), None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64), f(y), f(z)]
+        self._keep = arrs
+        lib().oracle_pop_set_photon_state(self.h, *[None if a is None else _ptr(a) for a in arrs])
+
+    def set_electron_chi(self, chi):
+        chi = np.ascontiguousarray(chi, dtype=np.float64)
+        lib().oracle_pop_set_electron_chi(self.h, _ptr(chi))
+
+    def permute(self, order):
+        """New slot i takes the particle that was in slot order[i]."""
+        order = np.ascontiguousarray(order, dtype=np.uint64)
+        assert len(order) == len(self)
+        lib().oracle_pop_permute(self.h, _ptr(order))
+
     def total_kinetic_energy(self):
         return lib().oracle_pop_total_kinetic_energy(self.h)
 
@@ -494,6 +526,45 @@ def emit_radiation(electrons, photons, seed, step, t, min_energy=None, max_angle
     if n < 0:
         raise NotImplementedError("chi >= 100 (photon_emission.rs:146 unimplemented!())")
     return n
+
+
+def airy_ai(x):
+    """airy_ai_for_positive (qed/special_functions/airy.rs:19-69); None where the reference returns None."""
+    out = C.c_double()
+    return out.value if lib().oracle_airy_ai(float(x), C.byref(out)) else None
+
+
+def cross_sections(k, p, chi_gamma, chi_e):
+    """(absorption, stimulated emission) scaled cross sections (photon_absorption.rs:16-34,
+    stimulated_emission.rs:16-37); None where the reference returns None."""
+    k = np.ascontiguousarray(k, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    a, b = C.c_double(), C.c_double()
+    ra = lib().oracle_absorption_cross_section(_ptr(k), _ptr(p), chi_gamma, chi_e, C.byref(a))
+    rb = lib().oracle_stimulated_cross_section(_ptr(k), _ptr(p), chi_gamma, chi_e, C.byref(b))
+    return (a.value if ra else None), (b.value if rb else None)
+
+
+def birth_randoms(seed, pid, step):
+    out = np.empty(2)
+    lib().oracle_birth_randoms(seed, pid, step, _ptr(out))
+    return out
+
+
+def absorption_randoms(seed, pid, birth_time, step):
+    out = np.empty(3)
+    lib().oracle_absorption_randoms(seed, pid, birth_time, step, _ptr(out))
+    return out
+
+
+def absorb(electrons, photons, seed, step, t, dt, dx, max_displacement=None, stop_time=None):
+    """absorb (interactions.rs:145-340) for one subdomain; returns (absorbed, stimulated)."""
+    f = lambda v: -1.0 if v is None else float(v)
+    counts = np.zeros(2, dtype=np.uint64)
+    bad = lib().oracle_absorb(electrons.h, photons.h, seed, step, t, dt, dx, f(max_displacement), f(stop_time), _ptr(counts))
+    if bad:
+        raise AssertionError("the reference's assert!(partial_prob >= 0.0) fires (photon.rs:325,336)")
+    return int(counts[0]), int(counts[1])
 
 
 ACCESSORS = {"x": 0, "r": 1, "energy": 2, "px": 3, "py": 4, "pz": 5, "p_perp": 6, "theta": 7, "phi": 8,
