@@ -383,9 +383,10 @@ def main():
         nonlocal link_kind
         if link_kind == "rccl":
             try:
-                if os.environ.get("OPAL_BENCH_EXACT"):  # diagnostic: big buffers, messages sized to their content
-                    return RcclLink(r, w, device, particle_capacity=1 << 18, exact=True)
-                return RcclLink(r, w, device, particle_capacity=link_capacity)
+                lk = RcclLink(r, w, device, particle_capacity=link_capacity)
+                if os.environ.get("OPAL_BENCH_FIXED"):  # diagnostic: ship all slots every step
+                    lk.set_bounded(False)
+                return lk
             except Exception as e:  # e.g. no librccl to open: the torch.distributed transport does the same job
                 print(f"[bench] native RCCL link unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
                 link_kind = "torch"

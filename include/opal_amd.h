@@ -286,13 +286,22 @@ int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle
 /* Ranks of the RCCL communicator behind a link made by opal_link_create_rccl (ncclCommCount): lets a caller
  * report that the subdomains really are joined by one RCCL communicator. */
 int opal_link_rccl_ranks(const opal_link_t *l, int *out);
-/* on != 0: whole-message exchanges ship the 704-byte head first and then only the occupied part of every
- * column (one host synchronisation per exchange) instead of all `particle_capacity` slots: for links sized
- * for a large peak flux.  Off by default. */
-int opal_link_set_exact(opal_link_t *l, int on);
+/* Per-edge sizes.  A message's body is laid out so that the leavers it carries sit in a prefix (link.cpp), and
+ * every push counts the particles within 3 cells of each edge into the message header; from those counts --
+ * which both ends of an edge hold, three exchanges later, without any extra traffic or host synchronisation --
+ * the library sizes each edge's messages to what can physically cross it.  That needs a transport that takes
+ * one size per edge: the left edge (send_left and recv_left) moves nbytes_left, the right edge nbytes_right.
+ * Links made by opal_link_create_rccl have one; a callback transport opts in here.  Without it every
+ * whole-message exchange ships all `particle_capacity` slots, as the plain opal_exchange_fn implies. */
+typedef int (*opal_exchange2_fn)(void *user, const void *send_left, const void *send_right, void *recv_left,
+                                 void *recv_right, size_t nbytes_left, size_t nbytes_right);
+int opal_link_set_exchange2(opal_link_t *l, opal_exchange2_fn exchange2);
+/* on = 0: ship all slots every time even though the transport could take sizes (diagnostic; default on) */
+int opal_link_set_bounded(opal_link_t *l, int on);
+/* bytes the last whole-message exchange moved over the left / right edge (0 where there is no neighbour) */
+int opal_link_last_exchange_bytes(const opal_link_t *l, size_t *left, size_t *right);
 int opal_link_free(opal_link_t *l);
-/* bytes per direction of a whole message (halo + both species' leavers) and of its halo-only prefix;
- * the `nbytes` passed to the exchange callback is always one of the two */
+/* bytes per direction of a message with every slot in use (what the buffers hold) and of its halo-only prefix */
 size_t opal_link_message_bytes(const opal_link_t *l);
 size_t opal_link_halo_bytes(const opal_link_t *l);
 size_t opal_link_particle_capacity(const opal_link_t *l);

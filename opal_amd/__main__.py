@@ -32,15 +32,13 @@ def main(argv):
                                 **({"device_id": device} if backend == "nccl" else {}))
         cfg = oa.Config(path=argv[1])
         emission, absorption = cfg.read_bool("qed", "photon_emission"), cfg.read_bool("qed", "photon_absorption")
-        # room for the leavers of one step through one cut, per species (an overflow is reported as an error).
-        # Messages normally have a fixed size -- all slots travel every step; OPAL_LINK_EXACT=1 sizes them to
-        # their content instead (two RCCL groups and a host synchronisation per step, ~+13 % on a 0.35 ms step:
-        # worth it for links that need a very large capacity, e.g. a dense beam crossing the cuts)
+        # room in the buffers for the leavers of one step through one cut, per species (an overflow is reported as an
+        # error); what travels each step is sized to the particles within 3 cells of each cut, not to this
         cap = int(os.environ.get("OPAL_LINK_CAPACITY", "65536"))
         stream = torch.cuda.current_stream().cuda_stream
         if backend == "nccl" and os.environ.get("OPAL_LINK", "rccl") == "rccl":
-            link = RcclLink(rank, world, device, cap, photon_emission=emission, photon_absorption=absorption, stream=stream,
-                            exact=os.environ.get("OPAL_LINK_EXACT", "0") == "1")  # native RCCL send/recv
+            link = RcclLink(rank, world, device, cap, photon_emission=emission, photon_absorption=absorption,
+                            stream=stream)  # native RCCL send/recv
         else:
             link = TorchLink(rank, world, device if backend == "nccl" else torch.device("cpu"), cap,
                              photon_emission=emission, photon_absorption=absorption, stream=stream)

@@ -13,6 +13,7 @@ FN1 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
 FN2 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_void_p)
 FN3 = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+EXCHANGE2_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.c_int)
 GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double),
                         C.POINTER(C.c_size_t), C.c_int)
@@ -98,7 +99,9 @@ SIGNATURES = {
     "opal_hist_filename": (C.c_int, [C.c_char_p, sz, C.c_char_p, C.c_char_p, C.c_char_p, sz]),
     "opal_pop_write_data": (C.c_int, [vp, vp, C.c_char_p, sz, C.c_char_p, C.POINTER(C.c_char_p), sz]),
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),
-    "opal_link_set_exact": (C.c_int, [vp, C.c_int]),
+    "opal_link_set_exchange2": (C.c_int, [vp, EXCHANGE2_FN]),
+    "opal_link_set_bounded": (C.c_int, [vp, C.c_int]),
+    "opal_link_last_exchange_bytes": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz)]),
     "opal_link_rccl_ranks": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "opal_rccl_unique_id": (C.c_int, [C.c_char_p, vp]),
     "opal_link_create_rccl": (C.c_int, [pp, C.c_int, C.c_int, sz, C.c_int, C.c_int, C.c_char_p, vp, vp]),

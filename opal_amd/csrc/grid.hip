@@ -310,8 +310,7 @@ int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const d
     double *sr = reinterpret_cast<double *>(link_send(link, 1) + LINK_HEADER_BYTES);
     if (int rc = grid_pack_halo(g, sl, sr, st)) return rc;
     if (exchange) {
-        if (int rc = link_exchange(link, LINK_HEAD_BYTES, g->left_bdy == OPAL_BDY_INTERNAL,
-                                   g->right_bdy == OPAL_BDY_INTERNAL, st))
+        if (int rc = link_exchange_halo(link, g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL, st))
             return rc;
     }
     *recv_left = reinterpret_cast<const double *>(link_recv(link, 0) + LINK_HEADER_BYTES);

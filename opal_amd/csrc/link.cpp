@@ -1,22 +1,31 @@
 // Neighbour exchange between subdomains (stands in for the reference's MPI
 // point-to-point traffic: yee.rs:351-409 for the halo, particle/mod.rs:303-354
-// for migrating particles).  The library packs one fixed-layout message per
-// direction; the transport (RCCL, gloo, ...) is the callback the host supplied.
+// for migrating particles).  The library packs one message per direction; the
+// transport (RCCL, gloo, ...) is the callback the host supplied.
 //
-// Message layout (bytes), P = particle_capacity of the link:
-//   [0, 64)            header: uint32 count[S] (species slot 0 = electrons, 1 = ions, 2 = photons), padding
+// Message layout (bytes):
+//   [0, 64)            header (uint32 words): [0, 3) leavers per species slot (0 electrons, 1 ions, 2 photons);
+//                      [4, 7) particles per species within LINK_ZONE cells of the edge this message crosses,
+//                      counted by the push that packed it
 //   [64, 704)          halo: 8 cells x (rho jx jy jz Ex Ey Ez Bx By Bz) doubles  (yee.rs:353-354)
-//   then per species slot s = 0 .. S-1 (each block 8-byte aligned):
-//       int32  cell[P]            re-based cell index in the receiver's frame (mod.rs:291-293, 366-368)
-//       double x[P] ux[P] uy[P] uz[P] w[P] prev_x[P]
-//       double chi[P] work[P] y[P] z[P] tau[P] id[P]     only when the link was created with 12 fields
-//       double tau_abs[P] tau_st[P] birth[P]              only with 15 fields (photon absorption)
-// S = 2 and 6 fields by default; runs with photon emission use S = 3 and 12 fields (the reference ships
-// whole structs, so optical depths and ids must travel with an electron that changes subdomain).
-// A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes; anything with particles moves
-// the whole message -- all P slots of every column, because the receiver cannot know the counts before they
-// arrive -- unless the transport offers an exact-size exchange (rccl_link.cpp: head first, then only the
-// occupied part of every column, at the price of one host synchronisation per exchange).
+//   then row blocks of 64 particles, ordered (block b, species slot s) b-major:
+//       int32  cell[64]           re-based cell index in the receiver's frame (mod.rs:291-293, 366-368)
+//       double x[64] ux[64] uy[64] uz[64] w[64] prev_x[64]
+//       double chi[64] work[64] y[64] z[64] tau[64] id[64]      links created with >= 12 fields
+//       double tau_abs[64] tau_st[64] birth[64]                 links created with 15 fields (photon absorption)
+// so that the first m blocks of every species are a PREFIX of the message: an exchange ships
+// 704 + m S blk bytes per edge, m chosen per edge and step.
+//
+// How m follows the particles without the host waiting for the device.  A particle moves less than a cell per
+// step, so the leavers of step k through an edge are among the particles that stood within LINK_ZONE cells of
+// it after step k - LINK_ZONE.  Every push counts those into its message's header; the counts travel with the
+// message, and the unpack kernel copies both ends' counts of every exchange into mapped host memory.  When
+// exchange X is planned the host reads what exchanges X - LINK_ZONE - 2 .. X - LINK_ZONE left there (long since
+// written: the host merely cannot run more than LINK_ZONE exchanges ahead of the device) and sizes each edge to
+// the larger of the two ends' bounds plus LINK_SLACK.  Both ends of an edge hold the same numbers, so they agree
+// on the size without talking; a front that reaches a cut is seen LINK_ZONE cells before it arrives.  Transports
+// that cannot take a size per edge (opal_exchange_fn) keep shipping all `particle_capacity` slots.
+// A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes.
 // What a subdomain sends left arrives as its left neighbour's "recv_right".
 #include <hip/hip_runtime_api.h>
 
@@ -28,10 +37,13 @@ using namespace opal;
 
 namespace opal {
 
-size_t link_species_offset(const opal_link_t *l, int slot) { return LINK_HEAD_BYTES + (size_t)slot * l->species_bytes; }
-
 char *link_send(opal_link_t *l, int side) { return side == 0 ? l->d_send_left : l->d_send_right; }
 char *link_recv(opal_link_t *l, int side) { return side == 0 ? l->d_recv_left : l->d_recv_right; }
+
+size_t link_prefix_bytes(const opal_link_t *l, unsigned slots)
+{
+    return LINK_HEAD_BYTES + (size_t)(slots / LINK_ROWS) * l->layout.nslots * l->layout.blk;
+}
 
 // Leaver counts of the send messages start a step at zero.  The kernel that unpacks a step's arrivals also
 // re-zeroes them (they have been shipped by then) and marks the link clean, so only the first step -- or one
@@ -43,10 +55,41 @@ int link_begin(opal_link_t *l, hipStream_t st)
         OPAL_HIP(hipMemsetAsync(l->d_send_right, 0, LINK_HEADER_BYTES, st));
     }
     l->counts_clean = false;  // a push is about to count leavers into them
+    return link_plan(l);
+}
+
+int link_plan(opal_link_t *l)
+{
+    const unsigned full = (unsigned)l->cap;
+    l->send_cap[0] = l->send_cap[1] = full;
+    if (!l->bounded || !l->exchange2 || !l->h_bounds || l->xseq < (unsigned)LINK_ZONE) return OPAL_OK;
+    const unsigned newest = l->xseq - LINK_ZONE;  // exchange whose bounds cover the one being planned
+    unsigned need[2] = {0, 0};
+    for (unsigned back = 0; back < 3 && back <= newest; back++) {
+        const unsigned e = newest - back;
+        const LinkBounds *b = &l->h_bounds[e % LINK_RING];
+        // written by the unpack kernel of exchange e, at least LINK_ZONE exchanges ago: normally there already
+        while (b->seq != e + 1) {
+            hipError_t q = hipStreamQuery(l->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) OPAL_HIP(q);
+            if (q == hipSuccess && b->seq != e + 1) {
+                // the stream has drained and the entry is not there: that exchange was not followed by an unpack
+                return OPAL_OK;  // fall back to the full size (both ends reach this verdict together)
+            }
+        }
+        for (int side = 0; side < 2; side++)
+            for (int sp = 0; sp < 3; sp++) {
+                need[side] = need[side] > b->mine[side][sp] ? need[side] : b->mine[side][sp];
+                need[side] = need[side] > b->theirs[side][sp] ? need[side] : b->theirs[side][sp];
+            }
+    }
+    for (int side = 0; side < 2; side++) {
+        unsigned slots = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+        l->send_cap[side] = slots < full ? slots : full;
+    }
     return OPAL_OK;
 }
 
-// Moves `nbytes` of each send buffer to the neighbours and fills the recv buffers.
 // whether exchanges may be issued on `st` rather than on the stream the link was created with: host-staged
 // transports are synchronous (the library brackets them with copies on `st`), native ones follow set_stream
 bool link_can_use_stream(const opal_link_t *l, hipStream_t st)
@@ -54,37 +97,57 @@ bool link_can_use_stream(const opal_link_t *l, hipStream_t st)
     return st == l->stream || !l->device_buffers || l->set_stream;
 }
 
-int link_exchange(opal_link_t *l, size_t nbytes, bool to_left, bool to_right, hipStream_t st)
+// moves the first n_left / n_right bytes of the send buffers to the neighbours and fills the recv buffers
+static int link_move(opal_link_t *l, size_t n_left, size_t n_right, bool to_left, bool to_right, hipStream_t st)
 {
     if (l->set_stream) l->set_stream(l->user, st);
-    if (nbytes > l->nbytes) {
-        set_error("link_exchange: %zu bytes exceed the link's message size %zu", nbytes, l->nbytes);
+    if (n_left > l->nbytes || n_right > l->nbytes) {
+        set_error("link exchange: %zu / %zu bytes exceed the link's message size %zu", n_left, n_right, l->nbytes);
         return OPAL_ERR_ARG;
     }
-    if (l->exchange_exact && nbytes == l->nbytes) {
-        if (l->exchange_exact(l, to_left, to_right, st)) return OPAL_ERR_LINK;  // the callee has set the error text
-        return OPAL_OK;
-    }
     if (!l->device_buffers) {
-        if (to_left) OPAL_HIP(hipMemcpyAsync(l->h_send_left, l->d_send_left, nbytes, hipMemcpyDeviceToHost, st));
-        if (to_right) OPAL_HIP(hipMemcpyAsync(l->h_send_right, l->d_send_right, nbytes, hipMemcpyDeviceToHost, st));
+        if (to_left) OPAL_HIP(hipMemcpyAsync(l->h_send_left, l->d_send_left, n_left, hipMemcpyDeviceToHost, st));
+        if (to_right) OPAL_HIP(hipMemcpyAsync(l->h_send_right, l->d_send_right, n_right, hipMemcpyDeviceToHost, st));
         OPAL_HIP(hipStreamSynchronize(st));
     }
     char *sl = l->device_buffers ? l->d_send_left : l->h_send_left;
     char *sr = l->device_buffers ? l->d_send_right : l->h_send_right;
     char *rl = l->device_buffers ? l->d_recv_left : l->h_recv_left;
     char *rr = l->device_buffers ? l->d_recv_right : l->h_recv_right;
-    int rc = l->exchange(l->user, to_left ? sl : nullptr, to_right ? sr : nullptr, to_left ? rl : nullptr,
-                         to_right ? rr : nullptr, nbytes);
+    int rc;
+    if (l->exchange2)
+        rc = l->exchange2(l->user, to_left ? sl : nullptr, to_right ? sr : nullptr, to_left ? rl : nullptr,
+                          to_right ? rr : nullptr, n_left, n_right);
+    else
+        rc = l->exchange(l->user, to_left ? sl : nullptr, to_right ? sr : nullptr, to_left ? rl : nullptr,
+                         to_right ? rr : nullptr, n_left > n_right ? n_left : n_right);
     if (rc) {
         set_error("exchange callback failed with %d", rc);
         return OPAL_ERR_LINK;
     }
     if (!l->device_buffers) {
-        if (to_left) OPAL_HIP(hipMemcpyAsync(l->d_recv_left, l->h_recv_left, nbytes, hipMemcpyHostToDevice, st));
-        if (to_right) OPAL_HIP(hipMemcpyAsync(l->d_recv_right, l->h_recv_right, nbytes, hipMemcpyHostToDevice, st));
+        if (to_left) OPAL_HIP(hipMemcpyAsync(l->d_recv_left, l->h_recv_left, n_left, hipMemcpyHostToDevice, st));
+        if (to_right) OPAL_HIP(hipMemcpyAsync(l->d_recv_right, l->h_recv_right, n_right, hipMemcpyHostToDevice, st));
     }
     return OPAL_OK;
+}
+
+int link_exchange_halo(opal_link_t *l, bool to_left, bool to_right, hipStream_t st)
+{
+    return link_move(l, LINK_HEAD_BYTES, LINK_HEAD_BYTES, to_left, to_right, st);
+}
+
+int link_exchange_particles(opal_link_t *l, bool to_left, bool to_right, hipStream_t st)
+{
+    // without a per-edge transport both edges (and every subdomain) must use one size: the full one
+    const bool per_edge = l->exchange2 != nullptr;
+    const size_t n_left = per_edge ? link_prefix_bytes(l, l->send_cap[0]) : l->nbytes;
+    const size_t n_right = per_edge ? link_prefix_bytes(l, l->send_cap[1]) : l->nbytes;
+    l->last_bytes[0] = to_left ? n_left : 0;
+    l->last_bytes[1] = to_right ? n_right : 0;
+    int rc = link_move(l, n_left, n_right, to_left, to_right, st);
+    l->xseq++;
+    return rc;
 }
 
 }  // namespace opal
@@ -119,8 +182,14 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
     l->stream = (hipStream_t)hip_stream;
     l->nslots = species_slots;
     l->nfields = fields_per_particle;
-    l->species_bytes = particle_capacity * (sizeof(int32_t) + (size_t)fields_per_particle * sizeof(double));
-    l->nbytes = LINK_HEAD_BYTES + (size_t)species_slots * l->species_bytes;
+    l->layout.nslots = (unsigned)species_slots;
+    l->layout.blk = LINK_ROWS * (unsigned)(sizeof(int32_t) + (size_t)fields_per_particle * sizeof(double));
+    l->nbytes = link_prefix_bytes(l, (unsigned)particle_capacity);
+    l->send_cap[0] = l->send_cap[1] = (unsigned)particle_capacity;
+    l->bounded = true;  // takes effect once a per-edge transport is set (opal_link_set_exchange2, native links)
+    OPAL_HIP(hipHostMalloc((void **)&l->h_bounds, sizeof(LinkBounds) * LINK_RING, hipHostMallocMapped));
+    memset((void *)l->h_bounds, 0, sizeof(LinkBounds) * LINK_RING);
+    OPAL_HIP(hipHostGetDevicePointer((void **)&l->d_bounds, (void *)l->h_bounds, 0));
     char **dev[4] = {&l->d_send_left, &l->d_send_right, &l->d_recv_left, &l->d_recv_right};
     for (auto d : dev) {
         OPAL_HIP(hipMalloc((void **)d, l->nbytes));
@@ -147,7 +216,39 @@ int opal_link_free(opal_link_t *l)
     if (!l->device_buffers && !l->external) {
         hipHostFree(l->h_send_left); hipHostFree(l->h_send_right); hipHostFree(l->h_recv_left); hipHostFree(l->h_recv_right);
     }
+    if (l->h_bounds) hipHostFree((void *)l->h_bounds);
     delete l;
+    return OPAL_OK;
+}
+
+int opal_link_set_exchange2(opal_link_t *l, opal_exchange2_fn exchange2)
+{
+    if (!l) {
+        set_error("opal_link_set_exchange2: null link");
+        return OPAL_ERR_ARG;
+    }
+    l->exchange2 = exchange2;
+    return OPAL_OK;
+}
+
+int opal_link_set_bounded(opal_link_t *l, int on)
+{
+    if (!l) {
+        set_error("opal_link_set_bounded: null link");
+        return OPAL_ERR_ARG;
+    }
+    l->bounded = on != 0;
+    return OPAL_OK;
+}
+
+int opal_link_last_exchange_bytes(const opal_link_t *l, size_t *left, size_t *right)
+{
+    if (!l) {
+        set_error("opal_link_last_exchange_bytes: null link");
+        return OPAL_ERR_ARG;
+    }
+    if (left) *left = l->last_bytes[0];
+    if (right) *right = l->last_bytes[1];
     return OPAL_OK;
 }
 

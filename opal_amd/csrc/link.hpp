@@ -6,6 +6,48 @@ namespace opal {
 constexpr size_t LINK_HEADER_BYTES = 64;
 constexpr size_t LINK_HALO_BYTES = 80 * sizeof(double);
 constexpr size_t LINK_HEAD_BYTES = LINK_HEADER_BYTES + LINK_HALO_BYTES;  // 704
+// header words (uint32): [0, 3) leavers per species slot, [4, 7) particles per species within LINK_ZONE cells of the
+// edge the message crosses after this step's push (an upper bound on the leavers LINK_ZONE steps from now)
+constexpr int LINK_H_COUNT = 0, LINK_H_ZONE = 4;
+constexpr int LINK_ZONE = 3;        // cells; also the lag (in exchanges) with which message sizes follow the bound
+constexpr unsigned LINK_ROWS = 64;  // particles per row block
+constexpr unsigned LINK_SLACK = 64; // slots beyond the bound (arrivals that turn round inside the zone)
+constexpr int LINK_RING = 8;        // exchanges whose bounds the host keeps
+
+// Row-blocked body: block (b, s) = particles [64 b, 64 b + 64) of species slot s: int32 cell[64] then `nfields`
+// columns of double[64]; blocks are ordered b-major, so "the first m blocks of every species" is a prefix.
+struct LinkLayout {
+    unsigned nslots, blk;  // species slots; bytes per block = 64 * (4 + 8 * nfields)
+};
+__host__ __device__ inline size_t link_block_off(LinkLayout L, int slot, unsigned i)
+{
+    return LINK_HEAD_BYTES + ((size_t)(i >> 6) * L.nslots + (unsigned)slot) * L.blk;
+}
+__host__ __device__ inline int *link_cell(char *msg, LinkLayout L, int slot, unsigned i)
+{
+    return reinterpret_cast<int *>(msg + link_block_off(L, slot, i)) + (i & 63u);
+}
+__host__ __device__ inline double *link_field(char *msg, LinkLayout L, int slot, int f, unsigned i)
+{
+    return reinterpret_cast<double *>(msg + link_block_off(L, slot, i) + 256 + (size_t)f * 512) + (i & 63u);
+}
+__host__ __device__ inline const int *link_cell(const char *msg, LinkLayout L, int slot, unsigned i)
+{
+    return reinterpret_cast<const int *>(msg + link_block_off(L, slot, i)) + (i & 63u);
+}
+__host__ __device__ inline const double *link_field(const char *msg, LinkLayout L, int slot, int f, unsigned i)
+{
+    return reinterpret_cast<const double *>(msg + link_block_off(L, slot, i) + 256 + (size_t)f * 512) + (i & 63u);
+}
+
+// what one exchange leaves for the host (mapped pinned memory, written by the unpack kernel): the zone counts of
+// this subdomain's two outgoing messages and of the two it received, and the exchange they belong to
+struct LinkBounds {
+    unsigned mine[2][3];    // [side][species slot]: my particles near my left / right edge
+    unsigned theirs[2][3];  // [side]: the left / right neighbour's particles near the edge we share
+    unsigned pad[3];
+    volatile unsigned seq;  // exchange number + 1, written last
+};
 }  // namespace opal
 
 struct opal_link {
@@ -13,30 +55,40 @@ struct opal_link {
     bool device_buffers;
     bool external;  // buffers the transport sees belong to the caller
     bool counts_clean;  // the send messages' leaver counts are known to be zero (see link_begin)
-    size_t cap;     // particles per species per direction
+    size_t cap;     // particles per species per direction the buffers have room for
     int nslots;     // species blocks per message: 2 (electrons, ions) or 3 (+ photons)
-    int nfields;    // doubles per particle: 6 (x ux uy uz w prev_x) or 12 (+ chi work y z tau id)
-    size_t species_bytes, nbytes;
+    int nfields;    // doubles per particle: 6 (x ux uy uz w prev_x), 12 (+ chi work y z tau id) or 15 (+ tau_abs tau_st birth)
+    opal::LinkLayout layout;
+    size_t nbytes;  // a message with all `cap` slots
     opal_exchange_fn exchange;
+    opal_exchange2_fn exchange2;  // optional: per-edge sizes (see link_exchange_particles)
     void *user;
     void (*user_free)(void *);  // releases `user` with the link (native transports), or null
-    // optional: ships a whole message but only the leavers it holds (see rccl_link.cpp); null = fixed size
-    int (*exchange_exact)(opal_link *l, bool to_left, bool to_right, hipStream_t st);
     // optional: tells a stream-ordered transport which stream the next exchanges are ordered on; null = it only
     // knows the stream it was created with (e.g. a host-language callback tied to its framework's stream)
     void (*set_stream)(void *user, hipStream_t st);
     hipStream_t stream;
     char *d_send_left, *d_send_right, *d_recv_left, *d_recv_right;  // device side (kernels pack / unpack here)
     char *h_send_left, *h_send_right, *h_recv_left, *h_recv_right;  // host staging when device_buffers == 0
+    // message sizes that follow the particles (link.cpp): bounds of the last LINK_RING exchanges, written by the device
+    opal::LinkBounds *h_bounds, *d_bounds;  // the same mapped pinned memory, host and device view
+    unsigned xseq;           // whole-message exchanges so far
+    unsigned send_cap[2];    // slots (a multiple of 64) the next exchange ships per species: left / right edge
+    bool bounded;            // sizes follow the bounds (needs exchange2); else every exchange ships all `cap` slots
+    size_t last_bytes[2];    // what the last whole-message exchange moved per edge (diagnostic)
 };
 
 namespace opal {
-size_t link_species_offset(const opal_link_t *l, int slot);
 char *link_send(opal_link_t *l, int side);
 char *link_recv(opal_link_t *l, int side);
 int link_begin(opal_link_t *l, hipStream_t st);
-int link_exchange(opal_link_t *l, size_t nbytes, bool to_left, bool to_right, hipStream_t st);
+// decides how many slots per species the coming exchange ships on each edge (send_cap), from the bounds the device
+// reported LINK_ZONE exchanges ago; call before the push that packs the leavers
+int link_plan(opal_link_t *l);
+size_t link_prefix_bytes(const opal_link_t *l, unsigned slots);
+// halo-only exchange (the first LINK_HEAD_BYTES of each message)
+int link_exchange_halo(opal_link_t *l, bool to_left, bool to_right, hipStream_t st);
+// whole messages, each edge as long as link_plan decided
+int link_exchange_particles(opal_link_t *l, bool to_left, bool to_right, hipStream_t st);
 bool link_can_use_stream(const opal_link_t *l, hipStream_t st);
-size_t link_body_bytes(const opal_link_t *l, const unsigned *counts);
-int link_repack(opal_link_t *l, char *const strided[2], char *const compact[2], bool to_compact, hipStream_t st);
 }  // namespace opal

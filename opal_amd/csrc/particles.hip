@@ -74,11 +74,11 @@ struct PushArgs {
     double dt, dt_over_dx, inv_dt, inv_dx, alpha, charge;
     int left_mode, right_mode;
     PopCounters *ctr;
-    // leaver buffers (EDGE_SEND) inside the link's send messages: SoA blocks of `send_cap` particles
-    unsigned *send_count[2];
-    int *send_cell[2];
-    double *send_f[2];  // x ux uy uz w prev_x, 6 x send_cap
-    unsigned send_cap;
+    // leavers (EDGE_SEND) go into the link's send messages (layout: link.hpp): header words + row blocks
+    char *send_msg[2];
+    unsigned send_cap[2];  // slots this step's message ships per species on that edge (link_plan)
+    LinkLayout send_layout;
+    int send_slot;         // this species' slot in the message
     unsigned send_nextra;  // extras carried behind the 6 base fields (0 for a plain link)
     unsigned *emit_list;   // EXTRAS == 2: slots whose optical depth ran out in this push (count in ctr->n_emit)
     // chunk table of the last re-binning (see opal_pop): workgroups [0, n_tab) take tab_slot[b] .. tab_slot[b+1],
@@ -284,6 +284,12 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             // slow particles -- and the test costs one compare and one scalar branch per attribute elsewhere
             // (and two registers per tested momentum component, which is why ux is not tested).
             auto differs = [](double p, double q) { return __double_as_longlong(p) != __double_as_longlong(q); };
+            // towards a neighbouring subdomain: count who stands within LINK_ZONE cells of that edge now -- nobody
+            // else can cross it in the next LINK_ZONE steps, which is what sizes the coming messages (link.cpp)
+            if (a.left_mode == EDGE_SEND && newc < LINK_ZONE)
+                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + LINK_H_ZONE + a.send_slot, 1u);
+            if (a.right_mode == EDGE_SEND && newc >= a.size - LINK_ZONE)
+                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + LINK_H_ZONE + a.send_slot, 1u);
             if (__ballot(newc != c_mem)) stk(cp.cell, kc, newc);
             stk(cp.x, kc, xn);
             if (SPECIES != OPAL_PHOTON) {  // a photon's momentum never changes
@@ -298,20 +304,20 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             atomicAdd(&a.ctr->n_dead, 1u);
         } else {
             atomicAdd(&a.ctr->n_dead, 1u);
-            unsigned slot = atomicAdd(a.send_count[send_side], 1u);
-            if (slot < a.send_cap) {
-                a.send_cell[send_side][slot] = newc;
-                double *f = a.send_f[send_side];
-                f[0 * (size_t)a.send_cap + slot] = xn;
-                f[1 * (size_t)a.send_cap + slot] = u.x;
-                f[2 * (size_t)a.send_cap + slot] = u.y;
-                f[3 * (size_t)a.send_cap + slot] = u.z;
-                f[4 * (size_t)a.send_cap + slot] = wt;
-                if (MODE == MODE_ADVANCE && cp.prev) f[5 * (size_t)a.send_cap + slot] = prev;
+            char *msg = a.send_msg[send_side];
+            unsigned slot = atomicAdd(reinterpret_cast<unsigned *>(msg) + LINK_H_COUNT + a.send_slot, 1u);
+            if (slot < a.send_cap[send_side]) {
+                *link_cell(msg, a.send_layout, a.send_slot, slot) = newc;
+                *link_field(msg, a.send_layout, a.send_slot, 0, slot) = xn;
+                *link_field(msg, a.send_layout, a.send_slot, 1, slot) = u.x;
+                *link_field(msg, a.send_layout, a.send_slot, 2, slot) = u.y;
+                *link_field(msg, a.send_layout, a.send_slot, 3, slot) = u.z;
+                *link_field(msg, a.send_layout, a.send_slot, 4, slot) = wt;
+                if (MODE == MODE_ADVANCE && cp.prev) *link_field(msg, a.send_layout, a.send_slot, 5, slot) = prev;
                 // A link laid out for photon emission carries the extras too (the reference ships the whole
                 // struct, mod.rs:308-354).  Only the leaver's slot is noted here; k_pack_extras copies the
-                // values afterwards, which keeps six more pointers out of this kernel's registers.
-                if (SENDX) f[6 * (size_t)a.send_cap + slot] = (double)(cp.chunk0 + kc);
+                // values afterwards, which keeps the extras' pointers out of this kernel's registers.
+                if (SENDX) *link_field(msg, a.send_layout, a.send_slot, 6, slot) = (double)(cp.chunk0 + kc);
             } else {
                 err |= 8;
             }
@@ -640,6 +646,10 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
             }
         }
         if (!deleted && send_side < 0) {
+            if (a.left_mode == EDGE_SEND && newc < LINK_ZONE)
+                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + LINK_H_ZONE + a.send_slot, 1u);
+            if (a.right_mode == EDGE_SEND && newc >= a.size - LINK_ZONE)
+                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + LINK_H_ZONE + a.send_slot, 1u);
             if (__ballot(newc != c)) stk(cellp, kc, newc);
             stk(xp, kc, xn);
         } else if (deleted) {
@@ -648,16 +658,16 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
             atomicAdd(&a.ctr->n_dead, 1u);
         } else {
             atomicAdd(&a.ctr->n_dead, 1u);
-            unsigned slot = atomicAdd(a.send_count[send_side], 1u);
-            if (slot < a.send_cap) {
-                a.send_cell[send_side][slot] = newc;
-                double *f = a.send_f[send_side];
-                f[0 * (size_t)a.send_cap + slot] = xn;
-                f[1 * (size_t)a.send_cap + slot] = k.x;
-                f[2 * (size_t)a.send_cap + slot] = k.y;
-                f[3 * (size_t)a.send_cap + slot] = k.z;
-                f[4 * (size_t)a.send_cap + slot] = a.w[chunk0 + kc];
-                if (SENDX) f[6 * (size_t)a.send_cap + slot] = (double)(chunk0 + kc);
+            char *msg = a.send_msg[send_side];
+            unsigned slot = atomicAdd(reinterpret_cast<unsigned *>(msg) + LINK_H_COUNT + a.send_slot, 1u);
+            if (slot < a.send_cap[send_side]) {
+                *link_cell(msg, a.send_layout, a.send_slot, slot) = newc;
+                *link_field(msg, a.send_layout, a.send_slot, 0, slot) = xn;
+                *link_field(msg, a.send_layout, a.send_slot, 1, slot) = k.x;
+                *link_field(msg, a.send_layout, a.send_slot, 2, slot) = k.y;
+                *link_field(msg, a.send_layout, a.send_slot, 3, slot) = k.z;
+                *link_field(msg, a.send_layout, a.send_slot, 4, slot) = a.w[chunk0 + kc];
+                if (SENDX) *link_field(msg, a.send_layout, a.send_slot, 6, slot) = (double)(chunk0 + kc);
             } else {
                 err |= 8;
             }
@@ -921,9 +931,9 @@ __global__ void k_init_prev(const int *cell, const double *x, const double *ux, 
 // right neighbour sent left (cell -1 -> += this subdomain's size, mod.rs:366-368).
 struct UnpackArgs {
     const char *recv[2];
-    size_t species_off;
+    LinkLayout layout;
     int slot;
-    unsigned link_cap;
+    unsigned recv_cap[2];  // slots per species the message of that edge shipped
     int *cell;
     double *f[5];
     double *prev_x;
@@ -935,21 +945,37 @@ struct UnpackArgs {
     unsigned *emit_list;  // electrons of an emission run: arrivals whose optical depth has run out join the list
 };
 
-// up to three species per launch (blocks 2 s and 2 s + 1 belong to species s); the first workgroup also
-// zeroes the leaver counts of the send messages for the next step when asked to (they have been shipped)
+// up to three species per launch (blocks 2 s and 2 s + 1 belong to species s).  The first workgroup also files
+// this exchange's zone counts -- mine from the send headers, the neighbours' from the received ones -- in the
+// link's mapped host ring (link.cpp), and then zeroes the send headers for the next step (they have been shipped).
 struct UnpackBatch {
     UnpackArgs a[3];
     int n;
     unsigned *zero[2];
+    const unsigned *send_head[2], *recv_head[2];  // null where there is no neighbour
+    LinkBounds *bounds;                            // ring entry of this exchange (mapped host memory), or null
+    unsigned seq;
 };
 
 __device__ void unpack_one(const UnpackArgs &a, int side);
 
 __global__ void k_unpack(UnpackBatch b)
 {
-    if (blockIdx.x == 0 && threadIdx.x < 16) {
-        if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
-        if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
+    if (blockIdx.x == 0) {
+        if (b.bounds && threadIdx.x < 6) {
+            const int side = threadIdx.x / 3, sp = threadIdx.x % 3;
+            b.bounds->mine[side][sp] = b.send_head[side] ? b.send_head[side][LINK_H_ZONE + sp] : 0u;
+            b.bounds->theirs[side][sp] = b.recv_head[side] ? b.recv_head[side][LINK_H_ZONE + sp] : 0u;
+        }
+        __syncthreads();
+        if (b.bounds && threadIdx.x == 0) {
+            __threadfence_system();
+            b.bounds->seq = b.seq;
+        }
+        if (threadIdx.x < 16) {
+            if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
+            if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
+        }
     }
     unpack_one(b.a[blockIdx.x >> 1], blockIdx.x & 1);
 }
@@ -959,8 +985,8 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
     __shared__ unsigned s_base;
     const char *msg = a.recv[side];
     if (!msg) return;
-    unsigned count = reinterpret_cast<const unsigned *>(msg)[a.slot];
-    if (count > a.link_cap) count = a.link_cap;  // the sender has flagged the overflow on its side
+    unsigned count = reinterpret_cast<const unsigned *>(msg)[LINK_H_COUNT + a.slot];
+    if (count > a.recv_cap[side]) count = a.recv_cap[side];  // the sender has flagged the overflow on its side
     if (count == 0) return;
     if (threadIdx.x == 0) s_base = atomicAdd(&a.ctr->n_slots, count);
     __syncthreads();
@@ -972,21 +998,19 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
         }
         return;
     }
-    const int *rc = reinterpret_cast<const int *>(msg + a.species_off);
-    const double *rf = reinterpret_cast<const double *>(msg + a.species_off + sizeof(int) * (size_t)a.link_cap);
     for (unsigned k = threadIdx.x; k < count; k += blockDim.x) {
-        a.cell[base + k] = rc[k] + (side == 1 ? a.my_size : 0);
+        a.cell[base + k] = *link_cell(msg, a.layout, a.slot, k) + (side == 1 ? a.my_size : 0);
 #pragma unroll
-        for (int c = 0; c < 5; c++) a.f[c][base + k] = rf[(size_t)c * a.link_cap + k];
-        if (a.prev_x) a.prev_x[base + k] = rf[(size_t)5 * a.link_cap + k];
+        for (int c = 0; c < 5; c++) a.f[c][base + k] = *link_field(msg, a.layout, a.slot, c, k);
+        if (a.prev_x) a.prev_x[base + k] = *link_field(msg, a.layout, a.slot, 5, k);
         // a plain link's message does not carry the extras (diagnostics only: a particle that changes
         // subdomain restarts them); a link laid out for photon emission carries all of them
 #pragma unroll
         for (int q = 0; q < NEX; q++)
-            if (a.ex[q]) a.ex[q][base + k] = q < (int)a.nextra ? rf[(size_t)(6 + q) * a.link_cap + k] : 0.0;
+            if (a.ex[q]) a.ex[q][base + k] = q < (int)a.nextra ? *link_field(msg, a.layout, a.slot, 6 + q, k) : 0.0;
         // an electron that crossed over with its optical depth already below zero radiates here (the reference
         // migrates before emit_radiation, main.rs:240-252): rare, one atomic each
-        if (a.emit_list && a.nextra > EX_TAU && rf[(size_t)(6 + EX_TAU) * a.link_cap + k] < 0.0)
+        if (a.emit_list && a.nextra > EX_TAU && *link_field(msg, a.layout, a.slot, 6 + EX_TAU, k) < 0.0)
             a.emit_list[atomicAdd(&a.ctr->n_emit, 1u)] = base + k;
     }
 }
@@ -995,22 +1019,21 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
 // first extras column): one workgroup per side.
 struct PackExtrasArgs {
     char *send[2];
-    size_t species_off;
+    LinkLayout layout;
     int slot;
-    unsigned link_cap, nextra;
+    unsigned send_cap[2], nextra;
     const double *ex[NEX];
 };
 __global__ void k_pack_extras(PackExtrasArgs a)
 {
     char *msg = a.send[blockIdx.x];
     if (!msg) return;
-    unsigned count = min(reinterpret_cast<const unsigned *>(msg)[a.slot], a.link_cap);
-    double *f = reinterpret_cast<double *>(msg + a.species_off + sizeof(int) * (size_t)a.link_cap);
+    unsigned count = min(reinterpret_cast<const unsigned *>(msg)[LINK_H_COUNT + a.slot], a.send_cap[blockIdx.x]);
     for (unsigned k = threadIdx.x; k < count; k += blockDim.x) {
-        size_t i = (size_t)f[(size_t)6 * a.link_cap + k];
+        size_t i = (size_t)*link_field(msg, a.layout, a.slot, 6, k);
 #pragma unroll
         for (int q = 0; q < NEX; q++)
-            if (q < (int)a.nextra) f[(size_t)(6 + q) * a.link_cap + k] = a.ex[q] ? a.ex[q][i] : 0.0;
+            if (q < (int)a.nextra) *link_field(msg, a.layout, a.slot, 6 + q, k) = a.ex[q] ? a.ex[q][i] : 0.0;
     }
 }
 
@@ -1247,13 +1270,11 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
             return OPAL_ERR_LINK;
         }
         for (int side = 0; side < 2; side++) {
-            char *msg = link_send(link, side);
-            char *blk = msg + link_species_offset(link, slot);
-            a.send_count[side] = reinterpret_cast<unsigned *>(msg) + slot;
-            a.send_cell[side] = reinterpret_cast<int *>(blk);
-            a.send_f[side] = reinterpret_cast<double *>(blk + sizeof(int) * link->cap);
+            a.send_msg[side] = link_send(link, side);
+            a.send_cap[side] = link->send_cap[side];
         }
-        a.send_cap = (unsigned)link->cap;
+        a.send_layout = link->layout;
+        a.send_slot = slot;
         a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
@@ -1404,7 +1425,9 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g);
 int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, UnpackArgs &u)
 {
     bool from_left = g->left_bdy == OPAL_BDY_INTERNAL, from_right = g->right_bdy == OPAL_BDY_INTERNAL;
-    size_t incoming = ((size_t)from_left + (size_t)from_right) * link->cap;
+    // at most what this step's messages ship per species (link_plan): the host's bound on the slots in use grows by
+    // that much, not by the link's full capacity
+    size_t incoming = (from_left ? (size_t)link->send_cap[0] : 0) + (from_right ? (size_t)link->send_cap[1] : 0);
     // the host only knows that at most `incoming` particles arrive per step; counter snapshots that land a
     // step or two later pull its bound on the slots in use back down to the true count
     if (int rc = opal::pop_tighten_upper(p)) return rc;
@@ -1426,8 +1449,9 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
         set_error("this link's messages have no room for species %d (see opal_link_set_layout)", u.slot);
         return OPAL_ERR_LINK;
     }
-    u.species_off = link_species_offset(link, u.slot);
-    u.link_cap = (unsigned)link->cap;
+    u.layout = link->layout;
+    u.recv_cap[0] = link->send_cap[0];  // an edge's two directions ship the same number of slots
+    u.recv_cap[1] = link->send_cap[1];
     u.cell = p->d_cell[k];
     u.f[0] = p->d_x[k]; u.f[1] = p->d_ux[k]; u.f[2] = p->d_uy[k]; u.f[3] = p->d_uz[k]; u.f[4] = p->d_w[k];
     u.prev_x = p->prev_valid ? p->d_prev_x : nullptr;
@@ -1463,6 +1487,15 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.zero[0] = reinterpret_cast<unsigned *>(link_send(link, 0));
         b.zero[1] = reinterpret_cast<unsigned *>(link_send(link, 1));
     }
+    if (link->d_bounds && link->xseq) {  // the exchange just made is number xseq - 1
+        const bool nb[2] = {g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL};
+        for (int side = 0; side < 2; side++) {
+            b.send_head[side] = nb[side] ? reinterpret_cast<const unsigned *>(link_send(link, side)) : nullptr;
+            b.recv_head[side] = nb[side] ? reinterpret_cast<const unsigned *>(link_recv(link, side)) : nullptr;
+        }
+        b.bounds = &link->d_bounds[(link->xseq - 1) % LINK_RING];
+        b.seq = link->xseq;
+    }
     k_unpack<<<2 * b.n, 256, 0, st>>>(b);
     OPAL_HIP(hipGetLastError());
     if (zero_counts) link->counts_clean = true;
@@ -1487,8 +1520,9 @@ int pack_leaver_extras(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g)
     a.send[0] = g->left_bdy == OPAL_BDY_INTERNAL ? link_send(link, 0) : nullptr;
     a.send[1] = g->right_bdy == OPAL_BDY_INTERNAL ? link_send(link, 1) : nullptr;
     a.slot = p->species;
-    a.species_off = link_species_offset(link, a.slot);
-    a.link_cap = (unsigned)link->cap;
+    a.layout = link->layout;
+    a.send_cap[0] = link->send_cap[0];
+    a.send_cap[1] = link->send_cap[1];
     a.nextra = (unsigned)(link->nfields - 6);
     for (int q = 0; q < NEX; q++) a.ex[q] = p->extras ? p->d_ex[q] : nullptr;
     k_pack_extras<<<2, 256, 0, p->stream>>>(a);
@@ -1508,7 +1542,7 @@ int advance_with_exchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, doub
     if (int rc = link_begin(link, p->stream)) return rc;
     if (int rc = run_push(p, link, g, dt, mode)) return rc;
     if (int rc = pack_leaver_extras(p, link, g)) return rc;
-    if (int rc = link_exchange(link, link->nbytes, g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL, p->stream)) return rc;
+    if (int rc = link_exchange_particles(link, g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL, p->stream)) return rc;
     return unpack_arrivals(&p, 1, link, g, true);
 }
 

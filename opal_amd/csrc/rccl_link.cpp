@@ -63,9 +63,6 @@ struct RcclState {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     int left = 0, right = 0;
-    unsigned *h_counts = nullptr;  // pinned: the four headers of an exact-size exchange
-    hipEvent_t ev = nullptr;
-    char *d_compact[4] = {nullptr, nullptr, nullptr, nullptr};  // contiguous bodies: send left / right, recv left / right
 };
 
 #define OPAL_NCCL(st, call)                                                                \
@@ -77,85 +74,26 @@ struct RcclState {
         }                                                                                  \
     } while (0)
 
-// send_left -> left neighbour's recv_right, send_right -> right neighbour's recv_left.  With two periodic
-// subdomains (or one, sending to itself) both neighbours are the same peer: RCCL matches sends and
+// send_left -> left neighbour's recv_right, send_right -> right neighbour's recv_left; the left edge moves
+// n_left bytes each way, the right edge n_right (both ends of an edge pass the same number: link.cpp).  With two
+// periodic subdomains (or one, sending to itself) both neighbours are the same peer: RCCL matches sends and
 // receives per peer in issue order, so sends go (left, right) and receives (right, left).
-int rccl_exchange(void *user, const void *send_left, const void *send_right, void *recv_left, void *recv_right,
-                  size_t nbytes)
+int rccl_exchange2(void *user, const void *send_left, const void *send_right, void *recv_left, void *recv_right,
+                   size_t n_left, size_t n_right)
 {
     RcclState *st = static_cast<RcclState *>(user);
     OPAL_NCCL(st, st->api.GroupStart());
-    if (send_left) OPAL_NCCL(st, st->api.Send(send_left, nbytes, ncclUint8, st->left, st->comm, st->stream));
-    if (send_right) OPAL_NCCL(st, st->api.Send(send_right, nbytes, ncclUint8, st->right, st->comm, st->stream));
-    if (recv_right) OPAL_NCCL(st, st->api.Recv(recv_right, nbytes, ncclUint8, st->right, st->comm, st->stream));
-    if (recv_left) OPAL_NCCL(st, st->api.Recv(recv_left, nbytes, ncclUint8, st->left, st->comm, st->stream));
+    if (send_left) OPAL_NCCL(st, st->api.Send(send_left, n_left, ncclUint8, st->left, st->comm, st->stream));
+    if (send_right) OPAL_NCCL(st, st->api.Send(send_right, n_right, ncclUint8, st->right, st->comm, st->stream));
+    if (recv_right) OPAL_NCCL(st, st->api.Recv(recv_right, n_right, ncclUint8, st->right, st->comm, st->stream));
+    if (recv_left) OPAL_NCCL(st, st->api.Recv(recv_left, n_left, ncclUint8, st->left, st->comm, st->stream));
     OPAL_NCCL(st, st->api.GroupEnd());
     return 0;
 }
-
-// Exact-size variant for links with room for a large peak flux (a dense beam crossing a cut): ship the
-// 704-byte head (leaver counts + halo) first, read both sides' counts on the host, then send the occupied
-// part of every column as one contiguous body (link_pack.hip).  Costs a second RCCL group and one stream
-// synchronisation per exchange; saves shipping `particle_capacity` slots per column when few are in use.
-#define OPAL_NCCL_L(st, call)                                                                    \
-    do {                                                                                         \
-        ncclResult_t r_ = (call);                                                                \
-        if (r_ != ncclSuccess) {                                                                 \
-            set_error("RCCL error %d (%s) in %s", (int)r_, (st)->api.GetErrorString(r_), #call); \
-            return 1;                                                                            \
-        }                                                                                        \
-    } while (0)
-#define OPAL_HIP_L(call)                                                      \
-    do {                                                                      \
-        hipError_t e_ = (call);                                               \
-        if (e_ != hipSuccess) {                                               \
-            set_error("HIP error %d (%s) in %s", (int)e_, hipGetErrorString(e_), #call); \
-            return 1;                                                         \
-        }                                                                     \
-    } while (0)
-
-int rccl_exchange_exact(opal_link *l, bool to_left, bool to_right, hipStream_t stream)
+int rccl_exchange(void *user, const void *send_left, const void *send_right, void *recv_left, void *recv_right,
+                  size_t nbytes)
 {
-    RcclState *st = static_cast<RcclState *>(l->user);
-    // phase 1: the heads (leaver counts + halo), fixed size
-    if (rccl_exchange(st, to_left ? l->d_send_left : nullptr, to_right ? l->d_send_right : nullptr,
-                      to_left ? l->d_recv_left : nullptr, to_right ? l->d_recv_right : nullptr, LINK_HEAD_BYTES))
-        return 1;
-    // meanwhile gather the occupied part of my columns into one contiguous body per direction
-    char *send_strided[2] = {to_left ? l->d_send_left : nullptr, to_right ? l->d_send_right : nullptr};
-    char *send_compact[2] = {st->d_compact[0], st->d_compact[1]};
-    if (link_repack(l, send_strided, send_compact, true, stream)) return 1;
-    // counts: what I send left / right, what arrives from the left / right
-    unsigned *h = st->h_counts;  // 4 x 16 uint32, pinned
-    const char *src[4] = {l->d_send_left, l->d_send_right, l->d_recv_left, l->d_recv_right};
-    const bool use[4] = {to_left, to_right, to_left, to_right};
-    for (int k = 0; k < 4; k++) {
-        if (use[k]) OPAL_HIP_L(hipMemcpyAsync(h + 16 * k, src[k], LINK_HEADER_BYTES, hipMemcpyDeviceToHost, stream));
-        else memset(h + 16 * k, 0, LINK_HEADER_BYTES);
-    }
-    // spin on an event rather than hipStreamSynchronize: the interrupt-driven wait wakes up ~100 us late, and
-    // the device idles until the host has issued phase 2
-    if (!st->ev) OPAL_HIP_L(hipEventCreateWithFlags(&st->ev, hipEventDisableTiming));
-    OPAL_HIP_L(hipEventRecord(st->ev, stream));
-    for (;;) {
-        hipError_t q = hipEventQuery(st->ev);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) OPAL_HIP_L(q);
-    }
-    // phase 2: the bodies, each exactly as long as its leavers need (both ends compute the same length from
-    // the same counts); same issue order as the fixed-size exchange
-    const size_t send_l = link_body_bytes(l, h), send_r = link_body_bytes(l, h + 16);
-    const size_t recv_l = link_body_bytes(l, h + 32), recv_r = link_body_bytes(l, h + 48);
-    if (send_l + send_r + recv_l + recv_r == 0) return 0;
-    OPAL_NCCL_L(st, st->api.GroupStart());
-    if (send_l) OPAL_NCCL_L(st, st->api.Send(st->d_compact[0], send_l, ncclUint8, st->left, st->comm, stream));
-    if (send_r) OPAL_NCCL_L(st, st->api.Send(st->d_compact[1], send_r, ncclUint8, st->right, st->comm, stream));
-    if (recv_r) OPAL_NCCL_L(st, st->api.Recv(st->d_compact[3], recv_r, ncclUint8, st->right, st->comm, stream));
-    if (recv_l) OPAL_NCCL_L(st, st->api.Recv(st->d_compact[2], recv_l, ncclUint8, st->left, st->comm, stream));
-    OPAL_NCCL_L(st, st->api.GroupEnd());
-    char *recv_strided[2] = {recv_l ? l->d_recv_left : nullptr, recv_r ? l->d_recv_right : nullptr};
-    char *recv_compact[2] = {st->d_compact[2], st->d_compact[3]};
-    return link_repack(l, recv_strided, recv_compact, false, stream);
+    return rccl_exchange2(user, send_left, send_right, recv_left, recv_right, nbytes, nbytes);
 }
 
 void rccl_free(void *user)
@@ -163,10 +101,6 @@ void rccl_free(void *user)
     RcclState *st = static_cast<RcclState *>(user);
     if (!st) return;
     if (st->comm) st->api.CommDestroy(st->comm);
-    if (st->h_counts) hipHostFree(st->h_counts);
-    if (st->ev) hipEventDestroy(st->ev);
-    for (char *p : st->d_compact)
-        if (p) hipFree(p);
     delete st;
 }
 
@@ -223,6 +157,7 @@ int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle
         return rc;
     }
     (*out)->user_free = rccl_free;
+    (*out)->exchange2 = rccl_exchange2;  // one size per edge: messages follow the particles (link.cpp)
     (*out)->set_stream = [](void *user, hipStream_t s) { static_cast<RcclState *>(user)->stream = s; };
     return OPAL_OK;
 }
@@ -243,21 +178,6 @@ int opal_link_rccl_ranks(const opal_link_t *l, int *out)
         set_error("ncclCommCount failed: %s", st->api.GetErrorString(r));
         return OPAL_ERR_LINK;
     }
-    return OPAL_OK;
-}
-
-int opal_link_set_exact(opal_link_t *l, int on)
-{
-    if (!l || l->user_free != rccl_free) {
-        set_error("opal_link_set_exact: only links created with opal_link_create_rccl can size their messages");
-        return OPAL_ERR_ARG;
-    }
-    RcclState *st = static_cast<RcclState *>(l->user);
-    if (on && !st->h_counts) {
-        OPAL_HIP(hipHostMalloc((void **)&st->h_counts, 4 * LINK_HEADER_BYTES));
-        for (char *&p : st->d_compact) OPAL_HIP(hipMalloc((void **)&p, l->nbytes));
-    }
-    l->exchange_exact = on ? rccl_exchange_exact : nullptr;
     return OPAL_OK;
 }
 

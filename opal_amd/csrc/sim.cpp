@@ -638,7 +638,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             const double *rl = nullptr, *rr = nullptr;
             if (!s->current_deposition)
                 if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
-            if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, st)) return rc;
+            if (int rc = link_exchange_particles(s->link, to_left, to_right, st)) return rc;
             if (int rc = pops_unpack(pops, 3, s->link, g)) return rc;
             if (int rc = absorb_now()) return rc;
             if (s->photon_emission && s->electrons)  // main.rs:250-252
@@ -688,7 +688,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 OPAL_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_edges, 0));
                 if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, s->comm_stream)) return rc;
                 if (int rc = pops_push_fused_pair_part(s->electrons, s->ions, s->link, g, s->dt, false)) return rc;
-                if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, s->comm_stream)) return rc;
+                if (int rc = link_exchange_particles(s->link, to_left, to_right, s->comm_stream)) return rc;
                 OPAL_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
                 OPAL_HIP(hipStreamWaitEvent(st, s->ev_comm, 0));
                 s->n_overlapped++;
@@ -702,7 +702,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                         if (int rc = pop_push_fused_noexchange(s->ions, s->link, g, s->dt)) return rc;
                 }
                 if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
-                if (int rc = link_exchange(s->link, s->link->nbytes, to_left, to_right, st)) return rc;
+                if (int rc = link_exchange_particles(s->link, to_left, to_right, st)) return rc;
             }
             double ly, lz;
             laser_now(ly, lz);

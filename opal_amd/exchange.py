@@ -66,6 +66,7 @@ class TorchLink:
         self.device = torch.device(device)
         device_buffers = 1 if self.device.type == "cuda" else 0
         self._cb = _lib.EXCHANGE_FN(self._exchange)  # keep alive
+        self._cb2 = _lib.EXCHANGE2_FN(self._exchange2)
         h = C.c_void_p()
         # runs with photon emission move a third species and the electrons' optical depths and ids; with
         # absorption also the photons' optical depths and birth times
@@ -75,6 +76,9 @@ class TorchLink:
         if rc:
             raise RuntimeError(self._lib.opal_last_error().decode())
         self.h = h
+        # one size per edge: whole messages are then as long as the particles near each cut require (link.cpp)
+        if self._lib.opal_link_set_exchange2(h, self._cb2):
+            raise RuntimeError(self._lib.opal_last_error().decode())
         self.nbytes = self._lib.opal_link_message_bytes(h)
         kw = {"dtype": torch.uint8, "device": self.device}
         self.bufs = [torch.zeros(self.nbytes, **kw) for _ in range(4)]  # send_left, send_right, recv_left, recv_right
@@ -92,22 +96,28 @@ class TorchLink:
             self.h = None
 
     def _exchange(self, user, send_left, send_right, recv_left, recv_right, nbytes):
+        return self._exchange2(user, send_left, send_right, recv_left, recv_right, nbytes, nbytes)
+
+    def _exchange2(self, user, send_left, send_right, recv_left, recv_right, n_left, n_right):
+        """The left edge (send_left, recv_left) moves n_left bytes each way, the right edge n_right."""
         try:
-            # the same few (size, directions) combinations recur every step: build the op list once
-            key = (nbytes, bool(send_left), bool(send_right), bool(recv_left), bool(recv_right))
+            # the same few (sizes, directions) combinations recur: build each op list once
+            key = (n_left, n_right, bool(send_left), bool(send_right), bool(recv_left), bool(recv_right))
             ops = self._ops.get(key)
             if ops is None:
                 sl, sr, rl, rr = self.bufs
                 tr = self.transport
                 ops = []
                 if send_left:
-                    ops.append(dist.P2POp(dist.isend, sl[:nbytes], tr.left, tr.group, TAG_LEFTWARD))
+                    ops.append(dist.P2POp(dist.isend, sl[:n_left], tr.left, tr.group, TAG_LEFTWARD))
                 if send_right:
-                    ops.append(dist.P2POp(dist.isend, sr[:nbytes], tr.right, tr.group, TAG_RIGHTWARD))
+                    ops.append(dist.P2POp(dist.isend, sr[:n_right], tr.right, tr.group, TAG_RIGHTWARD))
                 if recv_right:
-                    ops.append(dist.P2POp(dist.irecv, rr[:nbytes], tr.right, tr.group, TAG_LEFTWARD))
+                    ops.append(dist.P2POp(dist.irecv, rr[:n_right], tr.right, tr.group, TAG_LEFTWARD))
                 if recv_left:
-                    ops.append(dist.P2POp(dist.irecv, rl[:nbytes], tr.left, tr.group, TAG_RIGHTWARD))
+                    ops.append(dist.P2POp(dist.irecv, rl[:n_left], tr.left, tr.group, TAG_RIGHTWARD))
+                if len(self._ops) > 256:
+                    self._ops.clear()
                 self._ops[key] = ops
             if ops:
                 for w in dist.batch_isend_irecv(ops):
@@ -117,6 +127,14 @@ class TorchLink:
         except Exception:  # never let an exception cross the C boundary
             traceback.print_exc(file=sys.stderr)
             return 1
+
+    def last_exchange_bytes(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        self._lib.opal_link_last_exchange_bytes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def set_bounded(self, on=True):
+        self._lib.opal_link_set_bounded(self.h, 1 if on else 0)
 
 
 def _librccl_path():
@@ -132,9 +150,9 @@ class RcclLink:
     ranks (any backend), and by the output-time collectives."""
 
     def __init__(self, rank, world, device, particle_capacity=4096, group=None, stream=None, photon_emission=False,
-                 exact=False, photon_absorption=False):
-        """exact: size every message to the leavers it holds (one host synchronisation per exchange) instead of
-        shipping all particle_capacity slots: for links that must have room for a large peak flux."""
+                 photon_absorption=False):
+        """particle_capacity is what the buffers have room for; what travels each step follows the particles near
+        each cut (link.cpp)."""
         self._lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -158,13 +176,19 @@ class RcclLink:
             raise RuntimeError(self._lib.opal_last_error().decode())
         self.h = h
         self.nbytes = self._lib.opal_link_message_bytes(h)
-        if exact and self._lib.opal_link_set_exact(h, 1):
-            raise RuntimeError(self._lib.opal_last_error().decode())
 
     def __del__(self):
         if getattr(self, "h", None):
             self._lib.opal_link_free(self.h)
             self.h = None
+
+    def last_exchange_bytes(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        self._lib.opal_link_last_exchange_bytes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def set_bounded(self, on=True):
+        self._lib.opal_link_set_bounded(self.h, 1 if on else 0)
 
     def rccl_ranks(self):
         """ncclCommCount of the communicator the subdomains exchange through."""

@@ -278,14 +278,15 @@ dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 stream = torch.cuda.current_stream().cuda_stream
 out = {}
-for mode in ("wrap", "self", "native", "exact"):
+for mode in ("wrap", "self", "native", "fixed"):
     link = None
     if mode == "self":
         link = TorchLink(0, 1, dev, particle_capacity=512)      # torch.distributed P2P callback
     if mode == "native":
         link = RcclLink(0, 1, dev, particle_capacity=512)       # the library's own RCCL send/recv
-    if mode == "exact":                                         # ... shipping only the occupied slots
-        link = RcclLink(0, 1, dev, particle_capacity=1 << 14, exact=True)
+    if mode == "fixed":                                         # ... shipping every slot of a big buffer each step
+        link = RcclLink(0, 1, dev, particle_capacity=1 << 14)
+        link.set_bounded(False)
     sim = oa.Simulation(yaml_text=YAML.format(nx=1024, npc=16), rank=0, numtasks=1, link=link, stream=stream)
     if link is not None:
         sim.grid.set_self_exchange(True)
@@ -296,13 +297,17 @@ for mode in ("wrap", "self", "native", "exact"):
         s = p.soa(); o = np.lexsort((s["x"], s["ux"], s["w"]))
         out[mode][name] = {k: v[o] for k, v in s.items()}
     out[mode]["calls"] = getattr(link, "calls", 0)
+    if link is not None:
+        full = oa._lib.load().opal_link_message_bytes(link.h)
+        moved = link.last_exchange_bytes()
+        # messages follow the particles: 16 per cell and species within 3 cells of the cut, plus slack, in blocks
+        # of 64 -> 128 slots of the 512 (self, native); the fixed link ships all 16384
+        assert moved[0] == moved[1] and ((moved[0] == full) if mode == "fixed" else (704 < moved[0] < full // 3)), (mode, moved, full)
     # the native link (and it alone here: TorchLink's RCCL ops are tied to torch's stream) takes the overlapped step
-    # (the exact-size link is given 16 K slots per message here, more than the population: then the reserved
-    # tail outweighs the bulk and the step is not split)
-    assert mode == "exact" or (sim.overlapped_steps >= 20) == (mode == "native"), (mode, sim.overlapped_steps)
+    assert mode == "fixed" or (sim.overlapped_steps >= 20) == (mode == "native"), (mode, sim.overlapped_steps)
     del sim, link
 assert out["self"]["calls"] == 25, out["self"]["calls"]            # one exchange per step
-for mode in ("self", "native", "exact"):
+for mode in ("self", "native", "fixed"):
     for k in ("Ex", "Ey", "Ez", "By", "Bz"):
         a, b = out[mode][k], out["wrap"][k]
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), (mode, k)
@@ -321,8 +326,8 @@ print("SELF-EXCHANGE OK")
 @pytest.mark.parametrize("exact", [False, True])
 def test_emission_state_travels_through_rccl(tmp_path, exact):
     """Electrons with optical depths and ids, and photons, migrating through the native RCCL link (3 species
-    slots, 12 fields per particle; fixed-size and exact-size messages): a lone periodic subdomain in a strong
-    field made its own neighbour, against the in-place wrap.  Same emitters, same photons."""
+    slots, 12 fields per particle; messages that follow the particles, and fixed-size ones): a lone periodic
+    subdomain in a strong field made its own neighbour, against the in-place wrap.  Same emitters, same photons."""
     import subprocess
     from test_exchange_gloo import _free_port
     code = r'''
@@ -348,7 +353,8 @@ for mode in ("wrap", "link"):
     g.set_raw("Ey", np.full(g.len, 2.0e14)); g.set_raw("Bz", np.full(g.len, -0.5 * 2.0e14 / C))
     link = None
     if mode == "link":
-        link = RcclLink(0, 1, dev, particle_capacity=2048, photon_emission=True, exact=exact)
+        link = RcclLink(0, 1, dev, particle_capacity=2048, photon_emission=True)
+        link.set_bounded(exact)
         g.set_self_exchange(True)
     e = oa.Population(oa.ELECTRON, 4 * n); e.track_extras(2)
     e.upload(cell, x, ux, uy, uz, w, dx, dt); e.set_emission_state(tau0, np.arange(n, dtype=np.uint64))
