@@ -29,6 +29,7 @@
 // What a subdomain sends left arrives as its left neighbour's "recv_right".
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cstring>
 
 #include "link.hpp"
@@ -68,13 +69,19 @@ int link_plan(opal_link_t *l)
     for (unsigned back = 0; back < 3 && back <= newest; back++) {
         const unsigned e = newest - back;
         const LinkBounds *b = &l->h_bounds[e % LINK_RING];
-        // written by the unpack kernel of exchange e, at least LINK_ZONE exchanges ago: normally there already
-        while (b->seq != e + 1) {
-            hipError_t q = hipStreamQuery(l->stream);
-            if (q != hipSuccess && q != hipErrorNotReady) OPAL_HIP(q);
-            if (q == hipSuccess && b->seq != e + 1) {
-                // the stream has drained and the entry is not there: that exchange was not followed by an unpack
-                return OPAL_OK;  // fall back to the full size (both ends reach this verdict together)
+        // Written by the unpack kernel of exchange e, at least LINK_ZONE exchanges ago: normally there already.
+        // The wait must not have a timing-dependent way out -- a subdomain that gave up and shipped another
+        // size than its neighbour expects would hang the transport -- so it only ends in the entry or an error.
+        if (b->seq != e + 1) {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned long spins = 0;
+            while (b->seq != e + 1) {
+                if ((++spins & 0xfffff) == 0 &&
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                    set_error("link: the particle bounds of exchange %u never arrived (every whole-message exchange must "
+                              "be followed by the unpack of its arrivals on the link's stream)", e);
+                    return OPAL_ERR_LINK;
+                }
             }
         }
         for (int side = 0; side < 2; side++)

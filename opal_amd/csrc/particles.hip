@@ -1482,7 +1482,7 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         st = pops[i]->stream;
         b.n++;
     }
-    if (!b.n) return OPAL_OK;
+    if (!b.n) st = link->stream;  // nobody to unpack for: the kernel still files this exchange's bounds (link.cpp)
     if (zero_counts) {
         b.zero[0] = reinterpret_cast<unsigned *>(link_send(link, 0));
         b.zero[1] = reinterpret_cast<unsigned *>(link_send(link, 1));
@@ -1496,7 +1496,7 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.bounds = &link->d_bounds[(link->xseq - 1) % LINK_RING];
         b.seq = link->xseq;
     }
-    k_unpack<<<2 * b.n, 256, 0, st>>>(b);
+    k_unpack<<<b.n ? 2 * b.n : 1, 256, 0, st>>>(b);
     OPAL_HIP(hipGetLastError());
     if (zero_counts) link->counts_clean = true;
     // (only once the reservations since the last snapshot add up to a few per cent of the population: a
