@@ -166,6 +166,9 @@ int opal_pop_set_sort_interval(opal_pop_t *p, int interval);
  * per thread of the push kernels, [5] live particles and [6] non-empty cells at the last re-binning,
  * [7] host upper bound of the slots in use */
 int opal_pop_counters(const opal_pop_t *p, uint32_t *out);
+/* diagnostic: start != 0 begins recording the pushes' tile misses; start == 0 copies out[0] = misses seen and up to
+ * 4096 x (workgroup, slot, cell, tile base cell) into out (1 + 4 * 4096 int32) and stops */
+int opal_pop_debug_misses(opal_pop_t *p, int start, int32_t *out);
 /* level 1: carry chi, work, y, z for electrons (electron.rs:18-25) / chi, y, z, parent id for photons;
  * level 2 (electrons): also the optical depth and id that photon emission needs; 0 = off (default) */
 int opal_pop_track_extras(opal_pop_t *p, int on);

@@ -129,6 +129,7 @@ struct opal_pop {
     unsigned int *h_tab_slot;  // host copy of d_tab_slot (pop_plan_split)
     size_t tab_cap;
     unsigned int n_tab, n_sorted;
+    int *d_dbg;                // opal_pop_debug_misses
     unsigned int *d_count;     // sort scratch: ncells + 2
     size_t count_cap;
     double *d_partial;

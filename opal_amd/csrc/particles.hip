@@ -85,6 +85,7 @@ struct PushArgs {
     // the rest uniform chunks of BLOCK x ppt slots from n_sorted on.  n_tab = 0: uniform chunks throughout.
     const unsigned *tab_slot;
     unsigned n_tab, n_sorted;
+    int *dbg;  // diagnostic (opal_pop_debug_misses): [0] count, then (block, slot, cell, tile base cell) per tile miss
 };
 
 struct LdsFields {
@@ -236,7 +237,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         int s = min(max((int)fl, -1), 1);
         prev = xi - fl;
         xn = xn - fl;
-        newc = c + s;
+        newc = c_mem + s;  // from the stored cell: one wrap below brings it back into [0, size) whatever image c is
         idx = c + a.L + s;
         rel = rel + s;
     } else {
@@ -383,11 +384,17 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     const int c_n = have_n ? s_n.c : DEAD_CELL;
     // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin.  Slots that
     // hold far-away cells (particles that wrapped around a periodic domain, arrivals appended from both
-    // neighbours) must not drag the tile away from the bulk: when the cells of the first slots span more
-    // than a tile, the base is taken from the more populous half of that span.
-    {
-        const bool lv = c_n != DEAD_CELL;
-        int m = lv ? c_n : 0x7fffffff, M = lv ? c_n : (int)0x80000000;
+    // neighbours) must not drag the tile away from the bulk.
+    // A single periodic subdomain at least a tile long gets a MODULAR tile: tile cell t stands for interior cell
+    // (base + t) mod size, so the chunks at the two ends of the array keep the particles that wrapped around
+    // (they sit in slots sorted for the other end) in their tile.  The ghost cells a plain tile would have read
+    // hold copies of exactly those interior values, and synchronize would have folded the currents there.
+    const bool periodic = a.left_mode == EDGE_WRAP && a.right_mode == EDGE_WRAP;
+    const bool modular = periodic && a.size >= TILE;
+    const bool lv_n = c_n != DEAD_CELL;
+    auto block_minmax = [&](int v, int &lo, int &hi, bool again) {  // over the live first slots
+        int m = lv_n ? v : 0x7fffffff, M = lv_n ? v : (int)0x80000000;
+        if (again) __syncthreads();  // everyone has read the previous s_min / s_max
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             m = min(m, __shfl_xor(m, o));
@@ -397,20 +404,27 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             s_min[tid >> 6] = m;
             s_max[tid >> 6] = M;
         }
-    }
+        __syncthreads();
+        lo = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        hi = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    };
     if (DEPOSIT)
         for (int q = tid; q < 4 * TILE * REPL; q += BLOCK) s_acc[q] = 0.0;
-    __syncthreads();
-    int cmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
-    const int cmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    int cmin, cmax;
+    block_minmax(c_n, cmin, cmax, false);
+    int c_b = c_n;  // the cell this lane's first slot counts as when the base is chosen
+    if (modular && cmin != 0x7fffffff && cmin < TILE && cmax >= a.size - TILE) {  // block-uniform: both ends present
+        if (c_n >= a.size - TILE) c_b = c_n - a.size;  // the periodic image just below cell 0
+        block_minmax(c_b, cmin, cmax, true);
+    }
     if (cmin != 0x7fffffff && cmax - cmin > TILE_HI - TILE_LO) {  // block-uniform
+        // still wider than a tile: the base is taken from the more populous half of the span
         const int mid = cmin + (cmax - cmin) / 2;
-        const bool lv = c_n != DEAD_CELL;
-        const bool high = lv && c_n > mid;
-        int mh = high ? c_n : 0x7fffffff;
+        const bool high = lv_n && c_b > mid;
+        int mh = high ? c_b : 0x7fffffff;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mh = min(mh, __shfl_xor(mh, o));
-        int nh = __popcll(__ballot(high)), nl = __popcll(__ballot(lv && !high));
+        int nh = __popcll(__ballot(high)), nl = __popcll(__ballot(lv_n && !high));
         __syncthreads();  // everyone has read s_min / s_max
         if ((tid & 63) == 0) {
             s_min[tid >> 6] = mh;
@@ -426,18 +440,27 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     const int span = (cmin == 0x7fffffff || cmax - cmin > TILE_HI - TILE_LO) ? 0 : cmax - cmin;
     const int margin = tabled ? (TILE - span) / 2 : TILE_MARGIN;
     const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - margin;  // array index of tile cell 0
+    // array index behind tile cell j - base: the interior cell itself when the tile is modular
+    auto tile_index = [&](int j) {
+        if (modular) {
+            int cj = j - a.L;
+            cj += cj < 0 ? a.size : 0;
+            cj -= cj >= a.size ? a.size : 0;
+            j = cj + a.L;
+        }
+        return j;
+    };
     if (GATHER) {
         for (int q = tid; q < 6 * TILE; q += BLOCK) {
-            int comp = q / TILE, j = base + (q % TILE);
+            int comp = q / TILE, j = tile_index(base + (q % TILE));
             s_field[q] = (j >= 0 && j < a.len) ? a.eb[(size_t)comp * a.lenp + j] : 0.0;
         }
         __syncthreads();
     }
     int err = 0;
     // A single periodic subdomain: a particle that wrapped around sits in a chunk at the other end of
-    // the array.  Its periodic image (cell -1 or `size`, i.e. a ghost cell: E and B there are copies
-    // of the interior, and synchronize folds the currents back) lies inside this chunk's tile.
-    const bool periodic = a.left_mode == EDGE_WRAP && a.right_mode == EDGE_WRAP;
+    // the array.  Its periodic image lies inside this chunk's tile (a modular tile), or, on a domain shorter than
+    // a tile, in a ghost cell: E and B there are copies of the interior, and synchronize folds the currents back.
 
     // Main loop, software-pipelined: the next slot's 44 bytes are requested before the current particle
     // is processed, so HBM latency overlaps this lane's own arithmetic instead of relying on occupancy
@@ -474,7 +497,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         if (!in_tile && periodic) {
             int c2 = rel > HI ? c - a.size : c + a.size;
             int rel2 = c2 + a.L - base, j2 = c2 + a.L;
-            if (rel2 >= LO && rel2 <= HI && j2 >= REACH && j2 + REACH < a.len) {
+            if (rel2 >= LO && rel2 <= HI && (modular || (j2 >= REACH && j2 + REACH < a.len))) {
                 c = c2;
                 in_tile = true;
             }
@@ -496,6 +519,13 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
             double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
             const int cm = cp.cell[kc];
+            if (a.dbg) {
+                unsigned q = atomicAdd(reinterpret_cast<unsigned *>(a.dbg), 1u);
+                if (q < 4096) {
+                    a.dbg[1 + 4 * q] = (int)block; a.dbg[2 + 4 * q] = (int)(chunk0 + kc);
+                    a.dbg[3 + 4 * q] = cm; a.dbg[4 + 4 * q] = base - a.L;
+                }
+            }
             bool emits = false;
             process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err, emits);
             if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
@@ -546,7 +576,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             const double *row = s_acc + k2 * REPL;
 #pragma unroll 8
             for (int r = 0; r < REPL; r++) s += row[(r + tid) & (REPL - 1)];
-            int comp = k2 / TILE, j = base + (k2 % TILE);
+            int comp = k2 / TILE, j = tile_index(base + (k2 % TILE));
             if (s != 0.0 && j >= 0 && j < a.len) atomicAdd(a.jr + (size_t)comp * a.lenp + j, s);
         }
     }
@@ -1278,6 +1308,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
         a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
+    a.dbg = p->d_dbg;
     a.tab_slot = p->d_tab_slot;
     a.n_tab = p->n_tab;
     a.n_sorted = p->n_sorted;
@@ -1762,6 +1793,7 @@ int opal_pop_free(opal_pop_t *p)
     if (p->d_count) hipFree(p->d_count);
     if (p->d_emit_list) hipFree(p->d_emit_list);
     if (p->d_tab_slot) hipFree(p->d_tab_slot);
+    if (p->d_dbg) hipFree(p->d_dbg);
     free(p->h_tab_slot);
     free(p->h_cell_end);
     if (p->upper_event) hipEventDestroy(p->upper_event);
@@ -2052,6 +2084,27 @@ int opal_pop_counters(const opal_pop_t *p, uint32_t *out)
     out[5] = p->h_ctr->n_live;
     out[6] = p->h_ctr->n_nonempty;
     out[7] = (uint32_t)p->n_upper;
+    return OPAL_OK;
+}
+
+/* diagnostic: start (n > 0) or read and stop (out != null) recording the first tile misses of the pushes:
+ * out[0] = number of misses since the start, then up to 4096 x (workgroup, slot, cell, tile base cell) */
+int opal_pop_debug_misses(opal_pop_t *p, int start, int32_t *out)
+{
+    if (int rc = check_pop(p)) return rc;
+    if (start) {
+        if (!p->d_dbg) OPAL_HIP(hipMalloc(&p->d_dbg, sizeof(int) * (1 + 4 * 4096)));
+        OPAL_HIP(hipMemsetAsync(p->d_dbg, 0, sizeof(int) * (1 + 4 * 4096), p->stream));
+        return OPAL_OK;
+    }
+    if (!p->d_dbg || !out) {
+        set_error("opal_pop_debug_misses: not recording");
+        return OPAL_ERR_ARG;
+    }
+    OPAL_HIP(hipMemcpyAsync(out, p->d_dbg, sizeof(int) * (1 + 4 * 4096), hipMemcpyDeviceToHost, p->stream));
+    OPAL_HIP(hipStreamSynchronize(p->stream));
+    hipFree(p->d_dbg);
+    p->d_dbg = nullptr;
     return OPAL_OK;
 }
 

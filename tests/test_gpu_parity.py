@@ -296,6 +296,52 @@ def _two_stream_state(nx, npc, dx, seed):
     return cell, x, ux, uy, uz, w
 
 
+def test_wrapped_particles_stay_in_their_tile(oa, oracle):
+    """One periodic subdomain: particles that wrap around sit in slots sorted for the other end of the array.  The end
+    chunks' tiles are modular (tile cell t = interior cell (base + t) mod size), so 30 steps after a re-binning fast
+    counter-streaming beams still have no tile miss, and fields and energies follow the oracle (main.rs:238-267)."""
+    o = oracle
+    nx, npc, dx = 128, 1024, 500.0  # two cells per 2048-slot chunk, as dense runs have
+    dt = 0.95 * dx / C
+    rng = np.random.default_rng(77)
+    n = nx * npc
+    cell = np.repeat(np.arange(nx, dtype=np.int32), npc)
+    x = rng.random(n)
+    ux = 0.4 * (1.0 + 0.01 * rng.standard_normal(n)) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    z = np.zeros(n)
+    w = np.full(n, 20.0 * dx / npc)
+    g = oa.Grid.single(nx, 0.0, dx)
+    og = o.Grid.single(nx, 0.0, dx)
+    pe = oa.Population.from_soa(oa.ELECTRON, cell, x, ux, z, z, w, dx, dt)
+    pi = oa.Population.from_soa(oa.ION, cell, x, -ux, z, z, w, dx, dt)
+    a_pos = 9.109383e-31 / 1.672622e-27
+    pi.set_charge_state(1.0, 1.0, a_pos)
+    ope = o.Population.from_soa(o.ELECTRON, cell, x, ux, z, z, w, dx, dt)
+    opi = o.Population.from_soa(o.ION, cell, x, -ux, z, z, w, dx, dt)
+    opi.set_charge_state(1.0, 1.0, a_pos)
+    for p in (pe, pi):
+        p.sort(g)
+        p.set_sort_interval(0)
+    t = 0.0
+    for step in range(30):
+        g.clear()
+        pe.advance_deposit(g, dt)
+        pi.advance_deposit(g, dt)
+        g.synchronize(None, None, t, dt)
+        g.advance(dt)
+        assert o.world_step([og], [ope], [opi], True, t, dt, nthreads=2) == 0
+        t += dt
+    moved = pe.soa()
+    assert np.count_nonzero(moved["cell"][: 2 * npc] > nx // 2) > npc // 4  # the first slots did wrap around
+    for p in (pe, pi):
+        assert p.counters()["tile_misses"] == 0
+    _cmp_grids(g, og, ("Ex",), 1e-9)
+    for p, op in ((pe, ope), (pi, opi)):
+        ke, oke = p.total_kinetic_energy(), op.total_kinetic_energy()
+        assert abs(ke - oke) / oke < 1e-12
+        assert len(p) == len(op) == n
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_two_stream_steps(oa, oracle, fused):
     """40 steps of main.rs:238-267 (electrons + positrons-as-ions, periodic) against the oracle."""
