@@ -89,8 +89,10 @@ struct PushArgs {
 };
 
 struct LdsFields {
-    const double *f;  // [6][TILE]
-    __device__ double operator()(int comp, int j) const { return f[comp * TILE + j]; }
+    // [TILE][6]: the 18 values a particle gathers lie within 200 bytes of one address, so every ds_read of the gather
+    // takes the same address register with an immediate offset (component-major rows cost one address add per read)
+    const double *f;
+    __device__ double operator()(int comp, int j) const { return f[j * 6 + comp]; }
 };
 struct GlobalFields {
     const double *eb;
@@ -234,7 +236,8 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         xn = xi + r.dxi;
         double fl = floor(xn);
         // the reference steps the cell by the SIGN of floor(x) (one cell at most, electron.rs:319-327)
-        int s = min(max((int)fl, -1), 1);
+        int s;
+        asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s) : "v"((int)fl));  // min(max(floor, -1), 1) in one instruction
         prev = xi - fl;
         xn = xn - fl;
         newc = c_mem + s;  // from the stored cell: one wrap below brings it back into [0, size) whatever image c is
@@ -252,7 +255,9 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
     // that stepped outside [0, size); only those lanes look at the edge modes.
     bool deleted = false;
     int send_side = -1;
-    if (GATHER && (unsigned)newc >= (unsigned)a.size) {
+    // (the ballot makes the test a scalar branch: away from the subdomain's edges no lane of the wave has left, and
+    // the selects below are not even issued)
+    if (GATHER && __ballot((unsigned)newc >= (unsigned)a.size) && (unsigned)newc >= (unsigned)a.size) {
         const bool left = newc < 0;
         const int mode = left ? a.left_mode : a.right_mode;
         if (mode == EDGE_WRAP) {
@@ -453,7 +458,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     if (GATHER) {
         for (int q = tid; q < 6 * TILE; q += BLOCK) {
             int comp = q / TILE, j = tile_index(base + (q % TILE));
-            s_field[q] = (j >= 0 && j < a.len) ? a.eb[(size_t)comp * a.lenp + j] : 0.0;
+            s_field[(q % TILE) * 6 + comp] = (j >= 0 && j < a.len) ? a.eb[(size_t)comp * a.lenp + j] : 0.0;
         }
         __syncthreads();
     }

@@ -278,7 +278,7 @@ __device__ inline Pushed boris_push(V3 u, V3 E, V3 B, double alpha, double dt_ov
     // ion.rs:183 writes gamma as 1 + u^2 / (1 + sqrt(1 + u^2)), which is sqrt(1 + u^2); t = alpha / gamma
     double t = alpha * rsqrt_nr(1.0 + um2);
     V3 u_prime = u_minus + t * cross(u_minus, cB);
-    double t_prime = 2.0 * t / (1.0 + (t * t) * dot(cB, cB));
+    double t_prime = (2.0 * t) * rcp_nr(1.0 + (t * t) * dot(cB, cB));  // the denominator is >= 1
     V3 u_plus = u_minus + t_prime * cross(u_prime, cB);
     r.u = u_plus + alpha * E;
     double g2 = 1.0 + dot(r.u, r.u);
