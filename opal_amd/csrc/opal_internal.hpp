@@ -67,6 +67,9 @@ struct opal_grid {
     double *d_scalar; // scratch for reductions
     int *d_err;
     double *h_pin;    // pinned host scratch (>= 11 * len doubles)
+    // one word of mapped host memory: non-zero once a non-zero B has been uploaded or met by a push kernel launched
+    // in its B == 0 form (particles.hip, B0K); the host reads it without waiting to choose the kernel of later steps
+    int *h_bflag, *d_bflag;
     std::vector<double> damp_host;
     double cell_x(size_t c) const { return xmin_global + offset + (((double)c) - ((double)L)) * dx; }  // yee.rs:296
 };

@@ -157,13 +157,18 @@ __host__ __device__ inline GatherW gather_weights(double xi)
 
 // fields_at, yee.rs:499-529.  F is any accessor F(comp, cell_index) over the six
 // field components 0..5 = Ex Ey Ez Bx By Bz; j is the array index of the cell.
-template <class F>
+// B0: the caller knows B to be zero in every cell this gather can touch (see push_body) and skips reading it.
+template <bool B0 = false, class F>
 __host__ __device__ inline void gather(const F &f, int j, double xi, V3 &E, V3 &B)
 {
     GatherW g = gather_weights(xi);
     E.x = f(0, j - 1) * g.c0 + f(0, j) * g.c1 + f(0, j + 1) * g.c2;
     E.y = f(1, j - 1) * g.e0 + f(1, j) * g.e1 + f(1, j + 1) * g.e2 + f(1, j + 2) * g.e3;
     E.z = f(2, j - 1) * g.e0 + f(2, j) * g.e1 + f(2, j + 1) * g.e2 + f(2, j + 2) * g.e3;
+    if (B0) {
+        B = {0.0, 0.0, 0.0};
+        return;
+    }
     B.x = f(3, j);
     B.y = f(4, j - 1) * g.c0 + f(4, j) * g.c1 + f(4, j + 1) * g.c2;
     B.z = f(5, j - 1) * g.c0 + f(5, j) * g.c1 + f(5, j + 1) * g.c2;
@@ -210,10 +215,27 @@ __device__ inline double rcp_nr(double a)
 // The reference carries gamma in the struct and divides by it; here 1/gamma_old
 // is recomputed as 1/sqrt(1 + u.u) (equal up to rounding) so that gamma never
 // travels through HBM.
-template <bool EXTRAS>
+//
+// B0 = true is the same arithmetic with B == 0 put in: every term dropped below is an exact zero or an exact
+// identity of the general form (v x B = 0; tau = 0, so u* = tau^2 = 0, sigma = gamma'^2, t = 0, s = 1/(1 + 0) = 1 --
+// the Newton reciprocal of 1.0 is 1.0 -- and u_new = u'), so the two forms give the same numbers (up to the sign of
+// a zero) and a particle's result does not depend on which of them its wave took.
+template <bool EXTRAS, bool B0 = false>
 __device__ inline Pushed vay_push(V3 u, V3 E, V3 B, double alpha, double dt_over_dx, double dt)
 {
     Pushed r;
+    if (B0 && !EXTRAS) {
+        V3 u_prime = (u + alpha * E) + alpha * E;
+        double sigma = 1.0 + dot(u_prime, u_prime);
+        double rad = 0.25 * (sigma * sigma);
+        double g2 = 0.5 * sigma + rad * rsqrt_nr(rad);
+        double inv_gn = rsqrt_nr(g2);
+        r.u = u_prime;
+        r.gamma = g2 * inv_gn;
+        r.inv_gamma = inv_gn;
+        r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx * inv_gn;
+        return r;
+    }
     double inv_g = rsqrt_nr(1.0 + dot(u, u));
     V3 v = (SPEED_OF_LIGHT * inv_g) * u;
     V3 u_half = u + alpha * (E + cross(v, B));
@@ -267,9 +289,19 @@ __device__ inline Pushed photon_push(V3 k, V3 E, V3 B, double dt_over_dx)
 }
 
 // Ion::push, ion.rs:168-214 (Boris).  alpha = q dt / (2 M c) with q = Z* e, M = A m_p.
+// B0 = true: the same with B == 0 put in (both rotations add exact zeros: u_plus = u_minus), see vay_push.
+template <bool B0 = false>
 __device__ inline Pushed boris_push(V3 u, V3 E, V3 B, double alpha, double dt_over_dx)
 {
     Pushed r;
+    if (B0) {
+        r.u = (u + alpha * E) + alpha * E;
+        double g2 = 1.0 + dot(r.u, r.u);
+        r.inv_gamma = rsqrt_nr(g2);
+        r.gamma = g2 * r.inv_gamma;
+        r.dxi = SPEED_OF_LIGHT * r.u.x * dt_over_dx * r.inv_gamma;
+        return r;
+    }
     V3 cB = SPEED_OF_LIGHT * B;
     V3 u_minus = u + alpha * E;
     double um2 = dot(u_minus, u_minus);

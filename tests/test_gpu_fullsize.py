@@ -212,6 +212,59 @@ def _two_stream_checks(oa, nx, npc, steps, check_unfused):
         assert np.max(np.abs(ex1 - ex2)) < 1e-9 * np.max(np.abs(ex1))
 
 
+def test_b_zero_kernel_gives_the_general_kernels_numbers(oa):
+    """While the host has not heard of a non-zero B the paired launch runs the pushers' B == 0 form (exact zeros and
+    identities of electron.rs:268-330 / ion.rs:168-214 left out).  Same two-stream run twice: once as is, once with the
+    grid's flag raised (a non-zero By uploaded, then zeros again) so that the general kernel runs on the same all-zero
+    B.  Every particle must end up with the same bits (a zero may differ in sign), after 25 steps with re-binning off
+    (so that both runs add their currents in the same slot order up to the atomics' order)."""
+    nx, npc = 256, 512
+    runs = []
+    for general in (False, True):
+        sim = oa.Simulation(yaml_text=TWO_STREAM.format(nx=nx, npc=npc))
+        if general:
+            by = np.zeros(sim.grid.len)
+            by[3] = 1.0
+            sim.grid.set_raw("By", by)
+            sim.grid.set_raw("By", np.zeros(sim.grid.len))
+        sim.step(1)
+        sim.sync()
+        runs.append((sim.electrons.soa(), sim.ions.soa(), _interior(sim.grid, "jx")))
+    (e0, i0, j0), (e1, i1, j1) = runs
+    for a, b in ((e0, e1), (i0, i1)):
+        assert np.array_equal(a["cell"], b["cell"])
+        for f in ("x", "ux", "uy", "uz"):
+            assert np.array_equal(a[f], b[f]), f           # -0.0 == 0.0 here, everything else bit for bit
+    assert np.max(np.abs(j0 - j1)) <= 1e-13 * np.max(np.abs(j0))     # same taps, summed in another order
+
+
+def test_b_zero_kernel_notices_a_field(oa):
+    """A non-zero B met by a kernel launched in its B == 0 form (a laser that enters after the run has started; here: a
+    standing By uploaded and the flag withdrawn again with assume_b_zero): the workgroups that see it send their
+    particles down the general path at once and raise the flag, and later launches are general.  The run must equal
+    one that used the general kernel from the first step."""
+    nx, npc = 256, 256
+    res = []
+    for withdraw_flag in (True, False):
+        sim = oa.Simulation(yaml_text=TWO_STREAM.format(nx=nx, npc=npc))
+        g = sim.grid
+        # (period nx in the array index, so that the ghost cells hold their periodic images as in a real run)
+        g.set_raw("By", 2.0e-6 * np.sin(np.arange(g.len) * (2.0 * math.pi * 3.0 / nx)))
+        if withdraw_flag:
+            g.assume_b_zero()
+        sim.step(4)
+        sim.sync()
+        res.append((sim.electrons.soa(), sim.ions.soa(), _interior(g, "Ex"), _interior(g, "By")))
+    (e0, i0, ex0, by0), (e1, i1, ex1, by1) = res
+    assert np.max(np.abs(e0["uz"])) > 0.0                    # the field did bend them
+    for a, b in ((e0, e1), (i0, i1)):
+        assert np.array_equal(a["cell"], b["cell"])
+        for f in ("x", "ux", "uy", "uz"):
+            assert np.max(np.abs(a[f] - b[f])) <= 1e-12 * np.max(np.abs(b[f])), f
+    assert np.max(np.abs(ex0 - ex1)) <= 1e-11 * np.max(np.abs(ex1))
+    assert np.max(np.abs(by0 - by1)) <= 1e-11 * np.max(np.abs(by1))
+
+
 def test_configs1_both_species_full_size(oa):
     """BASELINE configs[1]: 4096 cells, 2441 e- + 2441 e+ per cell (2 x 9 998 336), the paired launch."""
     _two_stream_checks(oa, 4096, 2441, steps=12, check_unfused=True)
