@@ -36,7 +36,8 @@ struct PopCounters {
     unsigned int n_emit;       // electrons whose optical depth ran out in the last push (photon emission)
     unsigned int n_lost;       // photons that found no free slot (capacity is checked by the host first: stays 0)
     unsigned int n_dead;       // slots vacated (deleted or sent away) since the last re-binning
-    unsigned int pad[5];
+    unsigned int w_mixed;      // an arrival brought a weight other than the population's uniform one (see opal_pop::w_uniform)
+    unsigned int pad[4];
 };
 
 // EX_TAU_ABS, EX_TAU_ST, EX_BIRTH: a photon's optical depths against absorption / stimulated emission and its birth
@@ -133,6 +134,12 @@ struct opal_pop {
     size_t tab_cap;
     unsigned int n_tab, n_sorted;
     int *d_dbg;                // opal_pop_debug_misses
+    // Every particle uploaded so far carries the same weight w0 (a uniform plasma loaded with a fixed number per
+    // cell): the pushes then take it from their arguments instead of streaming 8 bytes per particle.  Arrivals
+    // are compared on the device (d_ctr->w_mixed, which the pushes read); anything else that writes weights into
+    // this population clears w_uniform on the host.
+    bool w_uniform;
+    double w0;
     unsigned int *d_count;     // sort scratch: ncells + 2
     size_t count_cap;
     double *d_partial;

@@ -85,6 +85,8 @@ struct PushArgs {
     // the rest uniform chunks of BLOCK x ppt slots from n_sorted on.  n_tab = 0: uniform chunks throughout.
     const unsigned *tab_slot;
     unsigned n_tab, n_sorted;
+    int w_uniform;  // every slot's weight is w0 unless ctr->w_mixed says otherwise (opal_pop::w_uniform)
+    double w0;
     int *b_flag;  // B0K kernels: raised when a tile holds a non-zero B (the grid's mapped host word)
     int *dbg;  // diagnostic (opal_pop_debug_misses): [0] count, then (block, slot, cell, tile base cell) per tile miss
 };
@@ -385,10 +387,12 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // Lanes past the end of the chunk load its last slot again (same cache lines, no extra HBM traffic) and are
     // masked by `have`: unconditional loads need neither an exec-mask branch nor zero-filled registers.
     const unsigned last = nloc - 1;  // nloc >= 1
+    const bool uniform_w = a.w_uniform && a.ctr->w_mixed == 0;
     auto fetch = [&](unsigned kk) {
         Slot sl;
         sl.c = ldk(cp.cell, kk); sl.x = ldk(cp.x, kk); sl.ux = ldk(cp.ux, kk); sl.uy = ldk(cp.uy, kk);
-        sl.uz = ldk(cp.uz, kk); sl.w = ldk(cp.w, kk);
+        sl.uz = ldk(cp.uz, kk);
+        sl.w = uniform_w ? a.w0 : ldk(cp.w, kk);  // block-uniform
         sl.prev = (MODE == MODE_DEPOSIT) ? ldk(cp.prev, kk) : 0.0;
         return sl;
     };
@@ -1000,6 +1004,8 @@ struct UnpackArgs {
     unsigned pop_cap;
     int my_size;
     unsigned *emit_list;  // electrons of an emission run: arrivals whose optical depth has run out join the list
+    int w_uniform;        // the population's weights are all w0 so far: an arrival with another raises ctr->w_mixed
+    double w0;
 };
 
 // up to three species per launch (blocks 2 s and 2 s + 1 belong to species s).  The first workgroup also files
@@ -1059,6 +1065,7 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
         a.cell[base + k] = *link_cell(msg, a.layout, a.slot, k) + (side == 1 ? a.my_size : 0);
 #pragma unroll
         for (int c = 0; c < 5; c++) a.f[c][base + k] = *link_field(msg, a.layout, a.slot, c, k);
+        if (a.w_uniform && *link_field(msg, a.layout, a.slot, 4, k) != a.w0) a.ctr->w_mixed = 1u;
         if (a.prev_x) a.prev_x[base + k] = *link_field(msg, a.layout, a.slot, 5, k);
         // a plain link's message does not carry the extras (diagnostics only: a particle that changes
         // subdomain restarts them); a link laid out for photon emission carries all of them
@@ -1335,6 +1342,8 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
         a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
+    a.w_uniform = p->w_uniform && p->species != OPAL_PHOTON;
+    a.w0 = p->w0;
     a.b_flag = g->d_bflag;
     a.dbg = p->d_dbg;
     a.tab_slot = p->d_tab_slot;
@@ -1521,6 +1530,8 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     u.nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     u.ctr = p->d_ctr;
     u.pop_cap = (unsigned)p->cap;
+    u.w_uniform = p->w_uniform;
+    u.w0 = p->w0;
     u.my_size = (int)g->size;
     u.emit_list = (p->emit_list_valid && p->emit_list_cap >= p->cap) ? p->d_emit_list : nullptr;
     if (!u.emit_list) p->emit_list_valid = false;  // arrivals the list does not know about
@@ -1862,6 +1873,9 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     OPAL_HIP(hipMemcpyAsync(p->d_uy[k], uy, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
     OPAL_HIP(hipMemcpyAsync(p->d_uz[k], uz, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
     OPAL_HIP(hipMemcpyAsync(p->d_w[k], w, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    p->w_uniform = n > 0;
+    p->w0 = n ? w[0] : 0.0;
+    for (size_t i = 1; i < n && p->w_uniform; i++) p->w_uniform = w[i] == p->w0;
     p->h_ctr->n_slots = (unsigned)n;
     OPAL_HIP(hipMemsetAsync(p->d_ctr, 0, sizeof(PopCounters), p->stream));
     OPAL_HIP(hipMemcpyAsync(&p->d_ctr->n_slots, &p->h_ctr->n_slots, sizeof(unsigned), hipMemcpyHostToDevice, p->stream));
