@@ -123,11 +123,13 @@ int opal_grid_write_rows(const double *rows, size_t n, const char *dir, size_t i
 /* ghost-inclusive component arrays (len doubles), for tests and for drivers that inject currents */
 int opal_grid_get_raw(const opal_grid_t *g, int comp, double *out);
 int opal_grid_set_raw(opal_grid_t *g, int comp, const double *in);
-/* The paired fused push has a form for B == 0 everywhere (electrostatic runs).  It is used until a non-zero B has been
- * uploaded with opal_grid_set_raw or met by a push (each workgroup checks its tile; one that finds a field takes the
- * general path and the following launches are general).  This call withdraws that knowledge: "B may be zero again" --
- * results never depend on it, only the speed of the next steps does. */
-int opal_grid_assume_b_zero(opal_grid_t *g);
+/* The paired fused push has an electrostatic form (Ey = Ez = B = 0 everywhere and uy = uz = 0 for every particle: it
+ * neither streams uy, uz nor gathers more than Ex).  It is used while every upload was of that kind and until a push
+ * meets a transverse field or momentum (each workgroup checks its tile and its population's flag; one that finds
+ * something takes the general path, and the following launches are general).  This call withdraws what the grid has
+ * heard so far: "the fields may be electrostatic again" -- results never depend on it, only the speed of the next
+ * steps does (populations that have been through a general push stay general until their next upload). */
+int opal_grid_assume_electrostatic(opal_grid_t *g);
 
 /* ------------------------------------------------------------------ Population */
 /* Population::new_empty (mod.rs:156); `capacity` slots are reserved on the device */

@@ -159,9 +159,9 @@ class Grid:
         assert a.shape == (self.len,)
         _check(self._lib.opal_grid_set_raw(self.h, COMP[name], _ptr(a)))
 
-    def assume_b_zero(self):
+    def assume_electrostatic(self):
         """Withdraw the knowledge that B is non-zero somewhere (the pushes check; only speed depends on it)."""
-        _check(self._lib.opal_grid_assume_b_zero(self.h))
+        _check(self._lib.opal_grid_assume_electrostatic(self.h))
 
 
 class Population:

@@ -54,7 +54,7 @@ SIGNATURES = {
     "opal_grid_write_data": (C.c_int, [vp, C.c_char_p, sz]),
     "opal_grid_get_raw": (C.c_int, [vp, C.c_int, vp]),
     "opal_grid_set_raw": (C.c_int, [vp, C.c_int, vp]),
-    "opal_grid_assume_b_zero": (C.c_int, [vp]),
+    "opal_grid_assume_electrostatic": (C.c_int, [vp]),
     "opal_pop_create": (C.c_int, [pp, C.c_int, sz, vp]),
     "opal_pop_free": (C.c_int, [vp]),
     "opal_pop_new": (C.c_int, [pp, C.c_int, sz, FN1, FN3, FN3, FN3, vp, vp, C.c_uint64, dbl, vp]),

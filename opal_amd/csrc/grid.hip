@@ -382,9 +382,9 @@ int opal_grid_build(opal_grid_t **out, int id, int numtasks, int left, int right
     OPAL_HIP(hipMalloc(&g->d_scalar, sizeof(double) * 8));
     OPAL_HIP(hipMalloc(&g->d_err, sizeof(int)));
     OPAL_HIP(hipHostMalloc(&g->h_pin, sizeof(double) * 11 * g->lenp));
-    OPAL_HIP(hipHostMalloc(&g->h_bflag, sizeof(int), hipHostMallocMapped));
-    *g->h_bflag = 0;  // the fields start at zero
-    OPAL_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_bflag), g->h_bflag, 0));
+    OPAL_HIP(hipHostMalloc(&g->h_esflag, sizeof(int), hipHostMallocMapped));
+    *g->h_esflag = 0;  // the fields start at zero
+    OPAL_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_esflag), g->h_esflag, 0));
     OPAL_HIP(hipMemsetAsync(g->d_eb[0], 0, 6 * nb, g->stream));
     OPAL_HIP(hipMemsetAsync(g->d_eb[1], 0, 6 * nb, g->stream));
     OPAL_HIP(hipMemsetAsync(g->d_jb[0], 0, 4 * nb, g->stream));
@@ -421,7 +421,7 @@ int opal_grid_free(opal_grid_t *g)
     hipFree(g->d_err);
     if (g->d_damp) hipFree(g->d_damp);
     hipHostFree(g->h_pin);
-    hipHostFree(g->h_bflag);
+    hipHostFree(g->h_esflag);
     delete g;
     return OPAL_OK;
 }
@@ -551,17 +551,17 @@ int opal_grid_set_raw(opal_grid_t *g, int comp, const double *in)
                                     : g->d_eb[g->cur] + (size_t)(comp - OPAL_EX) * g->lenp;
     OPAL_HIP(hipMemcpyAsync(dst, in, sizeof(double) * g->len, hipMemcpyHostToDevice, g->stream));
     OPAL_HIP(hipStreamSynchronize(g->stream));
-    if (comp >= OPAL_EX + 3)  // a magnetic component
+    if (comp > OPAL_EX)  // a transverse component: Ey, Ez or any of B
         for (size_t i = 0; i < g->len; i++)
-            if (in[i] != 0.0) *g->h_bflag = 1;
+            if (in[i] != 0.0) *g->h_esflag = 1;
     return OPAL_OK;
 }
 
-int opal_grid_assume_b_zero(opal_grid_t *g)
+int opal_grid_assume_electrostatic(opal_grid_t *g)
 {
     if (int rc = check_grid(g)) return rc;
     OPAL_HIP(hipStreamSynchronize(g->stream));  // no kernel that could still raise the flag is in flight
-    *g->h_bflag = 0;
+    *g->h_esflag = 0;
     return OPAL_OK;
 }
 

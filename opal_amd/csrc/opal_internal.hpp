@@ -37,7 +37,8 @@ struct PopCounters {
     unsigned int n_lost;       // photons that found no free slot (capacity is checked by the host first: stays 0)
     unsigned int n_dead;       // slots vacated (deleted or sent away) since the last re-binning
     unsigned int w_mixed;      // an arrival brought a weight other than the population's uniform one (see opal_pop::w_uniform)
-    unsigned int pad[4];
+    unsigned int hot_yz;       // some slot may hold a non-zero uy or uz (see opal_pop::cold_yz)
+    unsigned int pad[3];
 };
 
 // EX_TAU_ABS, EX_TAU_ST, EX_BIRTH: a photon's optical depths against absorption / stimulated emission and its birth
@@ -68,9 +69,9 @@ struct opal_grid {
     double *d_scalar; // scratch for reductions
     int *d_err;
     double *h_pin;    // pinned host scratch (>= 11 * len doubles)
-    // one word of mapped host memory: non-zero once a non-zero B has been uploaded or met by a push kernel launched
-    // in its B == 0 form (particles.hip, B0K); the host reads it without waiting to choose the kernel of later steps
-    int *h_bflag, *d_bflag;
+    // one word of mapped host memory: non-zero once a transverse field (Ey, Ez, B) has been uploaded or an
+    // electrostatic push launch (particles.hip, ES) has found its belief wrong somewhere; the host reads it without waiting to choose the kernel of later steps
+    int *h_esflag, *d_esflag;
     std::vector<double> damp_host;
     double cell_x(size_t c) const { return xmin_global + offset + (((double)c) - ((double)L)) * dx; }  // yee.rs:296
 };
@@ -140,6 +141,9 @@ struct opal_pop {
     // this population clears w_uniform on the host.
     bool w_uniform;
     double w0;
+    // Every uy and uz uploaded was zero and only electrostatic launches (particles.hip, ES) have pushed the
+    // population since: they keep it so, or raise d_ctr->hot_yz and the grid's flag when they cannot.
+    bool cold_yz;
     unsigned int *d_count;     // sort scratch: ncells + 2
     size_t count_cap;
     double *d_partial;

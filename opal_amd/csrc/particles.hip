@@ -87,7 +87,7 @@ struct PushArgs {
     unsigned n_tab, n_sorted;
     int w_uniform;  // every slot's weight is w0 unless ctr->w_mixed says otherwise (opal_pop::w_uniform)
     double w0;
-    int *b_flag;  // B0K kernels: raised when a tile holds a non-zero B (the grid's mapped host word)
+    int *es_flag;  // ES kernels: raised when the launch's belief fails somewhere (the grid's mapped host word)
     int *dbg;  // diagnostic (opal_pop_debug_misses): [0] count, then (block, slot, cell, tile base cell) per tile miss
 };
 
@@ -180,12 +180,14 @@ struct ChunkPtrs {
 // The per-particle body shared by the three modes.  FAST = the particle's stencil lies inside the
 // workgroup's LDS tile (fields from LDS, currents into the LDS accumulators); otherwise fields come
 // from global memory and the taps go to the grid with global atomics.
-template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool FAST, bool B0 = false>
+template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool FAST, bool ES = false>
 __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkPtrs &cp, const double *s_field,
                                                  double *s_acc, int base, int lane, unsigned kc, int c, int c_mem,
                                                  double xi, V3 u, double wt, double prev, int &err, bool &emits)
 {
     // c: the cell to work in (the periodic image when the caller picked one); c_mem: what the slot holds
+    // ES: the slot's uy and uz are zero (not even loaded, see push_body) and, with no transverse field, stay zero
+    if (ES) u.y = u.z = 0.0;
     const double uy_mem = u.y, uz_mem = u.z;
     constexpr bool GATHER = MODE != MODE_DEPOSIT;
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
@@ -196,14 +198,14 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         V3 E, B;
         if (FAST) {
             LdsFields f{s_field};
-            gather<B0>(f, rel, xi, E, B);
+            gather<ES>(f, rel, xi, E, B);
         } else {
             GlobalFields f{a.eb, a.lenp};
             gather(f, c + a.L, xi, E, B);
         }
         Pushed r;
         if (SPECIES == OPAL_ELECTRON) {
-            r = vay_push<EXTRAS != 0, B0>(u, E, B, a.alpha, a.dt_over_dx, a.dt);
+            r = vay_push<EXTRAS != 0, ES>(u, E, B, a.alpha, a.dt_over_dx, a.dt);
             if (EXTRAS) {
                 size_t i = cp.chunk0 + kc;
                 // each array is optional (block-uniform tests): a run only carries what its outputs ask for
@@ -230,7 +232,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                 }
             }
         } else {
-            r = boris_push<B0>(u, E, B, a.alpha, a.dt_over_dx);
+            r = boris_push<ES>(u, E, B, a.alpha, a.dt_over_dx);
         }
         if (!(r.dxi < 1.0)) err |= 1;  // electron.rs:313, ion.rs:199
         u = r.u;
@@ -341,17 +343,20 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
 //   MODE_DEPOSIT : YeeGrid::deposit's per-particle body, yee.rs:573-610.
 //   MODE_FUSED   : both in one pass (prev_x stays in registers).
 //
-// B0K: the kernel was launched in the belief that B is zero everywhere (an electrostatic run -- the reference's
-// two-stream benchmark): its fast path is the pushers' B == 0 form, the same arithmetic with the exact zeros and
-// identities left out (pic_device.hpp), so no particle's result depends on which kernel ran.  The belief is checked
-// where it matters: a workgroup that finds a non-zero B in its tile sends all its particles down the general
-// (global-memory) path and raises the grid's flag, which the host reads -- without waiting -- before later
-// launches and then stays with the general kernel.
-template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool B0K = false>
+// ES ("electrostatic"): the kernel was launched in the belief that nothing transverse exists -- Ey = Ez = B = 0
+// everywhere and uy = uz = 0 for every particle of the population: the reference's two-stream benchmark, any 1-D
+// electrostatic run.  Its fast path then neither loads uy and uz (16 of the 44 bytes a particle reads) nor gathers
+// anything but Ex, and the pushers and the deposit are the general ones with those zeros put in: every term that
+// drops out is an exact zero or an exact identity (pic_device.hpp), so no particle's result depends on which kernel
+// ran.  The belief is checked where it matters: a workgroup whose tile holds a transverse field, or whose population
+// has been flagged as carrying transverse momentum (ctr->hot_yz: arrivals, a field met earlier), sends all its
+// particles down the general (global-memory) path and raises the grid's flag, which the host reads -- without
+// waiting -- before later launches and then stays with the general kernel.
+template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool ES = false>
 __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, double *s_field, double *s_acc, int *s_min,
                                           int *s_max)
 {
-    static_assert(!B0K || (MODE == MODE_FUSED && EXTRAS == 0 && SPECIES != OPAL_PHOTON), "B0K: plain fused pushes only");
+    static_assert(!ES || (MODE == MODE_FUSED && EXTRAS == 0 && SPECIES != OPAL_PHOTON), "ES: plain fused pushes only");
     constexpr bool GATHER = MODE != MODE_DEPOSIT;
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
     const int tid = threadIdx.x;
@@ -390,8 +395,9 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     const bool uniform_w = a.w_uniform && a.ctr->w_mixed == 0;
     auto fetch = [&](unsigned kk) {
         Slot sl;
-        sl.c = ldk(cp.cell, kk); sl.x = ldk(cp.x, kk); sl.ux = ldk(cp.ux, kk); sl.uy = ldk(cp.uy, kk);
-        sl.uz = ldk(cp.uz, kk);
+        sl.c = ldk(cp.cell, kk); sl.x = ldk(cp.x, kk); sl.ux = ldk(cp.ux, kk);
+        sl.uy = ES ? 0.0 : ldk(cp.uy, kk);
+        sl.uz = ES ? 0.0 : ldk(cp.uz, kk);
         sl.w = uniform_w ? a.w0 : ldk(cp.w, kk);  // block-uniform
         sl.prev = (MODE == MODE_DEPOSIT) ? ldk(cp.prev, kk) : 0.0;
         return sl;
@@ -468,18 +474,21 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         }
         return j;
     };
-    bool tile_b0 = true;  // B0K: B is zero in every cell of the tile, as the launch assumed
+    bool tile_es = true;  // ES: no transverse field in the tile and no transverse momentum in the population, as assumed
     if (GATHER) {
-        int b_seen = 0;
+        int f_seen = 0;
         for (int q = tid; q < 6 * TILE; q += BLOCK) {
             int comp = q / TILE, j = tile_index(base + (q % TILE));
             double v = (j >= 0 && j < a.len) ? a.eb[(size_t)comp * a.lenp + j] : 0.0;
             s_field[(q % TILE) * 6 + comp] = v;
-            if (B0K) b_seen |= (comp >= 3 && v != 0.0);
+            if (ES) f_seen |= (comp != 0 && v != 0.0);
         }
-        if (B0K) {
-            tile_b0 = !__syncthreads_or(b_seen);
-            if (!tile_b0 && tid == 0) *a.b_flag = 1;  // mapped host memory: the host's next launches go general
+        if (ES) {
+            tile_es = !__syncthreads_or(f_seen) && a.ctr->hot_yz == 0;
+            if (!tile_es && tid == 0) {
+                a.ctr->hot_yz = 1;  // the general path below may well leave transverse momentum behind
+                *a.es_flag = 1;     // mapped host memory: the host's next launches go general
+            }
         } else {
             __syncthreads();
         }
@@ -521,7 +530,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         }
         if (!ok) continue;
         in_tile = rel >= LO && rel <= HI;
-        if (B0K && !tile_b0) {
+        if (ES && !tile_es) {
             pending |= 1u << p;  // block-uniform: this tile is not what the launch assumed
             continue;
         }
@@ -535,7 +544,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         }
         if (in_tile) {
             bool emits = false;
-            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, true, B0K>(a, cp, s_field, s_acc, base, lane, kc, c, c_mem, xi, u, wt, prev, err, emits);
+            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, true, ES>(a, cp, s_field, s_acc, base, lane, kc, c, c_mem, xi, u, wt, prev, err, emits);
             if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
         } else {
             pending |= 1u << p;
@@ -562,7 +571,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
             slow++;
         }
-        if (!B0K || tile_b0) atomicAdd(&a.ctr->n_slow, slow);  // (a tile sent down this path whole is not a miss)
+        if (!ES || tile_es) atomicAdd(&a.ctr->n_slow, slow);  // (a tile sent down this path whole is not a miss)
     }
     if (err) atomicOr(&a.ctr->err, err);
 
@@ -636,7 +645,7 @@ struct PairPlan {
     unsigned i0, in0, i1, in1;
 };
 
-template <int MODE, bool RHO, bool B0K = false>
+template <int MODE, bool RHO, bool ES = false>
 __global__ __launch_bounds__(BLOCK, OPAL_PAIR_WAVES) void k_push_pair(PushArgs ae, PushArgs ai, PairPlan plan)
 {
     __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
@@ -646,11 +655,11 @@ __global__ __launch_bounds__(BLOCK, OPAL_PAIR_WAVES) void k_push_pair(PushArgs a
     const unsigned ne = plan.en0 + plan.en1;
     if (b < ne) {
         b = b < plan.en0 ? plan.e0 + b : plan.e1 + (b - plan.en0);
-        push_body<OPAL_ELECTRON, MODE, RHO, 0, false, B0K>(ae, b, s_field, s_acc, s_min, s_max);
+        push_body<OPAL_ELECTRON, MODE, RHO, 0, false, ES>(ae, b, s_field, s_acc, s_min, s_max);
     } else {
         b -= ne;
         b = b < plan.in0 ? plan.i0 + b : plan.i1 + (b - plan.in0);
-        push_body<OPAL_ION, MODE, RHO, 0, false, B0K>(ai, b, s_field, s_acc, s_min, s_max);
+        push_body<OPAL_ION, MODE, RHO, 0, false, ES>(ai, b, s_field, s_acc, s_min, s_max);
     }
 }
 
@@ -1006,6 +1015,7 @@ struct UnpackArgs {
     unsigned *emit_list;  // electrons of an emission run: arrivals whose optical depth has run out join the list
     int w_uniform;        // the population's weights are all w0 so far: an arrival with another raises ctr->w_mixed
     double w0;
+    int *es_flag;         // an arrival with transverse momentum ends the electrostatic launches (ctr->hot_yz, grid flag)
 };
 
 // up to three species per launch (blocks 2 s and 2 s + 1 belong to species s).  The first workgroup also files
@@ -1066,6 +1076,11 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
 #pragma unroll
         for (int c = 0; c < 5; c++) a.f[c][base + k] = *link_field(msg, a.layout, a.slot, c, k);
         if (a.w_uniform && *link_field(msg, a.layout, a.slot, 4, k) != a.w0) a.ctr->w_mixed = 1u;
+        if (a.ctr->hot_yz == 0 &&
+            (*link_field(msg, a.layout, a.slot, 2, k) != 0.0 || *link_field(msg, a.layout, a.slot, 3, k) != 0.0)) {
+            a.ctr->hot_yz = 1u;
+            *a.es_flag = 1;
+        }
         if (a.prev_x) a.prev_x[base + k] = *link_field(msg, a.layout, a.slot, 5, k);
         // a plain link's message does not carry the extras (diagnostics only: a particle that changes
         // subdomain restarts them); a link laid out for photon emission carries all of them
@@ -1344,7 +1359,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     size_t per_block = (size_t)BLOCK * p->ppt;
     a.w_uniform = p->w_uniform && p->species != OPAL_PHOTON;
     a.w0 = p->w0;
-    a.b_flag = g->d_bflag;
+    a.es_flag = g->d_esflag;
     a.dbg = p->d_dbg;
     a.tab_slot = p->d_tab_slot;
     a.n_tab = p->n_tab;
@@ -1371,6 +1386,7 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     unsigned nblk;
     if (int rc = build_args(p, link, g, dt, mode, a, nblk)) return rc;
     if (mode != MODE_DEPOSIT) p->sorted_exact = false;
+    if (mode != MODE_DEPOSIT) p->cold_yz = false;  // only the paired electrostatic launch keeps that promise
     if (p->species == OPAL_ELECTRON && p->extras == 2 && p->d_ex[EX_TAU] && mode != MODE_DEPOSIT) {
         // the push compacts this step's emitters as it goes (see push_body): start an empty list
         if (int rc = ensure_emit_list(p)) return rc;
@@ -1479,9 +1495,10 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     if (!total) return OPAL_OK;
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, pe->stream);
-    // B still zero as far as the host has heard: the B == 0 form (which checks, see push_body)
-    if (mode == MODE_FUSED && *static_cast<volatile int *>(g->h_bflag) == 0)
-        k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    // nothing transverse as far as the host has heard: the electrostatic form (which checks, see push_body)
+    const bool es = mode == MODE_FUSED && pe->cold_yz && pi->cold_yz && *static_cast<volatile int *>(g->h_esflag) == 0;
+    if (!es && mode != MODE_DEPOSIT) pe->cold_yz = pi->cold_yz = false;  // a general push may leave uy, uz behind
+    if (es) k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     else if (mode == MODE_FUSED) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     else if (mode == MODE_ADVANCE) k_push_pair<MODE_ADVANCE, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     else k_push_pair<MODE_DEPOSIT, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
@@ -1532,6 +1549,7 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     u.pop_cap = (unsigned)p->cap;
     u.w_uniform = p->w_uniform;
     u.w0 = p->w0;
+    u.es_flag = g->d_esflag;
     u.my_size = (int)g->size;
     u.emit_list = (p->emit_list_valid && p->emit_list_cap >= p->cap) ? p->d_emit_list : nullptr;
     if (!u.emit_list) p->emit_list_valid = false;  // arrivals the list does not know about
@@ -1873,6 +1891,8 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     OPAL_HIP(hipMemcpyAsync(p->d_uy[k], uy, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
     OPAL_HIP(hipMemcpyAsync(p->d_uz[k], uz, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
     OPAL_HIP(hipMemcpyAsync(p->d_w[k], w, sizeof(double) * n, hipMemcpyHostToDevice, p->stream));
+    p->cold_yz = true;
+    for (size_t i = 0; i < n && p->cold_yz; i++) p->cold_yz = uy[i] == 0.0 && uz[i] == 0.0;
     p->w_uniform = n > 0;
     p->w0 = n ? w[0] : 0.0;
     for (size_t i = 1; i < n && p->w_uniform; i++) p->w_uniform = w[i] == p->w0;

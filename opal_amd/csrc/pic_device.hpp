@@ -157,18 +157,19 @@ __host__ __device__ inline GatherW gather_weights(double xi)
 
 // fields_at, yee.rs:499-529.  F is any accessor F(comp, cell_index) over the six
 // field components 0..5 = Ex Ey Ez Bx By Bz; j is the array index of the cell.
-// B0: the caller knows B to be zero in every cell this gather can touch (see push_body) and skips reading it.
-template <bool B0 = false, class F>
+// ES: the caller knows Ey, Ez and B to be zero in every cell this gather can touch (see push_body) and reads Ex only.
+template <bool ES = false, class F>
 __host__ __device__ inline void gather(const F &f, int j, double xi, V3 &E, V3 &B)
 {
     GatherW g = gather_weights(xi);
     E.x = f(0, j - 1) * g.c0 + f(0, j) * g.c1 + f(0, j + 1) * g.c2;
-    E.y = f(1, j - 1) * g.e0 + f(1, j) * g.e1 + f(1, j + 1) * g.e2 + f(1, j + 2) * g.e3;
-    E.z = f(2, j - 1) * g.e0 + f(2, j) * g.e1 + f(2, j + 1) * g.e2 + f(2, j + 2) * g.e3;
-    if (B0) {
+    if (ES) {
+        E.y = E.z = 0.0;
         B = {0.0, 0.0, 0.0};
         return;
     }
+    E.y = f(1, j - 1) * g.e0 + f(1, j) * g.e1 + f(1, j + 1) * g.e2 + f(1, j + 2) * g.e3;
+    E.z = f(2, j - 1) * g.e0 + f(2, j) * g.e1 + f(2, j + 1) * g.e2 + f(2, j + 2) * g.e3;
     B.x = f(3, j);
     B.y = f(4, j - 1) * g.c0 + f(4, j) * g.c1 + f(4, j + 1) * g.c2;
     B.z = f(5, j - 1) * g.c0 + f(5, j) * g.c1 + f(5, j + 1) * g.c2;

@@ -212,12 +212,12 @@ def _two_stream_checks(oa, nx, npc, steps, check_unfused):
         assert np.max(np.abs(ex1 - ex2)) < 1e-9 * np.max(np.abs(ex1))
 
 
-def test_b_zero_kernel_gives_the_general_kernels_numbers(oa):
-    """While the host has not heard of a non-zero B the paired launch runs the pushers' B == 0 form (exact zeros and
-    identities of electron.rs:268-330 / ion.rs:168-214 left out).  Same two-stream run twice: once as is, once with the
-    grid's flag raised (a non-zero By uploaded, then zeros again) so that the general kernel runs on the same all-zero
-    B.  Every particle must end up with the same bits (a zero may differ in sign), after 25 steps with re-binning off
-    (so that both runs add their currents in the same slot order up to the atomics' order)."""
+def test_electrostatic_kernel_gives_the_general_kernels_numbers(oa):
+    """While nothing transverse has been seen (Ey = Ez = B = 0, uy = uz = 0) the paired launch runs its electrostatic
+    form: uy, uz not streamed, only Ex gathered, the exact zeros and identities of electron.rs:268-330 /
+    ion.rs:168-214 left out.  Same two-stream step twice: once as is, once with the grid's flag raised (a non-zero By
+    uploaded, then zeros again) so that the general kernel runs on the same data.  Every particle must end up with
+    the same bits (a zero may differ in sign)."""
     nx, npc = 256, 512
     runs = []
     for general in (False, True):
@@ -238,9 +238,9 @@ def test_b_zero_kernel_gives_the_general_kernels_numbers(oa):
     assert np.max(np.abs(j0 - j1)) <= 1e-13 * np.max(np.abs(j0))     # same taps, summed in another order
 
 
-def test_b_zero_kernel_notices_a_field(oa):
+def test_electrostatic_kernel_notices_a_field(oa):
     """A non-zero B met by a kernel launched in its B == 0 form (a laser that enters after the run has started; here: a
-    standing By uploaded and the flag withdrawn again with assume_b_zero): the workgroups that see it send their
+    standing By uploaded and the flag withdrawn again with assume_electrostatic): the workgroups that see it send their
     particles down the general path at once and raise the flag, and later launches are general.  The run must equal
     one that used the general kernel from the first step."""
     nx, npc = 256, 256
@@ -251,7 +251,7 @@ def test_b_zero_kernel_notices_a_field(oa):
         # (period nx in the array index, so that the ghost cells hold their periodic images as in a real run)
         g.set_raw("By", 2.0e-6 * np.sin(np.arange(g.len) * (2.0 * math.pi * 3.0 / nx)))
         if withdraw_flag:
-            g.assume_b_zero()
+            g.assume_electrostatic()
         sim.step(4)
         sim.sync()
         res.append((sim.electrons.soa(), sim.ions.soa(), _interior(g, "Ex"), _interior(g, "By")))
