@@ -173,6 +173,10 @@ int opal_pop_set_sort_interval(opal_pop_t *p, int interval);
  * per thread of the push kernels, [5] live particles and [6] non-empty cells at the last re-binning,
  * [7] host upper bound of the slots in use */
 int opal_pop_counters(const opal_pop_t *p, uint32_t *out);
+/* Measurement aid (default on).  With 0 the pushes stream every attribute of every particle whatever the data hold:
+ * no electrostatic launches (opal_grid_assume_electrostatic) and no uniform weight taken from the launch arguments.
+ * Results are the same either way; bench.py uses it to report the general kernel beside the default. */
+int opal_set_elision(int on);
 /* diagnostic: start != 0 begins recording the pushes' tile misses; start == 0 copies out[0] = misses seen and up to
  * 4096 x (workgroup, slot, cell, tile base cell) into out (1 + 4 * 4096 int32) and stops */
 int opal_pop_debug_misses(opal_pop_t *p, int start, int32_t *out);

@@ -44,6 +44,11 @@ def device_count():
     return n.value
 
 
+def set_elision(on):
+    """Measurement aid: False makes the pushes stream every attribute whatever the data hold (see opal_set_elision)."""
+    _check(_lib.load().opal_set_elision(1 if on else 0))
+
+
 def set_device(i):
     _check(_lib.load().opal_set_device(i))
 

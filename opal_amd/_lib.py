@@ -71,6 +71,7 @@ SIGNATURES = {
     "opal_pop_set_sort_interval": (C.c_int, [vp, C.c_int]),
     "opal_pop_counters": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "opal_pop_debug_misses": (C.c_int, [vp, C.c_int, vp]),
+    "opal_set_elision": (C.c_int, [C.c_int]),
     "opal_pop_track_extras": (C.c_int, [vp, C.c_int]),
     "opal_pop_track_fields": (C.c_int, [vp, C.c_uint]),
     "opal_pop_keep_prev_x": (C.c_int, [vp, C.c_int]),

@@ -58,6 +58,7 @@ constexpr int TILE_LO = 3;      // a particle whose old cell sits at tile offset
 constexpr int TILE_HI = TILE - 4;  // gathers (rel-1..rel+2) and deposits (rel-3..rel+3) inside the tile
 
 enum { MODE_ADVANCE = 0, MODE_FUSED = 1, MODE_DEPOSIT = 2 };
+bool g_elision = true;  // opal_set_elision
 enum { EDGE_WRAP = 0, EDGE_DELETE = 1, EDGE_SEND = 2 };
 
 struct PushArgs {
@@ -1357,7 +1358,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
         a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
-    a.w_uniform = p->w_uniform && p->species != OPAL_PHOTON;
+    a.w_uniform = g_elision && p->w_uniform && p->species != OPAL_PHOTON;
     a.w0 = p->w0;
     a.es_flag = g->d_esflag;
     a.dbg = p->d_dbg;
@@ -1496,7 +1497,7 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, pe->stream);
     // nothing transverse as far as the host has heard: the electrostatic form (which checks, see push_body)
-    const bool es = mode == MODE_FUSED && pe->cold_yz && pi->cold_yz && *static_cast<volatile int *>(g->h_esflag) == 0;
+    const bool es = g_elision && mode == MODE_FUSED && pe->cold_yz && pi->cold_yz && *static_cast<volatile int *>(g->h_esflag) == 0;
     if (!es && mode != MODE_DEPOSIT) pe->cold_yz = pi->cold_yz = false;  // a general push may leave uy, uz behind
     if (es) k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     else if (mode == MODE_FUSED) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
@@ -2154,6 +2155,12 @@ int opal_pop_counters(const opal_pop_t *p, uint32_t *out)
 
 /* diagnostic: start (n > 0) or read and stop (out != null) recording the first tile misses of the pushes:
  * out[0] = number of misses since the start, then up to 4096 x (workgroup, slot, cell, tile base cell) */
+int opal_set_elision(int on)
+{
+    g_elision = on != 0;
+    return OPAL_OK;
+}
+
 int opal_pop_debug_misses(opal_pop_t *p, int start, int32_t *out)
 {
     if (int rc = check_pop(p)) return rc;

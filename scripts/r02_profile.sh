@@ -7,7 +7,7 @@ O=$R/gpurun_out/${1:-r02_prof}
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--no-cpu-baseline --no-secondary"
+ARGS="--no-cpu-baseline --no-secondary $OPAL_PROFILE_ARGS"  # e.g. OPAL_PROFILE_ARGS=--no-elision
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/bench_under_kt.json 2> $O/kt.log
 echo "kernel-trace done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_sq -o sq -- python3 $R/bench.py $ARGS --steps 5 --warmup 2 > /dev/null 2> $O/pmc_sq.log

@@ -6,7 +6,8 @@
                            MI355X_MICROARCH.md prescribes (FETCH_SIZE counts half of a coalesced streaming read)
   <tag>_pmc_sq.json        SQ / GRBM counters per launch of the fused kernel and what follows from them
   traffic.json             HBM bytes per particle-update, read by bench.py for roofline.traffic
-usage: summarise_profile.py gpurun_out/r02_prof_b r02
+usage: summarise_profile.py gpurun_out/r02_prof_b r02 [traffic-key]     (traffic-key: two_stream (default),
+       two_stream_no_elision, laser_plasma ... -- the entry of traffic.json this run describes)
 """
 import collections
 import csv
@@ -18,7 +19,8 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-KERNEL = "k_push_pair<1, true>"
+tkey = sys.argv[3] if len(sys.argv) > 3 else "two_stream"
+KERNEL = "k_push_pair<1, true"  # <1, true, true> is the electrostatic launch, <1, true, false> the general one
 
 
 def per_launch(path):
@@ -46,11 +48,12 @@ rd = 2.0 * f["FETCH_SIZE"]["mean"] * 1024.0
 wr = w["WRITE_SIZE"]["mean"] * 1024.0
 hbm = {
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 5 --warmup 2 "
-            "--no-cpu-baseline --no-secondary` (N=1, the default 1e8-particle workload), per launch of the fused kernel "
-            "(one launch = electrons + positrons). Units KiB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
-            "counts half of a coalesced streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for "
-            "streaming stores. Written bytes are BELOW the algorithmic 36 B/update because the kernel does not write "
-            "back attributes that no lane of a wave changed (uy, uz and most cell indices in this electrostatic run).",
+            "--no-cpu-baseline --no-secondary` plus the arguments recorded in the bench line beside this file, per "
+            "launch of the fused kernel (one launch = both species). Units KiB. gfx950 correction "
+            "(MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half of a coalesced streaming read, so read bytes = "
+            "2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for streaming stores. Bytes below the algorithmic 44 + 36 "
+            "per update are what the kernel does not move: a uniform weight, uy / uz of an electrostatic run, "
+            "write-back of attributes no lane of a wave changed (DESIGN.md 4.1).",
     "kernel": name,
     "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"],
     "particle_updates_per_launch": n,
@@ -62,8 +65,12 @@ hbm = {
     "hbm_GBps_actual": (rd + wr) / (avg_ns * 1e-9) / 1e9 if avg_ns else None,
 }
 json.dump(hbm, open(os.path.join(P, f"{tag}_pmc_hbm.json"), "w"), indent=1)
-json.dump({"hbm_bytes_per_particle_update": (rd + wr) / n, "source": f"profiles/{tag}_pmc_hbm.json"},
-          open(os.path.join(P, "traffic.json"), "w"), indent=1)
+tpath = os.path.join(P, "traffic.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+if "hbm_bytes_per_particle_update" in traffic:  # the single-entry layout of earlier rounds
+    traffic = {}
+traffic[tkey] = {"hbm_bytes_per_particle_update": (rd + wr) / n, "source": f"profiles/{tag}_pmc_hbm.json"}
+json.dump(traffic, open(tpath, "w"), indent=1)
 
 _, s1 = per_launch(os.path.join(src, "pmc_sq", "sq_counter_collection.csv"))
 _, s2 = per_launch(os.path.join(src, "pmc_sq2", "sq2_counter_collection.csv"))
