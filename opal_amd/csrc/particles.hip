@@ -42,6 +42,9 @@ constexpr int BLOCK = 256;
 #ifndef OPAL_MAX_PPT
 #define OPAL_MAX_PPT 8  // particles per thread of a push workgroup, at most
 #endif
+#ifndef OPAL_ES_PPT
+#define OPAL_ES_PPT 16  // the same for a population the electrostatic launch serves (see pop_max_ppt)
+#endif
 #ifndef OPAL_TILE
 #define OPAL_TILE 64
 #endif
@@ -59,6 +62,18 @@ constexpr int TILE_HI = TILE - 4;  // gathers (rel-1..rel+2) and deposits (rel-3
 
 enum { MODE_ADVANCE = 0, MODE_FUSED = 1, MODE_DEPOSIT = 2 };
 bool g_elision = true;  // opal_set_elision
+
+// Slots per thread of a push workgroup, at most.  The electrostatic launch moves 38 bytes per particle instead of 62-80,
+// so a workgroup's fixed cost (tile set-up, the replica fold and its atomics) weighs twice as much: with 1e8 particles
+// chunks twice as long are worth +6 % (the general kernel loses 5 % with them).  Only where the launch still has
+// thousands of workgroups per species, though: at 1e7 particles per species the longer chunks cost 5-8 % (the chip
+// holds ~2000 workgroups at a time, and a short launch is all ragged edge).
+int pop_max_ppt(const opal_pop_t *p)
+{
+    if (!(g_elision && p->cold_yz && p->species != OPAL_PHOTON)) return OPAL_MAX_PPT;
+    const size_t by_size = p->n_upper / ((size_t)BLOCK * 8192);  // keep >= 8192 workgroups per species
+    return (int)std::min<size_t>(OPAL_ES_PPT, std::max<size_t>(OPAL_MAX_PPT, by_size));
+}
 enum { EDGE_WRAP = 0, EDGE_DELETE = 1, EDGE_SEND = 2 };
 
 struct PushArgs {
@@ -375,7 +390,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         if (chunk0 >= n) return;
         nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
     }
-    const int iters = (int)((nloc + BLOCK - 1) / BLOCK);  // <= OPAL_MAX_PPT
+    const int iters = (int)((nloc + BLOCK - 1) / BLOCK);  // <= pop_max_ppt <= 32 (the masks below)
 
     ChunkPtrs cp;
     cp.cell = a.cell + chunk0;
@@ -1707,9 +1722,9 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
         hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
         p->ctr_pending = false;
     }
-    // the chunk table: slot ranges of the push workgroups, cut every 2048 slots and every CHUNK_CELLS cells
+    // the chunk table: slot ranges of the push workgroups, cut every BLOCK x pop_max_ppt slots and every CHUNK_CELLS cells
     {
-        const unsigned N = (unsigned)p->n_upper, chunk = BLOCK * OPAL_MAX_PPT;
+        const unsigned N = (unsigned)p->n_upper, chunk = BLOCK * pop_max_ppt(p);
         const unsigned K1 = (N + chunk - 1) / chunk, K2 = (unsigned)((ncells + CHUNK_CELLS - 1) / CHUNK_CELLS);
         const unsigned M = N ? K1 + K2 : 0;
         if (M + 1 > p->tab_cap) {
@@ -1734,7 +1749,7 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
     double per_cell = (double)p->h_ctr->n_live / ne;
     int ppt = (int)((TILE / 4) * per_cell / BLOCK);
-    p->ppt = std::max(1, std::min(OPAL_MAX_PPT, ppt));
+    p->ppt = std::max(1, std::min(pop_max_ppt(p), ppt));
     return OPAL_OK;
 }
 
@@ -1927,6 +1942,11 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
                 for (size_t c = 1; c < ncells; c++)
                     if (!p->h_cell_end[c]) p->h_cell_end[c] = p->h_cell_end[c - 1];  // empty cell
                 p->n_cell_end = ncells;
+                // uniform chunks until the first re-binning: about a quarter of a tile each, as do_sort sizes them
+                size_t nonempty = 1;
+                for (size_t i = 1; i < n; i++) nonempty += cell[i] != cell[i - 1];
+                int ppt = (int)((TILE / 4) * ((double)n / (double)nonempty) / BLOCK);
+                p->ppt = std::max(1, std::min(pop_max_ppt(p), ppt));
             }
         }
     }
