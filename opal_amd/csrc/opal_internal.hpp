@@ -72,6 +72,9 @@ struct opal_grid {
     // one word of mapped host memory: non-zero once a transverse field (Ey, Ez, B) has been uploaded or an
     // electrostatic push launch (particles.hip, ES) has found its belief wrong somewhere; the host reads it without waiting to choose the kernel of later steps
     int *h_esflag, *d_esflag;
+    // false on the steps of an opal_sim_step call whose rho nobody can observe (all but the last): the paired fused
+    // push then leaves the rho row at zero instead of depositing a diagnostic the next step's clear would erase
+    bool want_rho = true;
     std::vector<double> damp_host;
     double cell_x(size_t c) const { return xmin_global + offset + (((double)c) - ((double)L)) * dx; }  // yee.rs:296
 };

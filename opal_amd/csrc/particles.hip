@@ -1514,8 +1514,11 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     // nothing transverse as far as the host has heard: the electrostatic form (which checks, see push_body)
     const bool es = g_elision && mode == MODE_FUSED && pe->cold_yz && pi->cold_yz && *static_cast<volatile int *>(g->h_esflag) == 0;
     if (!es && mode != MODE_DEPOSIT) pe->cold_yz = pi->cold_yz = false;  // a general push may leave uy, uz behind
-    if (es) k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    else if (mode == MODE_FUSED) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    const bool rho = g->want_rho || !g_elision;  // (opal_sim_step: only the last step's rho can be observed)
+    if (es && rho) k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    else if (es) k_push_pair<MODE_FUSED, false, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    else if (mode == MODE_FUSED && rho) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
+    else if (mode == MODE_FUSED) k_push_pair<MODE_FUSED, false><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     else if (mode == MODE_ADVANCE) k_push_pair<MODE_ADVANCE, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     else k_push_pair<MODE_DEPOSIT, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
     prof_end(kid, pe->stream);

@@ -621,7 +621,14 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             lz = 2.0 * r * laser_z_cb(s->t, xs, &lp);
         }
     };
+    // rho is a diagnostic (yee.rs:606-609: no operator reads it) that every step's clear erases: only the one the
+    // last step of this call leaves behind can be looked at, so only that step's paired push deposits it
+    struct RhoGuard {
+        opal_grid_t *g;
+        ~RhoGuard() { g->want_rho = true; }
+    } rho_guard{s->grid};
     for (size_t k = 0; k < n; k++) {
+        s->grid->want_rho = k + 1 == n;
         if (linked && !(s->fused && s->current_deposition && !qed)) {
             // The reference's operator order across subdomains (main.rs:240-267) with the leavers of every
             // species in ONE message per neighbour.  Without current deposition the halo does not depend on
