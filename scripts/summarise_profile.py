@@ -10,6 +10,7 @@ usage: summarise_profile.py gpurun_out/r02_prof_b r02 [traffic-key]     (traffic
        two_stream_no_elision, laser_plasma ... -- the entry of traffic.json this run describes)
 """
 import collections
+import re
 import csv
 import json
 import os
@@ -20,7 +21,14 @@ src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 tkey = sys.argv[3] if len(sys.argv) > 3 else "two_stream"
-KERNEL = "k_push_pair<1, true"  # <1, true, true> is the electrostatic launch, <1, true, false> the general one
+# k_push_pair<FUSED, RHO, ES>: ES = the electrostatic launch; RHO = false on all but the last step of a
+# sim.step() call.  The variant with the most launches in the run is the one summarised.
+calls = collections.Counter()
+for r in csv.DictReader(open(os.path.join(src, "kt", "kt_kernel_stats.csv"))):
+    if "k_push_pair<1, " in r["Name"]:
+        calls[re.search(r"k_push_pair<[^>]*>", r["Name"]).group(0)] = int(r["Calls"])
+KERNEL = calls.most_common(1)[0][0]
+print("summarising", KERNEL, dict(calls))
 
 
 def per_launch(path):
