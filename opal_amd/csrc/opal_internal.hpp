@@ -29,7 +29,7 @@ struct PopCounters {
     unsigned int n_deleted;    // particles removed at open edges since last reset
     unsigned int n_sent_left;  // leavers packed for the left / right neighbour (this exchange)
     unsigned int n_sent_right;
-    unsigned int n_slow;       // deposits/gathers that missed the LDS tile since last sort
+    unsigned int n_slow;       // particles that missed the LDS tile (pushed through the slow path) since last sort
     int err;                   // bit 0: dxi >= 1; bit 1: gather index; bit 2: deposit index; bit 3: leaver overflow
     unsigned int n_live;       // written by sort / count kernels
     unsigned int n_nonempty;   // non-empty cells at last sort
@@ -38,7 +38,8 @@ struct PopCounters {
     unsigned int n_dead;       // slots vacated (deleted or sent away) since the last re-binning
     unsigned int w_mixed;      // an arrival brought a weight other than the population's uniform one (see opal_pop::w_uniform)
     unsigned int hot_yz;       // some slot may hold a non-zero uy or uz (see opal_pop::cold_yz)
-    unsigned int pad[3];
+    unsigned int n_slow_pass;  // wave passes through the slow path since last sort (what the misses cost, see maybe_sort)
+    unsigned int pad[2];
 };
 
 // EX_TAU_ABS, EX_TAU_ST, EX_BIRTH: a photon's optical depths against absorption / stimulated emission and its birth

@@ -566,28 +566,41 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             pending |= 1u << p;
         }
     }
-    // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.
-    if (pending) {
-        unsigned slow = 0;
-        for (int p = 0; p < iters; p++) {
-            if (!(pending & (1u << p))) continue;
-            unsigned kc = (unsigned)p * BLOCK + tid;
-            V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
-            double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
-            const int cm = cp.cell[kc];
-            if (a.dbg) {
-                unsigned q = atomicAdd(reinterpret_cast<unsigned *>(a.dbg), 1u);
-                if (q < 4096) {
-                    a.dbg[1 + 4 * q] = (int)block; a.dbg[2 + 4 * q] = (int)(chunk0 + kc);
-                    a.dbg[3 + 4 * q] = cm; a.dbg[4 + 4 * q] = base - a.L;
+    // Particles outside the tile (drifted since the last re-binning, or fresh arrivals): rare.  Counted twice for the
+    // re-binning policy: per particle, and per wave pass -- a wave goes through the slow path once per loop iteration
+    // in which ANY of its lanes has a pending particle, whether that is one lane or all 64.  A tail chunk full of
+    // fresh arrivals that all miss costs a handful of passes, not hundreds of isolated misses.
+    unsigned any_pending = pending;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) any_pending |= __shfl_xor(any_pending, o);
+    if (any_pending) {  // wave-uniform
+        unsigned slow_wave = (unsigned)__popc(pending);  // this lane's, then the wave's
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) slow_wave += __shfl_xor(slow_wave, o);
+        if (pending) {
+            for (int p = 0; p < iters; p++) {
+                if (!(pending & (1u << p))) continue;
+                unsigned kc = (unsigned)p * BLOCK + tid;
+                V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
+                double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
+                const int cm = cp.cell[kc];
+                if (a.dbg) {
+                    unsigned q = atomicAdd(reinterpret_cast<unsigned *>(a.dbg), 1u);
+                    if (q < 4096) {
+                        a.dbg[1 + 4 * q] = (int)block; a.dbg[2 + 4 * q] = (int)(chunk0 + kc);
+                        a.dbg[3 + 4 * q] = cm; a.dbg[4 + 4 * q] = base - a.L;
+                    }
                 }
+                bool emits = false;
+                process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err, emits);
+                if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
             }
-            bool emits = false;
-            process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err, emits);
-            if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
-            slow++;
         }
-        if (!ES || tile_es) atomicAdd(&a.ctr->n_slow, slow);  // (a tile sent down this path whole is not a miss)
+        // (a tile sent down this path whole by the electrostatic launch is not a miss)
+        if ((tid & 63) == 0 && (!ES || tile_es)) {
+            atomicAdd(&a.ctr->n_slow_pass, (unsigned)__popc(any_pending));
+            atomicAdd(&a.ctr->n_slow, slow_wave);
+        }
     }
     if (err) atomicOr(&a.ctr->err, err);
 
@@ -940,6 +953,7 @@ __global__ void k_sort_finish(PopCounters *ctr)
 {
     ctr->n_slots = ctr->n_live;
     ctr->n_slow = 0;
+    ctr->n_slow_pass = 0;
     ctr->n_dead = 0;
 }
 
@@ -1775,10 +1789,16 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
     // chunk table, 0.36 at 2000 and 5000 against 0.385 at 800: a miss costs far more than its own global atomics,
     // because the workgroup it sits in finishes late, and misses arrive in bursts (a bunch outruns its tile), so
     // a high price just triggers the re-binning one check earlier
-#ifndef OPAL_MISS_NS
-#define OPAL_MISS_NS 2000.0
+    // Two prices: a wave's pass through the slow path (its workgroup finishes that much later) and each particle in
+    // it (15 global atomics that contend with their neighbours').  An isolated miss costs their sum, ~2 us as before;
+    // 64 lanes missing together cost one pass and 64 small prices, not 64 passes.
+#ifndef OPAL_PASS_NS
+#define OPAL_PASS_NS 1900.0
 #endif
-    constexpr double miss_ns = OPAL_MISS_NS;
+#ifndef OPAL_MISS_NS
+#define OPAL_MISS_NS 100.0
+#endif
+    constexpr double miss_ns = OPAL_MISS_NS, pass_ns = OPAL_PASS_NS;
     if (p->steps_since_sort % check_every != 0) return OPAL_OK;
     // The counters are copied to pinned memory asynchronously and read at the NEXT check, check_every steps
     // later: waiting for that older copy keeps the host at most ~2 check intervals ahead of the device (so the
@@ -1814,7 +1834,7 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
         }
         return OPAL_OK;
     }
-    double lost_ms = (double)seen.n_slow * miss_ns * 1e-6;
+    double lost_ms = ((double)seen.n_slow_pass * pass_ns + (double)seen.n_slow * miss_ns) * 1e-6;
     if (lost_ms > sort_ms) return do_sort(p, g);
     return OPAL_OK;
 }
