@@ -209,7 +209,14 @@ def main():
             t += dt
         dump(outdir, rank, g, pe, pi)
     else:
-        sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc), rank=rank, numtasks=world, link=link)
+        text = YAML.format(nx=nx, npc=npc)
+        if mode == "sim_es":  # nothing transverse: the linked step runs the electrostatic launch
+            text = text.replace(" uy: 0.01 * nrand", " uy: 0.0").replace(" uz: 0.01 * nrand", " uz: 0.0")
+        if mode == "sim_half":  # transverse momenta in the left half of the domain only: the other subdomains start in
+            # the electrostatic launch and meet hot arrivals and the fields the left half radiates
+            half = f"step(x, 0.0, {0.5 * nx * dx!r})"
+            text = text.replace(" uy: 0.01 * nrand", f" uy: 0.01 * nrand * {half}").replace(" uz: 0.01 * nrand", f" uz: 0.01 * nrand * {half}")
+        sim = oa.Simulation(yaml_text=text, rank=rank, numtasks=world, link=link)
         sim.set_fused(bool(fused))
         sim.set_overlap(nx >= 512)  # the optional overlapped step: edge chunks, exchange on a second stream, bulk chunks
         sim.electrons.set_sort_interval(16)  # re-bin on a fixed schedule so that the test crosses re-binnings

@@ -64,8 +64,9 @@ def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused
     assert total == nx * npc
 
 
-@pytest.mark.parametrize("world,fused,nx", [(2, 1, 64), (2, 0, 64), (2, 1, 512), (3, 1, 768)])
-def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx):
+@pytest.mark.parametrize("world,fused,nx,mode", [(2, 1, 64, "sim"), (2, 0, 64, "sim"), (2, 1, 512, "sim"), (3, 1, 768, "sim"),
+                                                 (2, 1, 64, "sim_es"), (3, 1, 768, "sim_es"), (2, 1, 512, "sim_half")])
+def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx, mode):
     """The YAML driver's linked step: leavers of both species + halo in ONE message per neighbour (fused), or
     the reference's operator order with the leavers in one message and the halo in a second (fused = 0)."""
     o = oracle
@@ -74,8 +75,15 @@ def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx
     npc, steps = 16, 15 if nx == 64 else 40
     dx = 1.0e-8
     dt = 0.95 * dx / C
-    _launch("_gloo_hip_worker.py", world, ["sim", tmp_path, nx, npc, steps, fused])
+    # "sim_es": the same with uy = uz = 0 -- arrivals and leavers of the electrostatic launch, uniform weights checked;
+    # "sim_half": transverse momenta in the left half only -- the right subdomain starts electrostatic and has to
+    # notice the hot arrivals and the radiated fields
+    _launch("_gloo_hip_worker.py", world, [mode, tmp_path, nx, npc, steps, fused])
     got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    if mode == "sim_es":
+        assert all(np.all(g["e_uy"] == 0.0) and np.all(g["i_uz"] == 0.0) for g in got)
+    if mode == "sim_half":
+        assert np.all(got[-1]["init_e_uy"] == 0.0) and np.any(got[-1]["e_uy"] != 0.0)
     st_e = [tuple(g[f"init_e_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
     st_i = [tuple(g[f"init_i_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
     grids, pes, pis = _oracle_world(o, world, nx, dx, dt, st_e, st_i, steps)
