@@ -291,6 +291,7 @@ int opal_absorb(opal_pop_t *e, opal_pop_t *ph, const opal_grid_t *grid, uint64_t
         set_error("opal_absorb: needs an electron population, a photon population and their grid");
         return OPAL_ERR_ARG;
     }
+    e->cold_yz = false;  // this pass rewrites the electrons' momenta (see opal_pop::cold_yz)
     if (!e->extras || !e->d_ex[EX_CHI] || !e->d_ex[EX_ID]) {
         set_error("opal_absorb: the electrons do not carry chi and ids (opal_pop_track_fields)");
         return OPAL_ERR_ARG;

@@ -45,6 +45,9 @@ constexpr int BLOCK = 256;
 #ifndef OPAL_ES_PPT
 #define OPAL_ES_PPT 16  // the same for a population the electrostatic launch serves (see pop_max_ppt)
 #endif
+#ifndef OPAL_ES_WATCH
+#define OPAL_ES_WATCH 1  // the safety net of process_particle<ES_WATCH>; 0 only for experiments
+#endif
 #ifndef OPAL_TILE
 #define OPAL_TILE 64
 #endif
@@ -196,7 +199,9 @@ struct ChunkPtrs {
 // The per-particle body shared by the three modes.  FAST = the particle's stencil lies inside the
 // workgroup's LDS tile (fields from LDS, currents into the LDS accumulators); otherwise fields come
 // from global memory and the taps go to the grid with global atomics.
-template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool FAST, bool ES = false>
+// ES_WATCH: the general path inside an electrostatic launch (a particle outside its workgroup's tile, where the
+// tile's check says nothing about the fields): transverse momentum that appears here ends the population's promise.
+template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX, bool FAST, bool ES = false, bool ES_WATCH = false>
 __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkPtrs &cp, const double *s_field,
                                                  double *s_acc, int base, int lane, unsigned kc, int c, int c_mem,
                                                  double xi, V3 u, double wt, double prev, int &err, bool &emits)
@@ -252,6 +257,10 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         }
         if (!(r.dxi < 1.0)) err |= 1;  // electron.rs:313, ion.rs:199
         u = r.u;
+        if (ES_WATCH && (u.y != 0.0 || u.z != 0.0)) {
+            a.ctr->hot_yz = 1;
+            *a.es_flag = 1;
+        }
         inv_g = r.inv_gamma;
         // electron.rs:311-329 / ion.rs:197-213
         xn = xi + r.dxi;
@@ -592,7 +601,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
                     }
                 }
                 bool emits = false;
-                process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err, emits);
+                process_particle<SPECIES, MODE, RHO, EXTRAS, SENDX, false, false, ES && OPAL_ES_WATCH>(a, cp, s_field, s_acc, base, lane, kc, cm, cm, cp.x[kc], u, cp.w[kc], prev, err, emits);
                 if (EXTRAS == 2 && emits) emit_mask |= 1u << p;
             }
         }

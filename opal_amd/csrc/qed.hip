@@ -435,6 +435,7 @@ int opal_emit_radiation(opal_pop_t *e, opal_pop_t *ph, uint64_t seed, uint32_t s
         set_error("opal_emit_radiation: needs an electron and a photon population");
         return OPAL_ERR_ARG;
     }
+    e->cold_yz = false;  // this pass rewrites the electrons' momenta (see opal_pop::cold_yz)
     if (e->extras != 2 || !e->d_ex[EX_TAU] || !e->d_ex[EX_ID] || !e->d_ex[EX_CHI]) {
         set_error("opal_emit_radiation: the electrons do not carry optical depths (opal_pop_track_extras level 2)");
         return OPAL_ERR_ARG;
