@@ -44,6 +44,12 @@ struct PopCounters {
 
 // EX_TAU_ABS, EX_TAU_ST, EX_BIRTH: a photon's optical depths against absorption / stimulated emission and its birth
 // time (photon.rs:28-30), carried only when photon absorption is on
+struct PubCounters {
+    PopCounters c;
+    volatile unsigned seq;  // written after c, behind a system-scope fence
+    unsigned pad[15];
+};
+
 enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, EX_TAU_ABS = 6, EX_TAU_ST = 7, EX_BIRTH = 8, NEX = 9 };
 enum { KERNEL_FUSED = 0, KERNEL_ADVANCE = 1, KERNEL_DEPOSIT = 2, KERNEL_FIELD = 3, KERNEL_SORT = 4, KERNEL_COUNT = 5 };
 void prof_begin(int kernel, hipStream_t s);
@@ -121,9 +127,11 @@ struct opal_pop {
     double z_star, z, a;
     opal::PopCounters *d_ctr;
     opal::PopCounters *h_ctr;  // pinned
-    opal::PopCounters *h_ctr_async;  // pinned target of the asynchronous copy used by the re-binning policy
+    // what the re-binning policy reads: the counters as k_publish_counters last wrote them into mapped host memory,
+    // followed by the sequence number of that publication (no copy engine, no event: see maybe_sort)
+    opal::PubCounters *h_pub, *d_pub;
+    unsigned pub_seq;  // sequence number of the last publication asked for
     opal::PopCounters h_ctr_seen;
-    hipEvent_t ctr_event;
     hipEvent_t fetch_event;  // behind the synchronous counter read-backs
     bool ctr_pending;
     int sort_interval;         // 0 never, >0 fixed, <0 adaptive

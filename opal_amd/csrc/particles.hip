@@ -24,6 +24,7 @@
 #include "qed_device.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <type_traits>
@@ -958,6 +959,23 @@ __global__ void k_chunk_table(const unsigned *__restrict__ cell_end, int ncells,
         tab[j + before] = b;
     }
 }
+// the policy's view of the counters (maybe_sort): the 16 words of up to four populations into mapped host memory, each
+// followed by the sequence number the host waits for
+struct PublishBatch {
+    const PopCounters *src[4];
+    PubCounters *dst[4];
+    unsigned seq[4];
+    int n;
+};
+__global__ void k_publish_counters(PublishBatch b)
+{
+    static_assert(sizeof(PopCounters) == 64, "one word per lane below");
+    const int e = threadIdx.x >> 4, w = threadIdx.x & 15;
+    if (e < b.n) reinterpret_cast<volatile unsigned *>(&b.dst[e]->c)[w] = reinterpret_cast<const unsigned *>(b.src[e])[w];
+    __threadfence_system();
+    if (e < b.n && w == 0) b.dst[e]->seq = b.seq[e];
+}
+
 __global__ void k_sort_finish(PopCounters *ctr)
 {
     ctr->n_slots = ctr->n_live;
@@ -1512,8 +1530,9 @@ bool pop_plan_split(opal_pop_t *p, const opal_grid_t *g)
 // electrons and ions of one step in a single launch (fused pass only); `part` selects the edge or the bulk
 // chunks of a step that pop_plan_split has split for BOTH species
 int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, int part = PART_ALL,
-                  int mode = MODE_FUSED)
+                  int mode = MODE_FUSED, hipStream_t on = nullptr)
 {
+    const hipStream_t st = on ? on : pe->stream;  // (the edge chunks of a split step run beside the bulk, see sim.cpp)
     if (!pair_launch_possible(pe, pi, link)) {
         if (part != PART_ALL) {
             set_error("run_push_pair: a split step needs the paired launch");
@@ -1533,18 +1552,18 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     unsigned total = plan.en0 + plan.en1 + plan.in0 + plan.in1;
     if (!total) return OPAL_OK;
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
-    prof_begin(kid, pe->stream);
+    prof_begin(kid, st);
     // nothing transverse as far as the host has heard: the electrostatic form (which checks, see push_body)
     const bool es = g_elision && mode == MODE_FUSED && pe->cold_yz && pi->cold_yz && *static_cast<volatile int *>(g->h_esflag) == 0;
     if (!es && mode != MODE_DEPOSIT) pe->cold_yz = pi->cold_yz = false;  // a general push may leave uy, uz behind
     const bool rho = g->want_rho || !g_elision;  // (opal_sim_step: only the last step's rho can be observed)
-    if (es && rho) k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    else if (es) k_push_pair<MODE_FUSED, false, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    else if (mode == MODE_FUSED && rho) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    else if (mode == MODE_FUSED) k_push_pair<MODE_FUSED, false><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    else if (mode == MODE_ADVANCE) k_push_pair<MODE_ADVANCE, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    else k_push_pair<MODE_DEPOSIT, true><<<total, BLOCK, 0, pe->stream>>>(ae, ai, plan);
-    prof_end(kid, pe->stream);
+    if (es && rho) k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);
+    else if (es) k_push_pair<MODE_FUSED, false, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);
+    else if (mode == MODE_FUSED && rho) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);
+    else if (mode == MODE_FUSED) k_push_pair<MODE_FUSED, false><<<total, BLOCK, 0, st>>>(ae, ai, plan);
+    else if (mode == MODE_ADVANCE) k_push_pair<MODE_ADVANCE, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);
+    else k_push_pair<MODE_DEPOSIT, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);
+    prof_end(kid, st);
     OPAL_HIP(hipGetLastError());
     return OPAL_OK;
 }
@@ -1744,10 +1763,7 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     p->emit_list_valid = false;  // slots moved
     p->sorted_exact = true;
     p->dead_cost = 0.0;
-    if (p->ctr_pending) {
-        hipEventSynchronize(p->ctr_event);  // already complete: do_sort synchronised the stream
-        p->ctr_pending = false;
-    }
+    p->ctr_pending = false;  // (a publication still on its way carries an older sequence number and is never read)
     // the chunk table: slot ranges of the push workgroups, cut every BLOCK x pop_max_ppt slots and every CHUNK_CELLS cells
     {
         const unsigned N = (unsigned)p->n_upper, chunk = BLOCK * pop_max_ppt(p);
@@ -1776,6 +1792,71 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     double per_cell = (double)p->h_ctr->n_live / ne;
     int ppt = (int)((TILE / 4) * per_cell / BLOCK);
     p->ppt = std::max(1, std::min(pop_max_ppt(p), ppt));
+    return OPAL_OK;
+}
+
+// Publications asked for while a PublishScope is alive go out together when it ends (one launch for the species of a
+// step); without a scope each goes out at once.
+struct PublishScope;
+thread_local PublishScope *g_publish_scope = nullptr;
+struct PublishScope {
+    PublishBatch b{};
+    hipStream_t stream = nullptr;
+    PublishScope() { g_publish_scope = this; }
+    int flush()
+    {
+        if (b.n) {
+            k_publish_counters<<<1, 64, 0, stream>>>(b);
+            b.n = 0;
+            OPAL_HIP(hipGetLastError());
+        }
+        return OPAL_OK;
+    }
+    ~PublishScope()
+    {
+        flush();
+        g_publish_scope = nullptr;
+    }
+};
+
+int ask_publication(opal_pop_t *p)
+{
+    if (p->ctr_pending) return OPAL_OK;
+    p->pub_seq++;
+    p->ctr_pending = true;
+    PublishBatch one{};
+    PublishBatch &b = g_publish_scope ? g_publish_scope->b : one;
+    if (g_publish_scope) {
+        if (b.n == 4 || (b.n && g_publish_scope->stream != p->stream))
+            if (int rc = g_publish_scope->flush()) return rc;
+        g_publish_scope->stream = p->stream;
+    }
+    b.src[b.n] = p->d_ctr;
+    b.dst[b.n] = p->d_pub;
+    b.seq[b.n] = p->pub_seq;
+    b.n++;
+    if (!g_publish_scope) {
+        k_publish_counters<<<1, 64, 0, p->stream>>>(one);
+        OPAL_HIP(hipGetLastError());
+    }
+    return OPAL_OK;
+}
+
+int wait_published(const opal_pop_t *p)
+{
+    // the kernel that writes it was launched check_every steps ago: normally long done
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (p->h_pub->seq != p->pub_seq) {
+        if ((++spins & 0xffff) == 0) {
+            hipError_t q = hipStreamQuery(p->stream);  // surfaces a device fault instead of spinning on it
+            if (q != hipSuccess && q != hipErrorNotReady) OPAL_HIP(q);
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                set_error("the counters published for the re-binning policy never arrived");
+                return OPAL_ERR_HIP;
+            }
+        }
+    }
     return OPAL_OK;
 }
 
@@ -1809,24 +1890,20 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
 #endif
     constexpr double miss_ns = OPAL_MISS_NS, pass_ns = OPAL_PASS_NS;
     if (p->steps_since_sort % check_every != 0) return OPAL_OK;
-    // The counters are copied to pinned memory asynchronously and read at the NEXT check, check_every steps
-    // later: waiting for that older copy keeps the host at most ~2 check intervals ahead of the device (so the
-    // policy sees recent counts) while the device still has a check interval of queued steps to run and never
-    // idles.
+    // The counters are published to mapped host memory by a one-wave kernel and read at the NEXT check, check_every
+    // steps later: waiting for that older publication keeps the host at most ~2 check intervals ahead of the device
+    // (so the policy sees recent counts) while the device still has a check interval of queued steps to run and
+    // never idles.  No hipMemcpyAsync (a 64-byte copy hands the stream to the copy engine and back) and no event (a
+    // recorded event is a barrier packet, ~5 us between two 5 us kernels): the kernel writes a sequence number behind
+    // the counters and the host polls it; the populations checked in one step share one launch (PublishScope).
     bool fresh = false;
     if (p->ctr_pending) {
-        if (int rc = spin_wait(p->ctr_event)) return rc;
+        if (int rc = wait_published(p)) return rc;
         fresh = true;
-        p->h_ctr_seen = *p->h_ctr_async;
+        p->h_ctr_seen = p->h_pub->c;
         p->ctr_pending = false;
     }
-    if (!p->ctr_pending) {
-        if (!p->ctr_event) OPAL_HIP(hipEventCreateWithFlags(&p->ctr_event, hipEventDisableTiming));
-        OPAL_HIP(hipMemcpyAsync(p->h_ctr_async, p->d_ctr, sizeof(PopCounters), hipMemcpyDeviceToHost, p->stream));
-        OPAL_HIP(hipEventRecord(p->ctr_event, p->stream));
-        p->ctr_pending = true;
-        if (!fresh) return OPAL_OK;
-    }
+    if (int rc = ask_publication(p)) return rc;
     if (!fresh) return OPAL_OK;
     const PopCounters seen = p->h_ctr_seen;  // snapshot taken when the copy was found complete
     double sort_ms = 0.06 * (double)seen.n_slots * 1e-6 + 0.05;  // ~100 B per particle at ~2 TB/s + launches
@@ -1879,7 +1956,9 @@ int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_st
     if (int rc = alloc_set(p, 0)) return rc;
     OPAL_HIP(hipMalloc(&p->d_ctr, sizeof(PopCounters)));
     OPAL_HIP(hipHostMalloc(&p->h_ctr, sizeof(PopCounters)));
-    OPAL_HIP(hipHostMalloc(&p->h_ctr_async, sizeof(PopCounters)));
+    OPAL_HIP(hipHostMalloc(&p->h_pub, sizeof(PubCounters), hipHostMallocMapped));
+    memset((void *)p->h_pub, 0, sizeof(PubCounters));
+    OPAL_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_pub), p->h_pub, 0));
     OPAL_HIP(hipMemsetAsync(p->d_ctr, 0, sizeof(PopCounters), p->stream));
     p->partial_cap = 2048;
     OPAL_HIP(hipMalloc(&p->d_partial, sizeof(double) * (p->partial_cap + 8)));
@@ -1909,8 +1988,7 @@ int opal_pop_free(opal_pop_t *p)
     hipFree(p->d_partial);
     hipFree(p->d_ctr);
     hipHostFree(p->h_ctr);
-    hipHostFree(p->h_ctr_async);
-    if (p->ctr_event) hipEventDestroy(p->ctr_event);
+    hipHostFree(p->h_pub);
     if (p->fetch_event) hipEventDestroy(p->fetch_event);
     delete p;
     return OPAL_OK;
@@ -1957,6 +2035,7 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     p->emit_list_valid = false;
     p->sorted_exact = false;
     p->dead_cost = 0.0;
+    p->ctr_pending = false;  // (see do_sort)
     p->n_tab = 0;     // no re-binning yet: uniform chunks
     p->n_sorted = 0;
     p->dx_last = dx;
@@ -2378,13 +2457,23 @@ bool pops_plan_split(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, const op
     bool a = pop_plan_split(pe, g), b = pop_plan_split(pi, g);
     return a && b;
 }
-int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, bool edges)
+int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, bool edges,
+                              hipStream_t on)
 {
     pe->prev_valid = false;
     pi->prev_valid = false;
-    return run_push_pair(pe, pi, link, g, dt, edges ? PART_EDGES : PART_BULK);
+    return run_push_pair(pe, pi, link, g, dt, edges ? PART_EDGES : PART_BULK, MODE_FUSED, on);
 }
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
+// the re-binning bookkeeping of a step's species together (their counters are published in one launch)
+int pops_maybe_sort(opal_pop_t *const *pops, int npops, const opal_grid_t *g)
+{
+    PublishScope scope;
+    for (int i = 0; i < npops; i++)
+        if (pops[i])
+            if (int rc = maybe_sort(pops[i], g)) return rc;
+    return OPAL_OK;
+}
 // exact binning by cell now (photon absorption pairs every photon with the electrons of its cell): leaves
 // p->d_count[c] = one past the last slot of cell c
 int pop_sort_exact(opal_pop_t *p, const opal_grid_t *g)
@@ -2440,6 +2529,7 @@ int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opa
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g)
 {
     if (int rc = unpack_arrivals(pops, npops, link, g, true)) return rc;
+    PublishScope scope;  // the species' counters go out in one launch
     for (int i = 0; i < npops; i++)
         if (pops[i])
             if (int rc = maybe_sort(pops[i], g)) return rc;

@@ -27,12 +27,14 @@ int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *
 int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
+int pops_maybe_sort(opal_pop_t *const *pops, int npops, const opal_grid_t *g);
 int pops_advance_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt);
 int pops_deposit_pair(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt);
 int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right,
                        hipStream_t st);
 bool pops_plan_split(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, const opal_grid_t *g);
-int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, bool edges);
+int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, bool edges,
+                              hipStream_t on);
 int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz);
 }
 
@@ -685,16 +687,17 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
             // Overlap: only the particles within a few cells of the subdomain's ends can leave it or deposit
             // into the cells the halo carries, and after a re-binning they sit in the first and last chunks
-            // of the arrays.  Push those first, ship the message on a second stream, and push everybody
-            // else meanwhile; the exchange -- RCCL kernel, xGMI transfer, a neighbour that is a little
+            // of the arrays.  Those chunks are pushed on a second stream, BESIDE the bulk (the two launches share the
+            // GPU: the handful of edge workgroups would leave it idle on their own), and the message follows them
+            // on that stream; the exchange -- pack, RCCL kernel, xGMI transfer, a neighbour that is a little
             // late -- is off the critical path as long as it takes less than the bulk push.
             if (s->overlap && s->electrons && s->ions && pops_plan_split(s->electrons, s->ions, s->link, g) &&
                 ensure_comm_stream(s) == OPAL_OK && link_can_use_stream(s->link, s->comm_stream)) {
-                if (int rc = pops_push_fused_pair_part(s->electrons, s->ions, s->link, g, s->dt, true)) return rc;
-                OPAL_HIP(hipEventRecord(s->ev_edges, st));
+                OPAL_HIP(hipEventRecord(s->ev_edges, st));  // everything before this step (the clear, the last solve)
                 OPAL_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_edges, 0));
+                if (int rc = pops_push_fused_pair_part(s->electrons, s->ions, s->link, g, s->dt, true, s->comm_stream)) return rc;
+                if (int rc = pops_push_fused_pair_part(s->electrons, s->ions, s->link, g, s->dt, false, nullptr)) return rc;
                 if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, s->comm_stream)) return rc;
-                if (int rc = pops_push_fused_pair_part(s->electrons, s->ions, s->link, g, s->dt, false)) return rc;
                 if (int rc = link_exchange_particles(s->link, to_left, to_right, s->comm_stream)) return rc;
                 OPAL_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
                 OPAL_HIP(hipStreamWaitEvent(st, s->ev_comm, 0));
@@ -732,8 +735,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             if (s->electrons && s->ions && !linked) {
                 // both species in one launch, then the re-binning bookkeeping of each
                 if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, nullptr, s->grid, s->dt)) return rc;
-                if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
-                if (int rc = pop_maybe_sort(s->ions, s->grid)) return rc;
+                opal_pop_t *both[2] = {s->electrons, s->ions};
+                if (int rc = pops_maybe_sort(both, 2, s->grid)) return rc;
             } else {
                 if (s->electrons)
                     if (int rc = opal_pop_advance_deposit(s->electrons, s->link, s->grid, s->dt)) return rc;
@@ -745,8 +748,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             const bool pair = !linked && s->electrons && s->ions && !qed && s->current_deposition;
             if (pair) {
                 if (int rc = pops_advance_pair_noexchange(s->electrons, s->ions, s->grid, s->dt)) return rc;
-                if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
-                if (int rc = pop_maybe_sort(s->ions, s->grid)) return rc;
+                opal_pop_t *both[2] = {s->electrons, s->ions};
+                if (int rc = pops_maybe_sort(both, 2, s->grid)) return rc;
             } else {
                 if (s->electrons) {
                     // with emission on, the electrons' re-binning waits until the emission has consumed the list of
