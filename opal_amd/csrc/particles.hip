@@ -46,6 +46,9 @@ constexpr int BLOCK = 256;
 #ifndef OPAL_ES_PPT
 #define OPAL_ES_PPT 16  // the same for a population the electrostatic launch serves (see pop_max_ppt)
 #endif
+#ifndef OPAL_TWO_SIDED_TAIL
+#define OPAL_TWO_SIDED_TAIL 1  // chunks of arrivals are taken by two workgroups, one per half of the subdomain (push_body)
+#endif
 #ifndef OPAL_ES_WATCH
 #define OPAL_ES_WATCH 1  // the safety net of process_particle<ES_WATCH>; 0 only for experiments
 #endif
@@ -105,6 +108,7 @@ struct PushArgs {
     // the rest uniform chunks of BLOCK x ppt slots from n_sorted on.  n_tab = 0: uniform chunks throughout.
     const unsigned *tab_slot;
     unsigned n_tab, n_sorted;
+    int tail_sides;  // 2: the chunks behind the sorted slots are each taken by two workgroups (see push_body)
     int w_uniform;  // every slot's weight is w0 unless ctr->w_mixed says otherwise (opal_pop::w_uniform)
     double w0;
     int *es_flag;  // ES kernels: raised when the launch's belief fails somewhere (the grid's mapped host word)
@@ -389,6 +393,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     const int lane = tid & (REPL - 1);
     size_t chunk0;
     unsigned nloc;
+    int my_half = -1;  // block-uniform
     const bool tabled = block < a.n_tab;  // block-uniform
     if (tabled) {
         chunk0 = a.tab_slot[block];
@@ -396,10 +401,19 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         if (nloc == 0) return;
     } else {
         const unsigned n = a.ctr->n_slots;
-        chunk0 = (size_t)a.n_sorted + (size_t)(block - a.n_tab) * BLOCK * a.ppt;
+        const unsigned tb = block - a.n_tab;
+        chunk0 = (size_t)a.n_sorted + (size_t)(a.tail_sides == 2 ? tb >> 1 : tb) * BLOCK * a.ppt;
         if (chunk0 >= n) return;
         nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
+        if (OPAL_TWO_SIDED_TAIL && a.tail_sides == 2) my_half = (int)(tb & 1u);
     }
+    // Arrivals: behind the sorted slots, in the order they came -- from the left neighbour (cells near 0) and from the
+    // right one (cells near size - 1) in turn.  No tile spans both, so with two neighbours every chunk of arrivals is
+    // taken by TWO workgroups, one per half of the subdomain (my_half = 0 / 1; -1: everything is mine).  Each puts
+    // its tile at its own end; the other half's particles are half a subdomain away from it, fall out of the main
+    // loop as "pending" at no cost to that loop, and are dropped from the pending set below.  (Nobody in these chunks
+    // is anywhere near the middle: arrivals enter at the edges, move less than a cell per step, and maybe_sort
+    // re-bins before the oldest of them could have got there.)
     const int iters = (int)((nloc + BLOCK - 1) / BLOCK);  // <= pop_max_ppt <= 32 (the masks below)
 
     ChunkPtrs cp;
@@ -431,7 +445,8 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     unsigned k = tid;
     Slot s_n = fetch(min(k, last));
     bool have_n = k < nloc;
-    const int c_n = have_n ? s_n.c : DEAD_CELL;
+    int c_n = have_n ? s_n.c : DEAD_CELL;
+    if (OPAL_TWO_SIDED_TAIL && my_half >= 0 && (c_n >= (a.size >> 1)) != (my_half == 1)) c_n = DEAD_CELL;  // block-uniform test: the tile goes to MY end
     // tile base: lowest live cell among the first BLOCK slots of the chunk, minus a margin.  Slots that
     // hold far-away cells (particles that wrapped around a periodic domain, arrivals appended from both
     // neighbours) must not drag the tile away from the bulk.
@@ -580,6 +595,10 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // re-binning policy: per particle, and per wave pass -- a wave goes through the slow path once per loop iteration
     // in which ANY of its lanes has a pending particle, whether that is one lane or all 64.  A tail chunk full of
     // fresh arrivals that all miss costs a handful of passes, not hundreds of isolated misses.
+    if (OPAL_TWO_SIDED_TAIL && my_half >= 0 && pending) {  // (block-uniform first test) the other half's particles are not mine to push
+        for (int p = 0; p < iters; p++)
+            if ((pending & (1u << p)) && (cp.cell[(unsigned)p * BLOCK + tid] >= (a.size >> 1)) != (my_half == 1)) pending &= ~(1u << p);
+    }
     unsigned any_pending = pending;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) any_pending |= __shfl_xor(any_pending, o);
@@ -1422,7 +1441,12 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     a.n_tab = p->n_tab;
     a.n_sorted = p->n_sorted;
     const size_t behind = p->n_upper > p->n_sorted ? p->n_upper - p->n_sorted : 0;  // appended since the re-binning
-    nblk = p->n_tab + (unsigned)((behind + per_block - 1) / per_block);
+    // arrivals from both neighbours behind a sorted population: two workgroups per chunk of them (push_body)
+    // (safe while no arrival can have reached the middle of the subdomain: less than a cell per step since the last
+    // re-binning, see push_body and maybe_sort)
+    a.tail_sides = (OPAL_TWO_SIDED_TAIL && p->n_tab && link && g->size >= 8 * TILE &&
+                    (size_t)p->steps_since_sort + 2 * TILE < g->size / 2 && a.left_mode == EDGE_SEND && a.right_mode == EDGE_SEND && mode != MODE_DEPOSIT) ? 2 : 1;
+    nblk = p->n_tab + (unsigned)((behind + per_block - 1) / per_block) * (unsigned)a.tail_sides;
     return OPAL_OK;
 }
 
@@ -1868,8 +1892,11 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
         if (p->steps_since_sort >= p->sort_interval) return do_sort(p, g);
         return OPAL_OK;
     }
-    // adaptive ("rent or buy"): every few steps read the tile-miss counter (one 64-byte D2H copy); once the
-    // time lost to misses since the last re-binning exceeds what a re-binning costs, re-bin.
+    // arrivals must not get anywhere near the middle of the subdomain while their chunks are shared by two
+    // workgroups (push_body): re-bin long before they could
+    if (p->n_tab && g->size >= 8 * TILE && (size_t)p->steps_since_sort + 4 * TILE >= g->size / 2) return do_sort(p, g);
+    // adaptive ("rent or buy"): every few steps read the tile-miss counters; once the time lost to misses since the
+    // last re-binning exceeds what a re-binning costs, re-bin.
 #ifndef OPAL_CHECK_EVERY
 #define OPAL_CHECK_EVERY 2  // measured: the laser-plasma interaction is 6 % faster at 2 than at 4; two-stream does not care
 #endif
