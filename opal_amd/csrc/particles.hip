@@ -21,6 +21,7 @@
 #include "link.hpp"
 #include "opal_internal.hpp"
 #include "pic_device.hpp"
+#include "grid_device.hpp"
 #include "qed_device.hpp"
 
 #include <algorithm>
@@ -504,7 +505,12 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // below their lowest cell.
     const int span = (cmin == 0x7fffffff || cmax - cmin > TILE_HI - TILE_LO) ? 0 : cmax - cmin;
     const int margin = tabled ? (TILE - span) / 2 : TILE_MARGIN;
-    const int base = (cmin == 0x7fffffff ? 0 : cmin) + a.L - margin;  // array index of tile cell 0
+    // (nothing live among the first slots: the tile goes to cell 0 -- or, for the workgroup that takes the upper half of a
+    // chunk of arrivals, to the last cell: its tile must never reach the other half's particles, which it does not test)
+    const int c_none = my_half == 1 ? a.size - 1 : 0;
+    int base = (cmin == 0x7fffffff ? c_none : cmin) + a.L - margin;  // array index of tile cell 0
+    if (my_half == 0) base = min(base, (a.size >> 1) - TILE + a.L);  // (subdomains this applies to are >= 8 tiles long)
+    if (my_half == 1) base = max(base, (a.size >> 1) + a.L);
     // array index behind tile cell j - base: the interior cell itself when the tile is modular
     auto tile_index = [&](int j) {
         if (modular) {
@@ -596,8 +602,13 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // in which ANY of its lanes has a pending particle, whether that is one lane or all 64.  A tail chunk full of
     // fresh arrivals that all miss costs a handful of passes, not hundreds of isolated misses.
     if (OPAL_TWO_SIDED_TAIL && my_half >= 0 && pending) {  // (block-uniform first test) the other half's particles are not mine to push
-        for (int p = 0; p < iters; p++)
-            if ((pending & (1u << p)) && (cp.cell[(unsigned)p * BLOCK + tid] >= (a.size >> 1)) != (my_half == 1)) pending &= ~(1u << p);
+        // (the other workgroup may be pushing such a particle right now: its cell reads as the old or the new one, on
+        // the same side either way, or as DEAD_CELL if it has just left through that end)
+        for (int p = 0; p < iters; p++) {
+            if (!(pending & (1u << p))) continue;
+            const int c = cp.cell[(unsigned)p * BLOCK + tid];
+            if (c == DEAD_CELL || (c >= (a.size >> 1)) != (my_half == 1)) pending &= ~(1u << p);
+        }
     }
     unsigned any_pending = pending;
 #pragma unroll
@@ -1100,6 +1111,8 @@ struct UnpackArgs {
 struct UnpackBatch {
     UnpackArgs a[3];
     int n;
+    int has_sync;   // one more workgroup runs YeeGrid::synchronize's kernel (the fused linked step: independent work)
+    SyncArgs sync;
     unsigned *zero[2];
     const unsigned *send_head[2], *recv_head[2];  // null where there is no neighbour
     LinkBounds *bounds;                            // ring entry of this exchange (mapped host memory), or null
@@ -1126,7 +1139,12 @@ __global__ void k_unpack(UnpackBatch b)
             if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
         }
     }
-    unpack_one(b.a[blockIdx.x >> 1], blockIdx.x & 1);
+    const unsigned n_unpack = b.n ? 2u * (unsigned)b.n : 1u;
+    if (blockIdx.x >= n_unpack) {  // (only launched when has_sync)
+        synchronize_body(b.sync);
+        return;
+    }
+    if (b.n) unpack_one(b.a[blockIdx.x >> 1], blockIdx.x & 1);
 }
 
 __device__ void unpack_one(const UnpackArgs &a, int side)
@@ -1646,11 +1664,22 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
 
 // appends what the neighbours sent (already in the link's recv buffers) to the populations, one launch;
 // with zero_counts the send messages' leaver counts are reset for the next step (instead of link_begin)
-int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g, bool zero_counts)
+int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g, bool zero_counts,
+                    const SyncArgs *sync = nullptr)
 {
-    if (g->left_bdy != OPAL_BDY_INTERNAL && g->right_bdy != OPAL_BDY_INTERNAL) return OPAL_OK;
+    if (g->left_bdy != OPAL_BDY_INTERNAL && g->right_bdy != OPAL_BDY_INTERNAL) {
+        if (sync) {
+            set_error("unpack_arrivals: a synchronize to run, but no neighbour to unpack from");
+            return OPAL_ERR_ARG;
+        }
+        return OPAL_OK;
+    }
     UnpackBatch b;
     memset(&b, 0, sizeof b);
+    if (sync) {
+        b.has_sync = 1;
+        b.sync = *sync;
+    }
     hipStream_t st = nullptr;
     for (int i = 0; i < npops && b.n < 3; i++) {
         if (!pops[i]) continue;
@@ -1672,7 +1701,7 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.bounds = &link->d_bounds[(link->xseq - 1) % LINK_RING];
         b.seq = link->xseq;
     }
-    k_unpack<<<b.n ? 2 * b.n : 1, 256, 0, st>>>(b);
+    k_unpack<<<(b.n ? 2 * b.n : 1) + b.has_sync, 256, 0, st>>>(b);
     OPAL_HIP(hipGetLastError());
     if (zero_counts) link->counts_clean = true;
     // (only once the reservations since the last snapshot add up to a few per cent of the population: a
@@ -2553,9 +2582,10 @@ int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opa
 {
     return unpack_arrivals(pops, npops, link, g, true);
 }
-int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g)
+int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g,
+                               const SyncArgs *sync)
 {
-    if (int rc = unpack_arrivals(pops, npops, link, g, true)) return rc;
+    if (int rc = unpack_arrivals(pops, npops, link, g, true, sync)) return rc;
     PublishScope scope;  // the species' counters go out in one launch
     for (int i = 0; i < npops; i++)
         if (pops[i])

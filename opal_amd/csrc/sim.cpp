@@ -13,6 +13,7 @@
 #include <string>
 
 #include "config.hpp"
+#include "grid_device.hpp"
 #include "host_setup.hpp"
 #include "link.hpp"
 #include "opal_internal.hpp"
@@ -23,7 +24,9 @@ namespace opal {
 int pop_check_err(opal_pop_t *p);
 int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_push_advance_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
-int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
+int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g,
+                               const SyncArgs *sync);
+void grid_sync_args(const opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, SyncArgs &a);
 int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
@@ -716,10 +719,12 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
             double ly, lz;
             laser_now(ly, lz);
-            if (int rc = grid_apply_sync(g, rl, rr, ly, lz)) return rc;
             {
+                // synchronize's kernel and the unpack do not touch each other's data: one launch for both
+                SyncArgs sa;
+                grid_sync_args(g, rl, rr, ly, lz, sa);
                 opal_pop_t *pops[2] = {s->electrons, s->ions};
-                if (int rc = pops_unpack_and_maybe_sort(pops, 2, s->link, g)) return rc;
+                if (int rc = pops_unpack_and_maybe_sort(pops, 2, s->link, g, &sa)) return rc;
             }
             if (int rc = opal_grid_advance(g, s->dt)) return rc;
             s->t += s->dt;

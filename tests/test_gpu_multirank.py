@@ -295,11 +295,20 @@ for mode in ("wrap", "self", "native", "fixed"):
     if mode == "fixed":                                         # ... shipping every slot of a big buffer each step
         link = RcclLink(0, 1, dev, particle_capacity=1 << 14)
         link.set_bounded(False)
-    sim = oa.Simulation(yaml_text=YAML.format(nx=1024, npc=16), rank=0, numtasks=1, link=link, stream=stream)
+    # electrons all move right, positrons all move left: each species' arrivals come from ONE neighbour only
+    sign = " * (2.0 * floor(urand - 0.5) + 1.0)"
+    text = YAML.format(nx=1024, npc=16)
+    assert text.count(sign) == 2
+    text = text.replace(sign, "", 1).replace(sign, " * (-1.0)", 1)
+    sim = oa.Simulation(yaml_text=text, rank=0, numtasks=1, link=link, stream=stream)
     if link is not None:
         sim.grid.set_self_exchange(True)
         sim.set_overlap(True)
-    sim.step(25); sim.sync()
+    # a re-binning after 10 steps: from then on the arrivals sit behind sorted slots and each chunk of them is taken by
+    # two workgroups, one per half of the subdomain -- and here each species' arrivals come from ONE side only, the
+    # case in which the other workgroup must find nothing to do (it once put its tile at the wrong end and pushed the
+    # first workgroup's particles a second time)
+    sim.step(10); sim.electrons.sort(sim.grid); sim.ions.sort(sim.grid); sim.step(15); sim.sync()
     out[mode] = {k: sim.grid.raw(k) for k in ("Ex", "Ey", "Ez", "By", "Bz")}
     for name, p in (("e", sim.electrons), ("i", sim.ions)):
         s = p.soa(); o = np.lexsort((s["x"], s["ux"], s["w"]))
