@@ -1462,7 +1462,8 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     // arrivals from both neighbours behind a sorted population: two workgroups per chunk of them (push_body)
     // (safe while no arrival can have reached the middle of the subdomain: less than a cell per step since the last
     // re-binning, see push_body and maybe_sort)
-    a.tail_sides = (OPAL_TWO_SIDED_TAIL && p->n_tab && link && g->size >= 8 * TILE &&
+    // (and only where arrivals are all that is ever appended: photons are also born in place, anywhere)
+    a.tail_sides = (OPAL_TWO_SIDED_TAIL && p->species != OPAL_PHOTON && p->n_tab && link && g->size >= 8 * TILE &&
                     (size_t)p->steps_since_sort + 2 * TILE < g->size / 2 && a.left_mode == EDGE_SEND && a.right_mode == EDGE_SEND && mode != MODE_DEPOSIT) ? 2 : 1;
     nblk = p->n_tab + (unsigned)((behind + per_block - 1) / per_block) * (unsigned)a.tail_sides;
     return OPAL_OK;
