@@ -413,8 +413,9 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     // taken by TWO workgroups, one per half of the subdomain (my_half = 0 / 1; -1: everything is mine).  Each puts
     // its tile at its own end; the other half's particles are half a subdomain away from it, fall out of the main
     // loop as "pending" at no cost to that loop, and are dropped from the pending set below.  (Nobody in these chunks
-    // is anywhere near the middle: arrivals enter at the edges, move less than a cell per step, and maybe_sort
-    // re-bins before the oldest of them could have got there.)
+    // is anywhere near the middle: arrivals enter at the edges and move less than a cell per step, and build_args stops
+    // sharing the chunks long before the oldest of them could have got there -- the misses that follow bring on a
+    // re-binning, which starts the count again.)
     const int iters = (int)((nloc + BLOCK - 1) / BLOCK);  // <= pop_max_ppt <= 32 (the masks below)
 
     ChunkPtrs cp;
@@ -1461,7 +1462,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     const size_t behind = p->n_upper > p->n_sorted ? p->n_upper - p->n_sorted : 0;  // appended since the re-binning
     // arrivals from both neighbours behind a sorted population: two workgroups per chunk of them (push_body)
     // (safe while no arrival can have reached the middle of the subdomain: less than a cell per step since the last
-    // re-binning, see push_body and maybe_sort)
+    // re-binning, see push_body)
     // (and only where arrivals are all that is ever appended: photons are also born in place, anywhere)
     a.tail_sides = (OPAL_TWO_SIDED_TAIL && p->species != OPAL_PHOTON && p->n_tab && link && g->size >= 8 * TILE &&
                     (size_t)p->steps_since_sort + 2 * TILE < g->size / 2 && a.left_mode == EDGE_SEND && a.right_mode == EDGE_SEND && mode != MODE_DEPOSIT) ? 2 : 1;
@@ -1922,9 +1923,6 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
         if (p->steps_since_sort >= p->sort_interval) return do_sort(p, g);
         return OPAL_OK;
     }
-    // arrivals must not get anywhere near the middle of the subdomain while their chunks are shared by two
-    // workgroups (push_body): re-bin long before they could
-    if (p->n_tab && g->size >= 8 * TILE && (size_t)p->steps_since_sort + 4 * TILE >= g->size / 2) return do_sort(p, g);
     // adaptive ("rent or buy"): every few steps read the tile-miss counters; once the time lost to misses since the
     // last re-binning exceeds what a re-binning costs, re-bin.
 #ifndef OPAL_CHECK_EVERY
