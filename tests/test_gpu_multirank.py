@@ -340,6 +340,20 @@ print("SELF-EXCHANGE OK")
     assert r.returncode == 0 and "SELF-EXCHANGE OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+@pytest.mark.parametrize("kind", ["cold", "hot"])
+def test_linked_step_is_ballistic_in_a_thin_plasma(kind):
+    """scripts/soak_linked.py, short: in a plasma too thin to act on itself every particle must end up where N
+    ballistic steps put it, in place and through the RCCL self-exchange, across re-binnings -- a particle pushed twice
+    or not at all in any step, lost or duplicated on its way to a neighbour, is off by a fifth of a cell.  cold: the
+    electrostatic launch; hot: the general kernel."""
+    import subprocess
+    from test_exchange_gloo import _free_port
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_linked.py"), "1000", kind], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SOAK OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 @pytest.mark.parametrize("exact", [False, True])
 def test_emission_state_travels_through_rccl(tmp_path, exact):
     """Electrons with optical depths and ids, and photons, migrating through the native RCCL link (3 species
