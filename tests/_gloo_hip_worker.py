@@ -212,6 +212,10 @@ def main():
         text = YAML.format(nx=nx, npc=npc)
         if mode == "sim_es":  # nothing transverse: the linked step runs the electrostatic launch
             text = text.replace(" uy: 0.01 * nrand", " uy: 0.0").replace(" uz: 0.01 * nrand", " uz: 0.0")
+        if mode == "sim_thin":  # a plasma too thin to act on itself, cold: every particle moves freely (test: ballistic)
+            text = (text.replace(" ne: 1.0e27", " ne: 1.0e5").replace(" ni: 1.0e27", " ni: 1.0e5")
+                    .replace(" uy: 0.01 * nrand", " uy: 0.0").replace(" uz: 0.01 * nrand", " uz: 0.0")
+                    .replace("0.2 * (1.0 + 0.05 * nrand)", "0.5 * (1.0 + 0.3 * nrand)"))
         if mode == "sim_half":  # transverse momenta in the left half of the domain only: the other subdomains start in
             # the electrostatic launch and meet hot arrivals and the fields the left half radiates
             half = f"step(x, 0.0, {0.5 * nx * dx!r})"
@@ -219,8 +223,9 @@ def main():
         sim = oa.Simulation(yaml_text=text, rank=rank, numtasks=world, link=link)
         sim.set_fused(bool(fused))
         sim.set_overlap(nx >= 512)  # the optional overlapped step: edge chunks, exchange on a second stream, bulk chunks
-        sim.electrons.set_sort_interval(16)  # re-bin on a fixed schedule so that the test crosses re-binnings
-        sim.ions.set_sort_interval(16)
+        if mode != "sim_thin":  # (sim_thin keeps the adaptive policy)
+            sim.electrons.set_sort_interval(16)  # re-bin on a fixed schedule so that the test crosses re-binnings
+            sim.ions.set_sort_interval(16)
         init = {}
         for name, p in (("e", sim.electrons), ("i", sim.ions)):
             for k, v in p.soa().items():
@@ -228,7 +233,7 @@ def main():
         sim.step(steps)
         sim.sync()
         dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
-        if link is not None and fused and nx >= 512:
+        if link is not None and fused and nx >= 512 and mode != "sim_thin":
             # (not before the first re-binning: until then a chunk is 8 x 256 slots, half of such a small population)
             assert sim.overlapped_steps >= steps // 3, sim.overlapped_steps
         if link is not None:

@@ -97,6 +97,35 @@ def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx
     assert sum(len(g["e_w"]) for g in got) == nx * npc
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_decomposed_thin_plasma_is_ballistic(tmp_path, world):
+    """A plasma too thin to act on itself, cut into 2 and 3 subdomains, 700 steps under the adaptive re-binning policy:
+    every particle of the union must be where 700 free steps put it (matched by its momentum, which nothing changes).
+    A leaver lost or duplicated, an arrival pushed twice or skipped, is off by half a cell."""
+    import opal_amd as oa
+    nx, npc, steps = 1536, 24, 700
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    _launch("_gloo_hip_worker.py", world, ["sim_thin", tmp_path, nx, npc, steps, 1])
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    nxs, _ = oa.design_unbalanced(world, nx, dx)
+    first = np.concatenate([[0], np.cumsum(nxs)[:-1]]).astype(np.int64)
+    for name in ("e", "i"):
+        ini = {k: np.concatenate([g[f"init_{name}_{k}"] + (first[r] if k == "cell" else 0) for r, g in enumerate(got)])
+               for k in ("cell", "x", "ux")}
+        fin = {k: np.concatenate([g[f"{name}_{k}"] + (first[r] if k == "cell" else 0) for r, g in enumerate(got)])
+               for k in ("cell", "x", "ux")}
+        assert len(fin["ux"]) == len(ini["ux"]) == nx * npc
+        oi, of = np.argsort(ini["ux"], kind="stable"), np.argsort(fin["ux"], kind="stable")
+        assert np.array_equal(ini["ux"][oi], fin["ux"][of])           # nobody lost, nobody twice, nothing accelerated
+        u = ini["ux"][oi]
+        per_step = C * u / np.sqrt(1.0 + u * u) * dt / dx
+        want = (ini["cell"][oi] + ini["x"][oi] + steps * per_step) % nx
+        have = (fin["cell"][of] + fin["x"][of]) % nx
+        d = np.abs(have - want)
+        assert np.max(np.minimum(d, nx - d)) < 1e-6, name
+
+
 def test_receiving_subdomain_grows_its_storage(oracle, tmp_path):
     """All particles start on rank 0 and stream into rank 1, which starts with the minimum capacity."""
     o = oracle
