@@ -2,7 +2,7 @@
 fields do nothing, so every particle must end up exactly where N ballistic steps put it -- a particle pushed twice, or
 not at all, in any one step (the failure mode of shared chunks, races at re-binning, lost or duplicated leavers) is off
 by a fifth of a cell.  Particles are matched by their momentum, which nothing changes.
-usage: soak_linked.py [steps] [cold|hot]"""
+usage: soak_linked.py [steps] [cold|hot]      (environment: NX cells, NPC per cell and species, MODES="linked,in place")"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
@@ -10,7 +10,8 @@ import opal_amd as oa
 from opal_amd.exchange import RcclLink
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 hot = len(sys.argv) > 2 and sys.argv[2] == "hot"
-NX, NPC = 2048, 48
+NX, NPC = int(os.environ.get("NX", "2048")), int(os.environ.get("NPC", "48"))
+MODES = os.environ.get("MODES", "linked,in place").split(",")
 YAML = f"""---
 control:
  dx: 1.0e-8
@@ -47,7 +48,7 @@ dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 C = 2.997925e8
 bad = 0
-for mode in ("linked", "in place"):
+for mode in MODES:
     link = RcclLink(0, 1, dev, particle_capacity=4096) if mode == "linked" else None
     sim = oa.Simulation(yaml_text=YAML, rank=0, numtasks=1, link=link, stream=torch.cuda.current_stream().cuda_stream)
     if link is not None:
