@@ -1860,6 +1860,7 @@ thread_local PublishScope *g_publish_scope = nullptr;
 struct PublishScope {
     PublishBatch b{};
     hipStream_t stream = nullptr;
+    PublishScope *outer = g_publish_scope;  // (scopes may nest: the innermost one collects)
     PublishScope() { g_publish_scope = this; }
     int flush()
     {
@@ -1873,7 +1874,7 @@ struct PublishScope {
     ~PublishScope()
     {
         flush();
-        g_publish_scope = nullptr;
+        g_publish_scope = outer;
     }
 };
 
