@@ -575,6 +575,13 @@ def main():
                 "link": link_desc,
                 "link_particle_capacity": link_capacity if link is not None else None,
                 "rccl_ranks": rccl_ranks,
+                "elision": ("off (opal_set_elision(0)): every attribute of every particle is streamed, rho deposited every step"
+                            if args.no_elision else
+                            "on (default): what the data make unnecessary is not moved -- a uniform weight comes from the "
+                            "launch arguments, an electrostatic run (Ey = Ez = B = 0, uy = uz = 0, checked on the device) "
+                            "neither streams uy/uz nor gathers more than Ex, rho is deposited on the steps after which it "
+                            "can be observed; results are the general kernel's bit for bit; `without_elision` carries the "
+                            "same workload with all of it switched off"),
                 "frac_of_hbm_roofline_whole_step": m["value"] * BYTES_PER_UPDATE / (world * HBM_PEAK_GBS * 1e9),
             },
             "roofline": m["roofline"],
