@@ -232,3 +232,20 @@ def test_output_spec_file_names(oa):
     assert name("px:(32;weight)") == "out/7_electron_px.fits"
     assert name("x:px:pz") is None and name("bogus") is None and name("x:(volume)") is None
     assert name("x:(a;b;c)") == "out/7_electron_x.fits"               # three fields: defaults (mod.rs:463)
+
+
+def test_committed_traffic_figures_point_at_committed_profiles():
+    """bench.py's roofline.traffic comes from profiles/traffic.json (a separate rocprofv3 --pmc run): every entry must
+    name a committed PMC summary that holds the same bytes-per-update figure."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert "two_stream" in t and "two_stream_no_elision" in t
+    for key, entry in t.items():
+        src = os.path.join(root, entry["source"])
+        assert os.path.exists(src), (key, entry["source"])
+        pmc = json.load(open(src))
+        assert abs(pmc["hbm_bytes_per_particle_update"] - entry["hbm_bytes_per_particle_update"]) < 1e-9
+        assert 8.0 < entry["hbm_bytes_per_particle_update"] < 90.0
+    # the electrostatic launch moves less than the general kernel, which moves less than the survey's 80 B
+    assert t["two_stream"]["hbm_bytes_per_particle_update"] < t["two_stream_no_elision"]["hbm_bytes_per_particle_update"] < 80.0
