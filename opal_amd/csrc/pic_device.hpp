@@ -217,7 +217,7 @@ __device__ inline double rcp_nr(double a)
 // is recomputed as 1/sqrt(1 + u.u) (equal up to rounding) so that gamma never
 // travels through HBM.
 //
-// B0 = true is the same arithmetic with B == 0 put in: every term dropped below is an exact zero or an exact
+// B0 = true (the electrostatic launch, particles.hip) is the same arithmetic with B == 0 put in: every term dropped below is an exact zero or an exact
 // identity of the general form (v x B = 0; tau = 0, so u* = tau^2 = 0, sigma = gamma'^2, t = 0, s = 1/(1 + 0) = 1 --
 // the Newton reciprocal of 1.0 is 1.0 -- and u_new = u'), so the two forms give the same numbers (up to the sign of
 // a zero) and a particle's result does not depend on which of them its wave took.

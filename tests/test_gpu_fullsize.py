@@ -239,8 +239,8 @@ def test_electrostatic_kernel_gives_the_general_kernels_numbers(oa):
 
 
 def test_electrostatic_kernel_notices_a_field(oa):
-    """A non-zero B met by a kernel launched in its B == 0 form (a laser that enters after the run has started; here: a
-    standing By uploaded and the flag withdrawn again with assume_electrostatic): the workgroups that see it send their
+    """A transverse field met by a kernel launched in its electrostatic form (a laser that enters after the run has
+    started; here: a standing By uploaded and the flag withdrawn again with assume_electrostatic): the workgroups that see it send their
     particles down the general path at once and raise the flag, and later launches are general.  The run must equal
     one that used the general kernel from the first step."""
     nx, npc = 256, 256
