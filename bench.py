@@ -323,9 +323,13 @@ def main():
     ap.add_argument("--cells-per-gpu", type=int, default=None,
                     help=f"implies --weak; default {C2_CELLS} (with npc {C2_NPC}: BASELINE configs[1] per GPU)")
     ap.add_argument("--unfused", action="store_true", help="time the reference's operator sequence instead")
-    ap.add_argument("--no-elision", action="store_true",
-                    help="stream every attribute of every particle whatever the data hold (no electrostatic launches, "
-                         "no uniform weight from the launch arguments): the general kernel on the same workload")
+    ap.add_argument("--elision", choices=["off", "on"], default="off",
+                    help="off (default): the headline is the general kernel with every attribute of every particle "
+                         "streamed (SURVEY.md 8d's 80 B per update, rho every step), and the library's default path is "
+                         "reported beside it as `default_path`; on: the headline is the library's default path")
+    ap.add_argument("--no-elision", action="store_true", help="same as --elision off without the default_path measurement")
+    ap.add_argument("--no-default-path", action="store_true", help="skip the default_path measurement")
+    ap.add_argument("--no-laser-plasma", action="store_true", help="skip the laser-plasma interaction block of the N=1 line")
     ap.add_argument("--workload", choices=["two_stream", "laser_plasma"], default="two_stream",
                     help="two_stream (default; BASELINE configs[2], strong scaling) or laser_plasma "
                          "(configs[3]'s physics, --npc per cell in 5000 of 20000 cells, strong scaling)")
@@ -334,6 +338,8 @@ def main():
                          "to itself through RCCL (pack kernels, RCCL send/recv, unpack) instead of wrapping in place")
     args = ap.parse_args()
 
+    if args.no_elision:
+        args.elision, args.no_default_path = "off", True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -418,6 +424,9 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
 
+    def link_kind_desc():
+        return {"rccl": "native RCCL send/recv on the simulation stream", "torch": "torch.distributed P2P (RCCL)"}.get(link_kind, link_kind)
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -438,21 +447,65 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    def measure(sim, steps, warmup, elision=True):
+    def src_sha():
+        """Hash of the kernel sources the PMC traffic figures were taken with (profiles/traffic.json records it)."""
+        import hashlib
+        h = hashlib.sha256()
+        for f in ("particles.hip", "pic_device.hpp", "grid.hip", "grid_device.hpp"):
+            h.update(open(os.path.join(ROOT, "opal_amd", "csrc", f), "rb").read())
+        return h.hexdigest()[:16]
+
+    def bytes_model(forms, n_e, n_i, unfused):
+        """Algorithmic bytes per particle-update of the kernel FORM(S) that ran in the timed region:
+        cell, x, ux are read and written by every form (40 B); uy, uz are read and written (32 B) by every form but the
+        electrostatic launch; the weight is read (8 B) unless the launch takes it from its arguments.  The general
+        form with streamed weights is SURVEY.md 8d's 80 B.  Write-back elision and skipped rho are not byte-model
+        changes (rho lives in LDS; an attribute no lane changed is still part of what the form has to handle)."""
+        tot = sum(forms.values())
+        if not tot:
+            return None
+        n = max(n_e + n_i, 1)
+        acc, parts = 0.0, []
+        for f, cnt in sorted(forms.items()):
+            es, single = bool(f & 1), bool(f & 16)
+            base = 40.0 + (0.0 if es else 32.0) + (8.0 if unfused else 0.0)   # unfused advance also writes prev_x
+            if single:
+                w = 0.0 if f & 12 else 8.0
+            else:
+                w = ((0.0 if f & 4 else 8.0) * n_e + (0.0 if f & 8 else 8.0) * n_i) / n
+            acc += cnt * (base + w)
+            parts.append({"form": ("electrostatic" if es else "general") + (", rho deposited" if f & 2 else ", rho skipped")
+                                  + ("" if w == 8.0 else ", weight from the launch arguments" if w == 0.0 else ", one species' weight from the launch arguments")
+                                  + (", single species" if single else ""),
+                          "launches": cnt, "bytes_per_update": base + w})
+        dom = max(forms.items(), key=lambda kv: kv[1])[0]
+        mode = "0" if unfused else "1"
+        name = (f"k_push<{'0' if n_e else '1'}, {mode}, true, 0, false>" if dom & 16 else
+                f"k_push_pair<{mode}, {'true' if dom & 2 else 'false'}, {'true' if dom & 1 else 'false'}>")
+        return {"bytes_per_update": acc / tot, "forms": parts, "kernel": name,
+                "what": "read cell,x,ux + write cell,x,ux = 40 B; + uy,uz read and written = 32 B unless the launch is "
+                        "electrostatic; + w read = 8 B unless it comes from the launch arguments (general form, streamed "
+                        "weights: SURVEY.md 8d's 44 + 36 = 80 B)"}
+
+    def measure(sim, steps, warmup, preheat=True, workload_key="two_stream"):
         """Pre-heat (untimed, >= PREHEAT_SECONDS of steps so that clocks and caches are those of a running job),
         W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
-        n_local = len(sim.electrons) + (len(sim.ions) if sim.ions is not None else 0)
+        n_e = len(sim.electrons) if sim.electrons is not None else 0
+        n_i = len(sim.ions) if sim.ions is not None else 0
+        n_local = n_e + n_i
         barrier()
-        t0 = time.perf_counter()
-        sim.step(10)
-        sim.sync()
-        per_step = all_max((time.perf_counter() - t0) / 10)
-        preheat = 10
-        more = int(min(5000, max(0.0, PREHEAT_SECONDS - 10 * per_step) / max(per_step, 1e-7)))  # same on every rank
-        if more:
-            sim.step(more)
+        done = 0
+        if preheat:
+            t0 = time.perf_counter()
+            sim.step(10)
             sim.sync()
-            preheat += more
+            per_step = all_max((time.perf_counter() - t0) / 10)
+            done = 10
+            more = int(min(5000, max(0.0, PREHEAT_SECONDS - 10 * per_step) / max(per_step, 1e-7)))  # same on every rank
+            if more:
+                sim.step(more)
+                sim.sync()
+                done += more
         sim.step(warmup)
         sim.sync()
         oa.prof_reset()
@@ -471,15 +524,19 @@ def main():
         launches, total_ms = oa.prof_get(kname)
         sort_launches, sort_ms = oa.prof_get("sort")
         field_launches, field_ms = oa.prof_get("field")
+        forms = oa.prof_forms()
+        model = bytes_model(forms, n_e, n_i, args.unfused)
+        bpu = model["bytes_per_update"] if model else BYTES_PER_UPDATE
         # the dominant kernel covers this rank's particles once per step, in one launch (species paired) or two
         launches_total = oa.prof_seen(kname)
         per_launch = n_local * steps / max(launches_total, 1)
         avg_ms = total_ms / max(launches, 1)
-        achieved = BYTES_PER_UPDATE * per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        achieved = bpu * per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         value = n_total * steps / elapsed
         roof = {
             "bound": "hbm",
-            "kernel": "k_push_pair<fused>" if not args.unfused else "k_push_pair<advance>",
+            "kernel": model["kernel"] if model else None,
+            "bytes_model": model,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -488,49 +545,79 @@ def main():
             "launches_timed": launches,
             "launches_total": launches_total,
             "avg_launch_ms": avg_ms,
-            "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * per_launch,
+            "particle_updates_per_launch": per_launch,
+            "algorithmic_bytes_per_launch": bpu * per_launch,
+            # the cross-check a reader can make without the kernel time: the same bytes over the WHOLE step
+            "algorithmic_GBps_over_whole_step": bpu * n_total * steps / elapsed / 1e9 / world,
             "other_kernels_avg_ms": {"field_solve": field_ms / max(field_launches, 1), "rebin": sort_ms / max(sort_launches, 1)},
             "rebins_in_timed_region": oa.prof_seen("sort"),
         }
-        # PMC-measured HBM bytes per particle-update: a separate rocprofv3 --pmc run of this command (the
-        # counters cannot be read from inside the process); the file names the profile it came from
+        # PMC-measured HBM bytes per particle-update: separate rocprofv3 --pmc passes of this command
+        # (scripts/profile_bench.sh; the counters cannot be read from inside the process).  An entry is used only if
+        # it was taken for THIS workload and THIS kernel instantiation with the kernel sources as they are now.
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        tkey = ("two_stream" if args.workload == "two_stream" else "laser_plasma") + ("" if elision else "_no_elision")
-        if os.path.exists(tpath) and not args.unfused:
-            try:
-                tj = json.load(open(tpath)).get(tkey)
-                if tj:
-                    roof["traffic"] = tj["hbm_bytes_per_particle_update"] * per_launch
-                    roof["traffic_source"] = tj["source"] + " (separate rocprofv3 --pmc run; not measured in this process)"
-                    roof["traffic_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 if launches else None
-                    roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS if launches else None
-                    # `achieved` prices the survey's ALGORITHMIC 80 B/update; fewer bytes cross the HBM
-                    # interface where the data allow, which is how `frac` can exceed 1
-                    roof["traffic_note"] = (
-                        "traffic < algorithmic bytes: a uniform macro-particle weight comes from the launch arguments, "
-                        "uy/uz of an electrostatic run (all zero, no transverse field) are neither read nor written, and "
-                        "an attribute no lane of a wave changed is not written back; results are bit-identical to the "
-                        "general kernel's (tests/test_gpu_fullsize.py), whose numbers are in `without_elision`"
-                        if elision else
-                        "general kernel: everything is read; only the write-back of attributes no lane of a wave changed "
-                        "(uy, uz, most cell indices in this electrostatic run) is skipped")
-            except Exception:
-                roof["traffic"] = None
-        return {"value": value, "elapsed": elapsed, "n_total": n_total, "preheat": preheat, "roofline": roof}
+        try:
+            tj = json.load(open(tpath)).get(f"{workload_key}|{roof['kernel']}") if os.path.exists(tpath) else None
+        except Exception:
+            tj = None
+        if tj is None:
+            roof["traffic_note"] = f"no PMC entry for {workload_key}|{roof['kernel']} in profiles/traffic.json"
+        elif tj.get("src_sha") != src_sha():
+            roof["traffic_note"] = (f"profiles/traffic.json entry for {workload_key}|{roof['kernel']} is stale (kernel "
+                                    f"sources changed since {tj.get('source')}): not reported")
+        else:
+            roof["traffic"] = tj["hbm_bytes_per_particle_update"] * per_launch
+            roof["traffic_source"] = tj["source"] + " (separate rocprofv3 --pmc passes of this command; not measured in this process)"
+            roof["traffic_bytes_per_update"] = tj["hbm_bytes_per_particle_update"]
+            roof["traffic_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 if launches else None
+            roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS if launches else None
+            roof["traffic_note"] = ("bytes that crossed the HBM interface per launch; below the algorithmic bytes where the "
+                                    "write-back of attributes no lane of a wave changed (uy, uz, most cell indices in an "
+                                    "electrostatic run) is skipped")
+        return {"value": value, "elapsed": elapsed, "n_total": n_total, "preheat": done, "roofline": roof,
+                "ms_per_step": 1e3 * elapsed / steps,
+                "frac_of_hbm_roofline_whole_step": value * bpu / (world * HBM_PEAK_GBS * 1e9)}
+
+    def block(m, what, steps, extra=None):
+        out = {"what": what, "value": m["value"], "unit": "particle-updates/s", "particles_total": m["n_total"], "steps": steps,
+               "ms_per_step": m["ms_per_step"], "frac_of_hbm_roofline_whole_step": m["frac_of_hbm_roofline_whole_step"],
+               "roofline": m["roofline"]}
+        if extra:
+            out.update(extra)
+        return out
+
+    CONTRACT = ("general kernel, opal_set_elision(0): every attribute of every particle streamed (80 B per update, "
+                "SURVEY.md 8d), rho deposited every step")
+    DEFAULT = ("library default, opal_set_elision(1): what the data make unnecessary is not moved -- an electrostatic run "
+               "(Ey = Ez = B = 0, uy = uz = 0, checked on the device) neither streams uy/uz nor gathers more than Ex, a "
+               "uniform weight comes from the launch arguments, rho is deposited on the steps after which it can be "
+               "observed; results are the general kernel's bit for bit (tests/test_gpu_fullsize.py); its roofline is "
+               "priced with ITS form's bytes (bytes_model), not with 80 B")
 
     if args.workload == "laser_plasma":
+        wkey = f"laser_plasma:{npc}"
         sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
     else:
+        wkey = f"two_stream:{nx}x{npc}"
         sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
     sim.set_fused(not args.unfused)
-    if args.no_elision:
-        oa.set_elision(False)
     if args.self_exchange and world == 1:
         sim.grid.set_self_exchange(True)
     if os.environ.get("OPAL_BENCH_OVERLAP", "0") == "1":  # diagnostic: exchange on a second stream under the bulk push
         sim.set_overlap(True)
 
-    m = measure(sim, args.steps, args.warmup, elision=not args.no_elision)
+    # One population, two measurements.  First the library's default path (elision on: an electrostatic launch can
+    # only serve a population nothing but electrostatic launches have pushed), then -- the headline -- the general
+    # kernel with every byte of SURVEY.md 8d streamed.  `--elision on` makes the default path the headline instead.
+    m_default = None
+    half = max(20, args.steps // 2)
+    if args.elision == "on":
+        m = measure(sim, args.steps, args.warmup, workload_key=wkey)
+    else:
+        if not args.unfused and not args.no_default_path:
+            m_default = measure(sim, half, args.warmup, workload_key=wkey)
+        oa.set_elision(False)
+        m = measure(sim, args.steps, args.warmup, preheat=m_default is None, workload_key=wkey)
     t_end = sim.t
 
     if rank == 0:
@@ -549,8 +636,7 @@ def main():
         elif backend != "nccl":
             link_desc = f"REHEARSAL: {world} ranks share {ndev} GPU(s), host-staged gloo exchange"
         else:
-            link_desc = ("native RCCL send/recv on the simulation stream" if link_kind == "rccl" else "torch.distributed P2P (RCCL)") \
-                + (", self-exchange (multi-GPU step rehearsed on one GPU)" if args.self_exchange and world == 1 else "")
+            link_desc = link_kind_desc() + (", self-exchange (multi-GPU step rehearsed on one GPU)" if args.self_exchange and world == 1 else "")
         out = {
             "metric": "particle-updates/sec",
             "value": m["value"],
@@ -558,8 +644,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "preheat_steps": m["preheat"],
-            "ms_per_step": 1e3 * m["elapsed"] / args.steps,
+            "preheat_steps": m["preheat"] + (m_default["preheat"] if m_default else 0),
+            "ms_per_step": m["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak" if (weak and args.workload == "two_stream") else "strong",
             "vs_baseline": None,
@@ -567,59 +653,51 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload,
+                "workload_key": wkey,
+                "kernel_src_sha": src_sha(),
                 "particles_total": m["n_total"],
                 "cells_total": nx,
-                "path": ("fused advance+deposit" if not args.unfused else "advance, clear, deposit (reference order)")
-                        + (", elision off (general kernel)" if args.no_elision else ""),
+                "path": ("fused advance+deposit" if not args.unfused else "advance, clear, deposit (reference order)"),
+                "kernel_form": DEFAULT if args.elision == "on" else CONTRACT,
                 "parallelism": f"{world} subdomain(s), 1 per GPU" if backend == "nccl" or world == 1 else f"{world} subdomains on {ndev} GPU(s)",
                 "link": link_desc,
                 "link_particle_capacity": link_capacity if link is not None else None,
                 "rccl_ranks": rccl_ranks,
-                "elision": ("off (opal_set_elision(0)): every attribute of every particle is streamed, rho deposited every step"
-                            if args.no_elision else
-                            "on (default): what the data make unnecessary is not moved -- a uniform weight comes from the "
-                            "launch arguments, an electrostatic run (Ey = Ez = B = 0, uy = uz = 0, checked on the device) "
-                            "neither streams uy/uz nor gathers more than Ex, rho is deposited on the steps after which it "
-                            "can be observed; results are the general kernel's bit for bit; `without_elision` carries the "
-                            "same workload with all of it switched off"),
-                "frac_of_hbm_roofline_whole_step": m["value"] * BYTES_PER_UPDATE / (world * HBM_PEAK_GBS * 1e9),
+                "frac_of_hbm_roofline_whole_step": m["frac_of_hbm_roofline_whole_step"],
             },
             "roofline": m["roofline"],
         }
+        if m_default is not None:
+            out["default_path"] = block(m_default, DEFAULT, half)
         del sim
         if world == 1 and args.workload == "two_stream" and not weak and not args.no_secondary and not args.self_exchange \
-                and (nx, npc) == (C3_CELLS, C3_NPC):
+                and (nx, npc) == (C3_CELLS, C3_NPC) and args.elision == "off":
+            # BASELINE configs[1], measured the same way in the same process (default path first, then the contract run)
+            oa.set_elision(True)
             sim2 = oa.Simulation(yaml_text=YAML.format(nx=C2_CELLS, npc=C2_NPC), stream=stream)
             sim2.set_fused(not args.unfused)
-            m2 = measure(sim2, args.steps, args.warmup, elision=not args.no_elision)
+            k2 = f"two_stream:{C2_CELLS}x{C2_NPC}"
+            m2d = measure(sim2, half, args.warmup, workload_key=k2) if not (args.unfused or args.no_default_path) else None
+            oa.set_elision(False)
+            m2 = measure(sim2, args.steps, args.warmup, preheat=m2d is None, workload_key=k2)
             del sim2
-            out["secondary"] = {
-                "workload": f"two_stream, {C2_NPC} e- + {C2_NPC} e+ per cell, {C2_CELLS} cells (BASELINE configs[1]), 1 GPU",
-                "value": m2["value"],
-                "unit": "particle-updates/s",
-                "particles_total": m2["n_total"],
-                "steps": args.steps,
-                "preheat_steps": m2["preheat"],
-                "ms_per_step": 1e3 * m2["elapsed"] / args.steps,
-                "frac_of_hbm_roofline_whole_step": m2["value"] * BYTES_PER_UPDATE / (HBM_PEAK_GBS * 1e9),
-                "roofline": m2["roofline"],
-            }
-            # the same 1e8-particle workload through the general kernel (every attribute streamed)
-            if not args.no_elision and not args.unfused:
-                oa.set_elision(False)
-                sim3 = oa.Simulation(yaml_text=YAML.format(nx=C3_CELLS, npc=C3_NPC), stream=stream)
-                m3 = measure(sim3, max(20, args.steps // 2), args.warmup, elision=False)
+            out["secondary"] = block(m2, f"two_stream, {C2_NPC} e- + {C2_NPC} e+ per cell, {C2_CELLS} cells (BASELINE configs[1]), "
+                                         f"1 GPU; " + CONTRACT, args.steps,
+                                     {"default_path": block(m2d, DEFAULT, half)} if m2d else None)
+            if not args.unfused and not args.no_laser_plasma:
+                # BASELINE configs[3]'s physics on one GPU inside the laser-plasma INTERACTION (the pulse reaches the
+                # slab after ~21 000 steps): the workload in which nothing can be elided and the particles outrun
+                # their tiles -- general kernel, 80 B per update
+                lp_npc, lp_warm, lp_steps = 2000, 21000, 2000
+                sim3 = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=lp_npc), stream=stream)
+                m3 = measure(sim3, lp_steps, lp_warm, preheat=False, workload_key=f"laser_plasma:{lp_npc}")
+                t3 = sim3.t
                 del sim3
-                oa.set_elision(True)
-                out["without_elision"] = {
-                    "workload": "the headline workload with opal_set_elision(0): no electrostatic launches, weights streamed",
-                    "value": m3["value"],
-                    "unit": "particle-updates/s",
-                    "steps": max(20, args.steps // 2),
-                    "ms_per_step": 1e3 * m3["elapsed"] / max(20, args.steps // 2),
-                    "frac_of_hbm_roofline_whole_step": m3["value"] * BYTES_PER_UPDATE / (HBM_PEAK_GBS * 1e9),
-                    "roofline": m3["roofline"],
-                }
+                out["laser_plasma_interaction"] = block(
+                    m3, f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]) on 1 GPU, {lp_npc} e- + {lp_npc} C6+ "
+                        f"per cell in 5000 of 20000 cells, {lp_warm} untimed steps to bring the pulse onto the slab, then "
+                        f"{lp_steps} timed steps ending at t = {t3:.3e} s; " + CONTRACT, lp_steps)
+            oa.set_elision(True)
         if not args.no_cpu_baseline and world == 1 and args.workload == "two_stream":
             out["cpu_baseline"] = cpu_baseline(oa, nx, npc)
         sys.stdout.flush()

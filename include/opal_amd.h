@@ -380,6 +380,11 @@ int opal_prof_reset(void);
 int opal_prof_get(int kernel, uint64_t *launches, double *total_ms);
 /* launches of the kernel observed since the last reset while the timers were on (timed or not) */
 int opal_prof_seen(int kernel, uint64_t *launches_seen);
+/* launches of the fused push since the last reset (timers on), by the form of the kernel that ran: index = bit 0
+ * electrostatic launch (uy, uz not streamed) | bit 1 rho deposited | bit 2 / bit 3 electrons' / ions' weight from the
+ * launch arguments (not streamed) | bit 4 single-species launch; 32 entries.  Each form has its own algorithmic
+ * bytes per particle-update, which is what a roofline fraction must be priced with. */
+int opal_prof_forms(uint64_t *launches_by_form);
 
 /* Text forms used by the reference's outputs: kind 0 = SimulationTime (setup.rs:421-438), 1 = Rust {:e}
  * (yee.rs:768), 2 = {:.6e} (main.rs:35-38), 3 = {} (yee.rs:768, last column) */

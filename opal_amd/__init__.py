@@ -562,6 +562,14 @@ def prof_seen(kernel):
     return n.value
 
 
+def prof_forms():
+    """{form: launches} of the fused push since prof_reset; form bits: 1 electrostatic, 2 rho deposited, 4 / 8 the
+    electrons' / ions' weight from the launch arguments, 16 single-species launch (opal_prof_forms)."""
+    a = (C.c_uint64 * 32)()
+    _check(_lib.load().opal_prof_forms(a))
+    return {i: int(a[i]) for i in range(32) if a[i]}
+
+
 def prof_get(kernel):
     n = C.c_uint64()
     ms = C.c_double()

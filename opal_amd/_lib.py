@@ -141,6 +141,7 @@ SIGNATURES = {
     "opal_prof_reset": (C.c_int, []),
     "opal_prof_seen": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "opal_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(dbl)]),
+    "opal_prof_forms": (C.c_int, [C.POINTER(C.c_uint64)]),
     "opal_config_from_file": (C.c_int, [pp, C.c_char_p]),
     "opal_config_from_string": (C.c_int, [pp, C.c_char_p]),
     "opal_config_free": (C.c_int, [vp]),

@@ -37,6 +37,9 @@ struct ProfSlot {
     double total_ms = 0.0;
 };
 static ProfSlot g_prof[KERNEL_COUNT];
+// launches of the push kernels by the FORM that ran (prof_form), while the timers are on: what bench.py prices
+// a launch's algorithmic bytes by
+static uint64_t g_prof_forms[PUSH_FORMS];
 static int g_prof_stride = 0;  // 0 = off; n = time every n-th launch of each tracked kernel
 static std::mutex g_prof_mu;
 
@@ -74,6 +77,13 @@ void prof_begin(int kernel, hipStream_t st)
     if (s.seen++ % (uint64_t)g_prof_stride != 0) return;
     s.open = get_event(s);
     if (s.open) hipEventRecord(s.open, st);
+}
+
+void prof_form(unsigned form)
+{
+    if (!g_prof_stride) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_forms[form & (PUSH_FORMS - 1)]++;
 }
 
 void prof_end(int kernel, hipStream_t st)
@@ -134,6 +144,18 @@ int opal_prof_reset(void)
         s.launches = 0;
         s.total_ms = 0.0;
     }
+    for (auto &f : g_prof_forms) f = 0;
+    return OPAL_OK;
+}
+
+int opal_prof_forms(uint64_t *launches_by_form)
+{
+    if (!launches_by_form) {
+        set_error("opal_prof_forms: null output");
+        return OPAL_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < PUSH_FORMS; i++) launches_by_form[i] = g_prof_forms[i];
     return OPAL_OK;
 }
 

@@ -1500,6 +1500,8 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     }
     int kid = mode == MODE_FUSED ? KERNEL_FUSED : (mode == MODE_ADVANCE ? KERNEL_ADVANCE : KERNEL_DEPOSIT);
     prof_begin(kid, p->stream);
+    if (mode != MODE_DEPOSIT)
+        prof_form(FORM_SINGLE | FORM_RHO | (a.w_uniform ? (p->species == OPAL_ELECTRON ? FORM_W_ARG_E : FORM_W_ARG_I) : 0u));
     // which variant of the kernel: 2 runs down the optical depth, 1 touches chi / work / y / z, 0 neither
     int ex = !p->extras ? 0 : p->d_ex[EX_TAU] ? 2 : (p->d_ex[EX_CHI] || p->d_ex[EX_WORK] || p->d_ex[EX_Y]) ? 1 : 0;
     if (p->species == OPAL_ELECTRON) {
@@ -1604,6 +1606,9 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     const bool es = g_elision && mode == MODE_FUSED && pe->cold_yz && pi->cold_yz && *static_cast<volatile int *>(g->h_esflag) == 0;
     if (!es && mode != MODE_DEPOSIT) pe->cold_yz = pi->cold_yz = false;  // a general push may leave uy, uz behind
     const bool rho = g->want_rho || !g_elision;  // (opal_sim_step: only the last step's rho can be observed)
+    if (mode != MODE_DEPOSIT)
+        prof_form((es ? FORM_ES : 0u) | ((rho || mode != MODE_FUSED) ? FORM_RHO : 0u) | (ae.w_uniform ? FORM_W_ARG_E : 0u) |
+                  (ai.w_uniform ? FORM_W_ARG_I : 0u));
     if (es && rho) k_push_pair<MODE_FUSED, true, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);
     else if (es) k_push_pair<MODE_FUSED, false, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);
     else if (mode == MODE_FUSED && rho) k_push_pair<MODE_FUSED, true><<<total, BLOCK, 0, st>>>(ae, ai, plan);

@@ -1,0 +1,151 @@
+"""Known answers for the parts of the hot path the reference holds no test for (`fields_at`'s
+values, `Ion::push`), checked on the HIP path WITHOUT the oracle: every expected value below is an analytic
+property of the algorithm the reference's source states, so a mis-reading shared by oracle/opal_oracle.c and
+pic_device.hpp cannot pass here.
+
+* gather (yee.rs:499-529, stagger documented at yee.rs:70-82): the quadratic B-spline reproduces a linear field
+  exactly and a quadratic one up to its constant second moment 1/4 -- evaluated at the positions the reference
+  documents (Ex, By, Bz at cell centres, Ey, Ez at left-hand edges, Bx taken from the particle's cell as is);
+* ion push (ion.rs:168-214): the Boris rotation conserves |u| exactly and turns u by 2 atan(alpha c |B| / gamma)
+  per step about B, in the sense of a positive charge; in a static E the momentum grows by 2 alpha E per step --
+  the analogues of electron.rs:401-436 for `OPAL_ION`, through `opal_pop_advance`.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+C = 2.997925e8            # constants.rs:4
+E_CHARGE = 1.602177e-19   # constants.rs:12-14
+M_P = 1.672622e-27        # constants.rs:18
+M_E = 9.109383e-31        # constants.rs:16
+M_E_MEV = 0.510999        # constants.rs:20
+
+
+@pytest.fixture(scope="module")
+def oa():
+    import opal_amd
+    return opal_amd
+
+
+def test_gather_reproduces_linear_fields_at_the_documented_stagger(oa):
+    nx, dx = 96, 1.0e-7
+    g = oa.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    j = np.arange(g.len, dtype=np.float64)
+    rng = np.random.default_rng(11)
+    coef = {k: (rng.normal(), rng.normal()) for k in ("Ex", "Ey", "Ez", "By", "Bz")}
+    centred = {"Ex": True, "By": True, "Bz": True, "Ey": False, "Ez": False}
+    for k, (a, b) in coef.items():
+        g.set_raw(k, a + b * (j + (0.5 if centred[k] else 0.0)))  # the value AT the point the component lives at
+    bx = rng.normal(size=g.len)
+    g.set_raw("Bx", bx)
+    n = 4000
+    c = rng.integers(0, nx, n).astype(np.int32)
+    xi = rng.random(n)
+    xi[:4] = [0.0, 0.5, 0.499999999, 0.999999999]  # the spline's knots
+    E, B = g.fields_at(c, xi)
+    pos = c + L + xi  # the particle's position in units of dx, from the left end of the array
+    got = {"Ex": E[:, 0], "Ey": E[:, 1], "Ez": E[:, 2], "By": B[:, 1], "Bz": B[:, 2]}
+    for k, (a, b) in coef.items():
+        want = a + b * pos
+        assert np.max(np.abs(got[k] - want)) <= 2e-13 * np.max(np.abs(want)), k
+    assert np.array_equal(B[:, 0], bx[c + L])  # yee.rs:519: Bx is not interpolated
+
+
+def test_gather_is_a_quadratic_spline(oa):
+    """f(x) = x^2 comes back as x_p^2 + 1/4: the second moment of the order-2 B-spline, independent of where in the
+    cell the particle sits (a linear/CIC weighting would give x_p^2 + xi (1 - xi))."""
+    nx, dx = 64, 1.0
+    g = oa.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    j = np.arange(g.len, dtype=np.float64)
+    g.set_raw("Ex", (j + 0.5) ** 2)
+    g.set_raw("Ey", j ** 2)
+    g.set_raw("Bz", (j + 0.5) ** 2)
+    rng = np.random.default_rng(12)
+    c = rng.integers(0, nx, 1000).astype(np.int32)
+    xi = rng.random(1000)
+    E, B = g.fields_at(c, xi)
+    pos = c + L + xi
+    for got in (E[:, 0], E[:, 1], B[:, 2]):
+        assert np.max(np.abs(got - (pos ** 2 + 0.25))) <= 1e-12 * np.max(pos ** 2)
+
+
+@pytest.mark.parametrize("axis,z_star,a_mass", [("z", 1.0, 1.0), ("z", 6.0, 12.0), ("x", 1.0, 1.0), ("z", 1.0, M_E / M_P)])
+def test_ion_boris_rotation_in_a_static_magnetic_field(oa, axis, z_star, a_mass):
+    nx, steps = 64, 100
+    q, M = z_star * E_CHARGE, a_mass * M_P
+    u0 = np.array([0.8, 0.3, 0.0]) if axis == "z" else np.array([0.1, 0.7, -0.4])
+    gamma = np.sqrt(1.0 + u0 @ u0)
+    # choose dt for ~1/60 of a gyration per step in B0, and dx so that the ion crosses a third of a cell per step
+    b0 = 2.0
+    dt = (2.0 * np.pi / 60.0) * gamma * M / (q * b0)
+    dx = 3.0 * C * dt
+    g = oa.Grid.single(nx, 0.0, dx)
+    g.set_raw("Bz" if axis == "z" else "Bx", np.full(g.len, b0))
+    n = 512
+    rng = np.random.default_rng(13)
+    cell = np.sort(rng.integers(0, nx, n)).astype(np.int32)
+    x = rng.random(n)
+    p = oa.Population.from_soa(oa.ION, cell, x, np.full(n, u0[0]), np.full(n, u0[1]), np.full(n, u0[2]), np.ones(n), dx, dt)
+    p.set_charge_state(z_star, z_star, a_mass)
+    for _ in range(steps):
+        p.advance(g, dt)
+    s = p.soa()
+    alpha = q * dt / (2.0 * M * C)                       # ion.rs:173-175
+    theta = 2.0 * np.arctan(alpha * C * b0 / gamma)      # Boris: tan(theta / 2) = t |cB|, t = alpha / gamma
+    u = np.stack([s["ux"], s["uy"], s["uz"]], axis=1)
+    assert np.max(np.abs(np.sqrt(np.sum(u * u, axis=1)) - np.sqrt(u0 @ u0))) < 1e-12  # gamma conserved
+    if axis == "z":
+        # a positive charge turns clockwise about +z: phi decreases by theta per step
+        phi = np.arctan2(u0[1], u0[0]) - steps * theta
+        up = np.hypot(u0[0], u0[1])
+        want = np.array([up * np.cos(phi), up * np.sin(phi), 0.0])
+    else:
+        # ... and clockwise about +x in the (y, z) plane; ux untouched
+        phi = np.arctan2(u0[2], u0[1]) - steps * theta
+        up = np.hypot(u0[1], u0[2])
+        want = np.array([u0[0], up * np.cos(phi), up * np.sin(phi)])
+    assert np.max(np.abs(u - want)) < 1e-10
+    if axis == "z":
+        # positions: x advances with the NEW velocity each step (ion.rs:197-199)
+        k = np.arange(1, steps + 1)
+        moved = np.sum(C * up * np.cos(np.arctan2(u0[1], u0[0]) - k * theta) * dt / (gamma * dx))
+        order = np.argsort(s["w"], kind="stable")  # (all weights equal: slot order is kept by an un-rebinned advance)
+        have = (s["cell"] + s["x"]) % nx
+        want_pos = (cell + x + moved) % nx
+        d = np.abs(np.sort(have) - np.sort(want_pos))
+        assert np.max(np.minimum(d, nx - d)) < 1e-9, order[:1]
+
+
+def test_ion_in_a_static_electric_field(oa):
+    """ion.rs:176-196 with B = 0: u_x grows by 2 alpha E per step exactly (the two half kicks; the rotation is the
+    identity); the kinetic energy follows ion.rs:128-134."""
+    nx, steps = 32, 100
+    z_star, a_mass = 6.0, 12.0
+    q, M = z_star * E_CHARGE, a_mass * M_P
+    e0 = 1.0e12
+    dt = 1.0e-17
+    dx = 1.0e-6
+    g = oa.Grid.single(nx, 0.0, dx)
+    g.set_raw("Ex", np.full(g.len, e0))
+    n = 256
+    cell = np.repeat(np.arange(nx), n // nx).astype(np.int32)
+    x = np.linspace(0.05, 0.95, n)
+    w = np.full(n, 3.0)
+    p = oa.Population.from_soa(oa.ION, cell, x, np.zeros(n), np.zeros(n), np.zeros(n), w, dx, dt)
+    p.set_charge_state(z_star, z_star, a_mass)
+    for _ in range(steps):
+        p.advance(g, dt)
+    s = p.soa()
+    alpha = q * dt / (2.0 * M * C)
+    want = 2.0 * alpha * e0 * steps
+    assert want > 1e-4
+    assert np.max(np.abs(s["ux"] - want)) <= 1e-12 * want
+    assert np.all(s["uy"] == 0.0) and np.all(s["uz"] == 0.0)
+    gamma_m1 = want * want / (1.0 + np.sqrt(1.0 + want * want))
+    ke = np.sum(w) * gamma_m1 * (a_mass * M_P / M_E) * M_E_MEV * 1.0e6 * E_CHARGE
+    assert abs(p.total_kinetic_energy() - ke) <= 1e-11 * ke
+    # gamma(t) = sqrt(1 + (q E t / M c)^2), the form of electron.rs:423-436
+    assert abs(np.sqrt(1.0 + s["ux"][0] ** 2) - np.sqrt(1.0 + (q * e0 * steps * dt / (M * C)) ** 2)) < 1e-12
