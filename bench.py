@@ -365,7 +365,7 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     oa.set_device(dev_index)
-    link_kind = os.environ.get("OPAL_BENCH_LINK", "rccl") if backend == "nccl" else "gloo"
+    link_kind = os.environ.get("OPAL_BENCH_LINK", "peer") if backend == "nccl" else "gloo"
 
     weak = args.weak or args.cells_per_gpu is not None
     if args.workload == "laser_plasma":
@@ -388,8 +388,21 @@ def main():
     def make_link(r, w, device):
         """Neighbour transport over RCCL: native (the library issues the send/recv itself on the simulation's
         stream) unless OPAL_BENCH_LINK=torch asks for the torch.distributed callback."""
-        from opal_amd.exchange import RcclLink, TorchLink
+        from opal_amd.exchange import PeerLink, RcclLink, TorchLink
         nonlocal link_kind
+        if link_kind == "peer":
+            # mailboxes in the neighbours' device memory, written by the step's own kernels; checked once with a few
+            # halo exchanges on every subdomain -- if they do not all come through (no peer access between two GPUs),
+            # every subdomain falls back to RCCL together
+            lp_open = args.workload == "laser_plasma"
+            try:
+                lk = PeerLink(r, w, device, particle_capacity=link_capacity, stream=torch.cuda.current_stream().cuda_stream)
+                if lk.self_test(to_left=not (lp_open and r == 0), to_right=not (lp_open and r == w - 1)):
+                    return lk
+                print("[bench] peer link self-test failed; using RCCL", file=sys.stderr)
+            except Exception as e:
+                print(f"[bench] peer link unavailable ({e}); using RCCL", file=sys.stderr)
+            link_kind = "rccl"
         if link_kind == "rccl":
             try:
                 lk = RcclLink(r, w, device, particle_capacity=link_capacity)
@@ -425,7 +438,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def link_kind_desc():
-        return {"rccl": "native RCCL send/recv on the simulation stream", "torch": "torch.distributed P2P (RCCL)"}.get(link_kind, link_kind)
+        return {"peer": "peer-mapped mailboxes over xGMI, written and awaited by the step's own kernels (no transport call)",
+                "rccl": "native RCCL send/recv on the simulation stream", "torch": "torch.distributed P2P (RCCL)"}.get(link_kind, link_kind)
 
     def barrier():
         torch.cuda.synchronize()
@@ -578,6 +592,14 @@ def main():
                 "ms_per_step": 1e3 * elapsed / steps,
                 "frac_of_hbm_roofline_whole_step": value * bpu / (world * HBM_PEAK_GBS * 1e9)}
 
+    def regroup(sim):
+        """A re-binning, so that the push workgroups' chunks are cut for the kernel form about to run (the electrostatic
+        launch takes chunks twice as long as the general kernel: pop_max_ppt) -- what a run that started in this form
+        would have had from its first re-binning on."""
+        for p in (sim.electrons, sim.ions):
+            if p is not None and len(p):
+                p.sort(sim.grid)
+
     def block(m, what, steps, extra=None):
         out = {"what": what, "value": m["value"], "unit": "particle-updates/s", "particles_total": m["n_total"], "steps": steps,
                "ms_per_step": m["ms_per_step"], "frac_of_hbm_roofline_whole_step": m["frac_of_hbm_roofline_whole_step"],
@@ -617,6 +639,8 @@ def main():
         if not args.unfused and not args.no_default_path:
             m_default = measure(sim, half, args.warmup, workload_key=wkey)
         oa.set_elision(False)
+        if m_default is not None:
+            regroup(sim)
         m = measure(sim, args.steps, args.warmup, preheat=m_default is None, workload_key=wkey)
     t_end = sim.t
 
@@ -679,6 +703,8 @@ def main():
             k2 = f"two_stream:{C2_CELLS}x{C2_NPC}"
             m2d = measure(sim2, half, args.warmup, workload_key=k2) if not (args.unfused or args.no_default_path) else None
             oa.set_elision(False)
+            if m2d is not None:
+                regroup(sim2)
             m2 = measure(sim2, args.steps, args.warmup, preheat=m2d is None, workload_key=k2)
             del sim2
             out["secondary"] = block(m2, f"two_stream, {C2_NPC} e- + {C2_NPC} e+ per cell, {C2_CELLS} cells (BASELINE configs[1]), "

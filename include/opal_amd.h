@@ -297,6 +297,26 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
 int opal_rccl_unique_id(const char *librccl_path, void *id128);
 int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle_capacity, int species_slots,
                           int fields_per_particle, const char *librccl_path, const void *unique_id, void *hip_stream);
+/* Peer-mapped mailboxes: no transport is called at all -- the kernels of the step write their messages straight
+ * into mailboxes in the neighbours' device memory (over xGMI between GPUs of one node) and wait for theirs
+ * (peer_device.hpp).  Replaces the blocking MPI_Sendrecv pairs of yee.rs:358-409 and particle/mod.rs:303-354 with
+ * zero launches and zero host calls per exchange on the fused step.  Set-up: every subdomain creates its link,
+ * exports the 64-byte handle of its mailboxes (hipIpcGetMemHandle), the handles travel by any means (one
+ * all-gather), and every subdomain connects with its left and right neighbour's handle; NULL for a neighbour means
+ * "myself" (a lone periodic subdomain exchanging with itself).  When both neighbours are the same subdomain
+ * (two subdomains, periodic) pass the same handle twice. */
+#define OPAL_PEER_HANDLE_BYTES 64
+int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle_capacity, int species_slots,
+                          int fields_per_particle, void *hip_stream);
+int opal_link_peer_export(opal_link_t *l, void *handle64);
+int opal_link_peer_connect(opal_link_t *l, const void *left_handle64, const void *right_handle64);
+/* Synchronises the link's stream and reports: timeouts != 0 if a wait for a neighbour's message ever gave up (the
+ * call then fails with OPAL_ERR_LINK), the kind of memory the mailboxes live in (0 uncached, 1 fine-grained, 2
+ * plain), and the number of exchanges made so far. */
+int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges);
+/* n halo-only exchanges with the neighbours on the link's stream, then a synchronisation: 0 if they completed (any
+ * kind of link).  Collective in the sense that the neighbours must make the same calls. */
+int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n);
 /* Ranks of the RCCL communicator behind a link made by opal_link_create_rccl (ncclCommCount): lets a caller
  * report that the subdomains really are joined by one RCCL communicator. */
 int opal_link_rccl_ranks(const opal_link_t *l, int *out);

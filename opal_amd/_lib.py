@@ -106,6 +106,11 @@ SIGNATURES = {
     "opal_link_set_bounded": (C.c_int, [vp, C.c_int]),
     "opal_link_last_exchange_bytes": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz)]),
     "opal_link_rccl_ranks": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "opal_link_create_peer": (C.c_int, [pp, C.c_int, C.c_int, sz, C.c_int, C.c_int, vp]),
+    "opal_link_self_test": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "opal_link_peer_export": (C.c_int, [vp, vp]),
+    "opal_link_peer_connect": (C.c_int, [vp, vp, vp]),
+    "opal_link_peer_status": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "opal_rccl_unique_id": (C.c_int, [C.c_char_p, vp]),
     "opal_link_create_rccl": (C.c_int, [pp, C.c_int, C.c_int, sz, C.c_int, C.c_int, C.c_char_p, vp, vp]),
     "opal_link_create_layout": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.c_int, EXCHANGE_FN, vp, vp]),

@@ -14,6 +14,7 @@
 #include "pic_device.hpp"
 #include "grid_device.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -41,81 +42,27 @@ __global__ void k_pack_halo(const double *__restrict__ eb, const double *__restr
 __global__ void k_synchronize(SyncArgs a) { synchronize_body(a); }
 
 constexpr int FT = 256;       // cells written per workgroup
-constexpr int FH = 2;         // halo cells recomputed on each side
-constexpr int FW = FT + 2 * FH;
 
-// YeeGrid::advance, yee.rs:345-349 = advance_B(dt/2) (:839-848), advance_E(dt)
-// (:852-867), advance_B(dt/2), fused.  Each sub-step reads only the other field,
-// so it is order-independent inside the sub-step; a workgroup loads its tile plus
-// a 2-cell halo into LDS, runs the three sub-steps there and writes its tile to
-// the other field buffer.  The array ends follow the reference loops: B is not
-// advanced in the last cell, cell 0 gets the Silver-Mueller update.
-__global__ __launch_bounds__(FT) void k_advance(const double *__restrict__ src, double *__restrict__ dst,
-                                                const double *__restrict__ jr, double *__restrict__ jr_next,
-                                                size_t lenp, int len, double dt, double dx)
+// YeeGrid::advance (grid_device.hpp: advance_tile), one tile of FT cells per workgroup
+__global__ __launch_bounds__(FT) void k_advance(AdvArgs a)
 {
-    __shared__ double Ex[FW], Ey[FW], Ez[FW], By[FW], Bz[FW];
-    const int t = threadIdx.x;
-    const int s = blockIdx.x * FT;  // first cell written by this workgroup
-    for (int k = t; k < FW; k += FT) {
-        int i = s - FH + k;
-        bool in = i >= 0 && i < len;
-        Ex[k] = in ? src[0 * lenp + i] : 0.0;
-        Ey[k] = in ? src[1 * lenp + i] : 0.0;
-        Ez[k] = in ? src[2 * lenp + i] : 0.0;
-        By[k] = in ? src[4 * lenp + i] : 0.0;
-        Bz[k] = in ? src[5 * lenp + i] : 0.0;
-    }
-    __syncthreads();
-    const double hdt = 0.5 * dt;
-    // B half step on local cells k in [0, FW-1): needs E[k+1]
-    for (int k = t; k < FW - 1; k += FT) {
-        int i = s - FH + k;
-        if (i >= 0 && i < len - 1) {
-            By[k] += hdt * (Ez[k + 1] - Ez[k]) / dx;
-            Bz[k] += hdt * (Ey[k] - Ey[k + 1]) / dx;
-        }
-    }
-    __syncthreads();
-    // E full step on local cells k in [1, FW-1): needs B[k-1] (post half step)
-    for (int k = 1 + t; k < FW - 1; k += FT) {
-        int i = s - FH + k;
-        if (i == 0) {
-            double kappa = 2.0 * SPEED_OF_LIGHT * dt / (SPEED_OF_LIGHT * dt + dx);
-            double sigma = 1.0 - kappa;
-            Ex[k] = 0.0;
-            Ey[k] = sigma * Ey[k] - SPEED_OF_LIGHT * kappa * Bz[k];
-            Ez[k] = sigma * Ez[k] + SPEED_OF_LIGHT * kappa * By[k];
-        } else if (i > 0 && i < len) {
-            double jx = jr[0 * lenp + i], jy = jr[1 * lenp + i], jz = jr[2 * lenp + i];
-            Ex[k] += -dt * jx / VACUUM_PERMITTIVITY;
-            Ey[k] += dt * SPEED_OF_LIGHT_SQD * (Bz[k - 1] - Bz[k]) / dx - dt * jy / VACUUM_PERMITTIVITY;
-            Ez[k] += dt * SPEED_OF_LIGHT_SQD * (By[k] - By[k - 1]) / dx - dt * jz / VACUUM_PERMITTIVITY;
-        }
-    }
-    __syncthreads();
-    // second B half step on the tile proper, then write out
-    {
-        int k = FH + t, i = s + t;
-        if (i < len) {
-            double by = By[k], bz = Bz[k];
-            if (i < len - 1) {
-                by += hdt * (Ez[k + 1] - Ez[k]) / dx;
-                bz += hdt * (Ey[k] - Ey[k + 1]) / dx;
-            }
-            dst[0 * lenp + i] = Ex[k];
-            dst[1 * lenp + i] = Ey[k];
-            dst[2 * lenp + i] = Ez[k];
-            dst[3 * lenp + i] = src[3 * lenp + i];  // Bx: "nothing happens to Bx in 1D" (yee.rs:844)
-            dst[4 * lenp + i] = by;
-            dst[5 * lenp + i] = bz;
-            // YeeGrid::clear (yee.rs:543-549) for the next step, done on the spare current buffer: nobody
-            // reads it during this kernel, and the currents just used stay available to write_data
-            jr_next[0 * lenp + i] = 0.0;
-            jr_next[1 * lenp + i] = 0.0;
-            jr_next[2 * lenp + i] = 0.0;
-            jr_next[3 * lenp + i] = 0.0;
-        }
+    __shared__ double lds[5 * (FT + 2 * ADV_HALO)];
+    advance_tile<FT>(a, blockIdx.x * FT, a.len, threadIdx.x, lds);
+}
+
+constexpr int ADV_LDS = 2 * 5 * (ADV_EDGE + 2 * ADV_HALO);  // doubles: the synchronize workgroup's two edge tiles
+static_assert(ADV_LDS >= 5 * (ADV_TILE + 2 * ADV_HALO), "an interior tile fits the same array");
+
+// synchronize + advance in ONE launch: workgroup 0 runs synchronize and then advances the cells it touched (and their
+// stencil neighbours); the other workgroups advance the tiles in between, which depend on nothing synchronize writes
+__global__ __launch_bounds__(ADV_TILE) void k_sync_advance(SyncArgs sa, AdvArgs a)
+{
+    __shared__ double lds[ADV_LDS];
+    if (blockIdx.x == 0) {
+        synchronize_body(sa);
+        advance_edges(a, lds);
+    } else {
+        advance_interior(a, (int)blockIdx.x - 1, lds);
     }
 }
 
@@ -181,6 +128,7 @@ int check_grid(const opal_grid_t *g)
 }  // namespace
 
 namespace opal {
+int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz);
 // used by particles.hip and link.cpp
 int grid_pack_halo(opal_grid_t *g, double *send_left, double *send_right, hipStream_t st)
 {
@@ -206,6 +154,56 @@ void grid_sync_args(const opal_grid_t *g, const double *recv_left, const double 
     a.laser_y = ly;
     a.laser_z = lz;
     a.damp = g->d_damp;
+}
+
+// The arguments of the field solve for a caller that runs it inside a launch that also runs synchronize, and the
+// bookkeeping that follows such a launch (the ping-pong field buffers swap, the spare current block is zero again).
+// The edges: synchronize writes cells [0, 8) and the last max(8, R) (ghost overlay, laser cell 2 or so, absorbing /
+// conducting layer); a tile's stencil reaches 2 cells beyond what it writes.
+void grid_advance_args(const opal_grid_t *g, double dt, AdvArgs &a)
+{
+    a.src = g->d_eb[g->cur];
+    a.dst = g->d_eb[g->cur ^ 1];
+    a.jr = g->j();
+    a.jr_next = g->d_jb[g->jcur ^ 1];
+    a.lenp = g->lenp;
+    a.len = (int)g->len;
+    a.dt = dt;
+    a.dx = g->dx;
+    const int len = (int)g->len;
+    const int touched = std::max(std::max(g->R, 2 * GHOST_SIZE), g->L) + ADV_HALO;
+    a.edge_left = std::min(64, len / 2);
+    a.edge_right = (touched + 63) / 64 * 64;
+    if (len - a.edge_left <= ADV_EDGE || a.edge_right > ADV_EDGE) a.edge_right = len - a.edge_left;  // no interior
+}
+int grid_interior_tiles(const AdvArgs &a)
+{
+    const int n = a.len - a.edge_left - a.edge_right;
+    return n > 0 ? (n + ADV_TILE - 1) / ADV_TILE : 0;
+}
+void grid_advance_done(opal_grid_t *g)
+{
+    g->j_spare_zero = true;
+    g->cur ^= 1;
+}
+
+// synchronize + advance in one launch
+int grid_sync_advance(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, double dt)
+{
+    SyncArgs sa;
+    grid_sync_args(g, recv_left, recv_right, ly, lz, sa);
+    AdvArgs a;
+    grid_advance_args(g, dt, a);
+    if (a.edge_left > ADV_EDGE || a.edge_right > ADV_EDGE) {  // (a grid too short to have an interior, yet longer than one workgroup's edges)
+        if (int rc = grid_apply_sync(g, recv_left, recv_right, ly, lz)) return rc;
+        return opal_grid_advance(g, dt);
+    }
+    prof_begin(KERNEL_FIELD, g->stream);
+    k_sync_advance<<<1 + grid_interior_tiles(a), ADV_TILE, 0, g->stream>>>(sa, a);
+    prof_end(KERNEL_FIELD, g->stream);
+    OPAL_HIP(hipGetLastError());
+    grid_advance_done(g);
+    return OPAL_OK;
 }
 
 int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz)
@@ -381,13 +379,14 @@ int opal_grid_advance(opal_grid_t *g, double dt)
 {
     if (int rc = check_grid(g)) return rc;
     int nblk = (int)((g->len + FT - 1) / FT);
+    AdvArgs a;
+    grid_advance_args(g, dt, a);
+    a.edge_left = a.edge_right = 0;
     prof_begin(KERNEL_FIELD, g->stream);
-    k_advance<<<nblk, FT, 0, g->stream>>>(g->d_eb[g->cur], g->d_eb[g->cur ^ 1], g->j(), g->d_jb[g->jcur ^ 1], g->lenp,
-                                          (int)g->len, dt, g->dx);
-    g->j_spare_zero = true;
+    k_advance<<<nblk, FT, 0, g->stream>>>(a);
     prof_end(KERNEL_FIELD, g->stream);
     OPAL_HIP(hipGetLastError());
-    g->cur ^= 1;
+    grid_advance_done(g);
     return OPAL_OK;
 }
 

@@ -21,7 +21,140 @@ struct SyncArgs {
 };
 
 
+// YeeGrid::advance's device side.  grid.hip's k_advance runs one tile per workgroup over the whole grid.  Launches that
+// also run YeeGrid::synchronize (k_sync_advance; the tail kernel of a linked step, particles.hip) split the grid: the
+// cells synchronize writes -- the first and last 8, the laser cell, the absorbing or conducting layer -- and their
+// stencil neighbours belong to the ONE workgroup that runs synchronize, which advances them right afterwards
+// (edge_left cells at the left end, edge_right at the right end); every other tile depends on nothing synchronize
+// touches and is advanced by a workgroup of its own, concurrently -- in a linked step even while the neighbours'
+// messages are still on their way.
+struct AdvArgs {
+    const double *src;   // field buffer read (6 x lenp)
+    double *dst;         // field buffer written
+    const double *jr;    // currents of this step (4 x lenp)
+    double *jr_next;     // the spare current block, zeroed for the next step's deposits (YeeGrid::clear, yee.rs:543-549)
+    size_t lenp;
+    int len;
+    double dt, dx;
+    int edge_left, edge_right;  // cells the synchronize workgroup advances itself (0, 0: nobody runs synchronize here)
+};
+
+// host side (grid.hip)
+void grid_sync_args(const opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, SyncArgs &a);
+void grid_advance_args(const opal_grid_t *g, double dt, AdvArgs &a);  // with the edge split for a synchronize workgroup
+void grid_advance_done(opal_grid_t *g);  // after a launch that ran the field solve with grid_advance_args
+int grid_interior_tiles(const AdvArgs &a);  // workgroups of ADV_TILE cells between the two edges
+int grid_sync_advance(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, double dt);
+
+constexpr int ADV_TILE = 1024;  // cells per interior workgroup of the launches that also run synchronize
+constexpr int ADV_EDGE = 512;   // at most this many cells per end for the synchronize workgroup (half its threads each)
+
 #ifdef __HIPCC__
+constexpr int ADV_HALO = 2;  // halo cells recomputed on each side of a tile
+
+// YeeGrid::advance, yee.rs:345-349 = advance_B(dt/2) (:839-848), advance_E(dt) (:852-867), advance_B(dt/2), fused,
+// for the cells [s, min(s + T, e)).  Each sub-step reads only the other field, so it is order-independent inside the
+// sub-step; a group of T threads (t = the thread's index in it) loads its tile plus a 2-cell halo into LDS
+// (5 x (T + 4) doubles), runs the three sub-steps there and writes its tile to the other field buffer.  The array
+// ends follow the reference loops: B is not advanced in the last cell, cell 0 gets the Silver-Mueller update.
+// Contains workgroup barriers: every thread of the workgroup must call it (groups with nothing to do pass e <= s).
+template <int T>
+__device__ inline void advance_tile(const AdvArgs &a, int s, int e, int t, double *lds)
+{
+    constexpr int FH = ADV_HALO, FW = T + 2 * FH;
+    double *Ex = lds, *Ey = lds + FW, *Ez = lds + 2 * FW, *By = lds + 3 * FW, *Bz = lds + 4 * FW;
+    const size_t lenp = a.lenp;
+    const int len = a.len;
+    const double dt = a.dt, dx = a.dx;
+    const bool work = e > s;
+    if (work)
+        for (int k = t; k < FW; k += T) {
+            int i = s - FH + k;
+            bool in = i >= 0 && i < len;
+            Ex[k] = in ? a.src[0 * lenp + i] : 0.0;
+            Ey[k] = in ? a.src[1 * lenp + i] : 0.0;
+            Ez[k] = in ? a.src[2 * lenp + i] : 0.0;
+            By[k] = in ? a.src[4 * lenp + i] : 0.0;
+            Bz[k] = in ? a.src[5 * lenp + i] : 0.0;
+        }
+    // (the currents the E step needs are requested now, so that their latency overlaps the B half step)
+    double jx0 = 0.0, jy0 = 0.0, jz0 = 0.0, jx1 = 0.0, jy1 = 0.0, jz1 = 0.0;
+    {
+        int i = s - FH + 1 + t;  // the E step's first pass: k = 1 + t
+        if (work && i > 0 && i < len) { jx0 = a.jr[0 * lenp + i]; jy0 = a.jr[1 * lenp + i]; jz0 = a.jr[2 * lenp + i]; }
+        i += T;                  // ... and its second (k = 1 + t + T < FW - 1 only for t < 2)
+        if (work && t < FW - 2 - T && i > 0 && i < len) { jx1 = a.jr[0 * lenp + i]; jy1 = a.jr[1 * lenp + i]; jz1 = a.jr[2 * lenp + i]; }
+    }
+    __syncthreads();
+    const double hdt = 0.5 * dt;
+    // B half step on local cells k in [0, FW-1): needs E[k+1]
+    if (work)
+        for (int k = t; k < FW - 1; k += T) {
+            int i = s - FH + k;
+            if (i >= 0 && i < len - 1) {
+                By[k] += hdt * (Ez[k + 1] - Ez[k]) / dx;
+                Bz[k] += hdt * (Ey[k] - Ey[k + 1]) / dx;
+            }
+        }
+    __syncthreads();
+    // E full step on local cells k in [1, FW-1): needs B[k-1] (post half step)
+    if (work)
+        for (int k = 1 + t, pass = 0; k < FW - 1; k += T, pass++) {
+            int i = s - FH + k;
+            if (i == 0) {
+                double kappa = 2.0 * SPEED_OF_LIGHT * dt / (SPEED_OF_LIGHT * dt + dx);
+                double sigma = 1.0 - kappa;
+                Ex[k] = 0.0;
+                Ey[k] = sigma * Ey[k] - SPEED_OF_LIGHT * kappa * Bz[k];
+                Ez[k] = sigma * Ez[k] + SPEED_OF_LIGHT * kappa * By[k];
+            } else if (i > 0 && i < len) {
+                double jx = pass ? jx1 : jx0, jy = pass ? jy1 : jy0, jz = pass ? jz1 : jz0;
+                Ex[k] += -dt * jx / VACUUM_PERMITTIVITY;
+                Ey[k] += dt * SPEED_OF_LIGHT_SQD * (Bz[k - 1] - Bz[k]) / dx - dt * jy / VACUUM_PERMITTIVITY;
+                Ez[k] += dt * SPEED_OF_LIGHT_SQD * (By[k] - By[k - 1]) / dx - dt * jz / VACUUM_PERMITTIVITY;
+            }
+        }
+    __syncthreads();
+    // second B half step on the tile proper, then write out
+    {
+        int k = FH + t, i = s + t;
+        if (work && i < len && i < e) {
+            double by = By[k], bz = Bz[k];
+            if (i < len - 1) {
+                by += hdt * (Ez[k + 1] - Ez[k]) / dx;
+                bz += hdt * (Ey[k] - Ey[k + 1]) / dx;
+            }
+            a.dst[0 * lenp + i] = Ex[k];
+            a.dst[1 * lenp + i] = Ey[k];
+            a.dst[2 * lenp + i] = Ez[k];
+            a.dst[3 * lenp + i] = a.src[3 * lenp + i];  // Bx: "nothing happens to Bx in 1D" (yee.rs:844)
+            a.dst[4 * lenp + i] = by;
+            a.dst[5 * lenp + i] = bz;
+            // YeeGrid::clear (yee.rs:543-549) for the next step, done on the spare current buffer: nobody
+            // reads it during this kernel, and the currents just used stay available to write_data
+            a.jr_next[0 * lenp + i] = 0.0;
+            a.jr_next[1 * lenp + i] = 0.0;
+            a.jr_next[2 * lenp + i] = 0.0;
+            a.jr_next[3 * lenp + i] = 0.0;
+        }
+    }
+}
+
+// what the workgroup that runs synchronize (1024 threads) does next: the two ends of the grid, half its threads each
+__device__ inline void advance_edges(const AdvArgs &a, double *lds /* 2 x 5 x (ADV_EDGE + 4) doubles */)
+{
+    const int half = threadIdx.x >> 9, t = threadIdx.x & (ADV_EDGE - 1);
+    const int s = half ? a.len - a.edge_right : 0;
+    const int e = half ? a.len : a.edge_left;
+    __syncthreads();  // synchronize's writes are done
+    advance_tile<ADV_EDGE>(a, s, e, t, lds + half * 5 * (ADV_EDGE + 2 * ADV_HALO));
+}
+// ... and an interior workgroup (ADV_TILE threads): tile number `tile` between the edges
+__device__ inline void advance_interior(const AdvArgs &a, int tile, double *lds /* 5 x (ADV_TILE + 4) doubles */)
+{
+    advance_tile<ADV_TILE>(a, a.edge_left + tile * ADV_TILE, a.len - a.edge_right, threadIdx.x, lds);
+}
+
 constexpr int HALO_CELLS = 2 * GHOST_SIZE;    // yee.rs:353-354
 constexpr int HALO_COMPS = 10;                // rho j[3] E[3] B[3]
 constexpr int HALO_DOUBLES = HALO_CELLS * HALO_COMPS;

@@ -217,6 +217,7 @@ int opal_link_free(opal_link_t *l)
 {
     if (!l) return OPAL_OK;
     if (l->user_free) l->user_free(l->user);
+    link_peer_free(l);
     if (!(l->external && l->device_buffers)) {
         hipFree(l->d_send_left); hipFree(l->d_send_right); hipFree(l->d_recv_left); hipFree(l->d_recv_right);
     }

@@ -76,6 +76,8 @@ struct opal_link {
     unsigned send_cap[2];    // slots (a multiple of 64) the next exchange ships per species: left / right edge
     bool bounded;            // sizes follow the bounds (needs exchange2); else every exchange ships all `cap` slots
     size_t last_bytes[2];    // what the last whole-message exchange moved per edge (diagnostic)
+    // peer-mapped mailboxes (peer.hip, peer_device.hpp): the kernels of the step move the messages themselves
+    struct opal_peer *peer;  // null for transports that are called (RCCL, torch.distributed, host callbacks)
 };
 
 namespace opal {
@@ -91,4 +93,12 @@ int link_exchange_halo(opal_link_t *l, bool to_left, bool to_right, hipStream_t 
 // whole messages, each edge as long as link_plan decided
 int link_exchange_particles(opal_link_t *l, bool to_left, bool to_right, hipStream_t st);
 bool link_can_use_stream(const opal_link_t *l, hipStream_t st);
+// peer.hip
+struct PeerArgs;
+struct HaloSrc;
+bool link_is_peer(const opal_link_t *l);
+// the arguments with which a kernel of the step makes the NEXT exchange itself (advances the link's sequence); halo
+// = where the halo is packed from, or null when the send messages already hold it
+int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, const HaloSrc *halo, PeerArgs &a);
+void link_peer_free(opal_link_t *l);
 }  // namespace opal

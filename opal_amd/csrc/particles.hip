@@ -22,6 +22,7 @@
 #include "opal_internal.hpp"
 #include "pic_device.hpp"
 #include "grid_device.hpp"
+#include "peer_device.hpp"
 #include "qed_device.hpp"
 
 #include <algorithm>
@@ -1109,14 +1110,24 @@ struct UnpackArgs {
     int *es_flag;         // an arrival with transverse momentum ends the electrostatic launches (ctr->hot_yz, grid flag)
 };
 
-// up to three species per launch (blocks 2 s and 2 s + 1 belong to species s).  The first workgroup also files
-// this exchange's zone counts -- mine from the send headers, the neighbours' from the received ones -- in the
-// link's mapped host ring (link.cpp), and then zeroes the send headers for the next step (they have been shipped).
+// The tail of a linked step, one launch: up to three species' arrivals (blocks 2 s and 2 s + 1 belong to species s), and,
+// in one more workgroup, YeeGrid::synchronize (has_sync) followed by the whole field solve of a small subdomain
+// (has_adv).  With a peer link (peer.enabled) the launch IS the exchange: workgroup 0 first writes this subdomain's two
+// messages -- header, the halo packed straight from the grid rows, the row blocks the leavers occupy -- into the
+// neighbours' mailboxes, and every workgroup waits for the neighbours' messages before it reads them (peer_device.hpp).
+// The first workgroup also files this exchange's zone counts -- mine from the send headers, the neighbours' from the
+// received ones -- in the link's mapped host ring (link.cpp: transports whose message sizes the host plans), zeroes the
+// send headers for the next step (they have been shipped) and publishes the re-binning policy's counters when a check
+// is due (pub.n: what k_publish_counters does on the unlinked path).
 struct UnpackBatch {
     UnpackArgs a[3];
     int n;
     int has_sync;   // one more workgroup runs YeeGrid::synchronize's kernel (the fused linked step: independent work)
     SyncArgs sync;
+    int has_adv;    // ... and then YeeGrid::advance, tile after tile (small grids: grid_is_small)
+    AdvArgs adv;
+    PeerArgs peer;
+    PublishBatch pub;
     unsigned *zero[2];
     const unsigned *send_head[2], *recv_head[2];  // null where there is no neighbour
     LinkBounds *bounds;                            // ring entry of this exchange (mapped host memory), or null
@@ -1125,9 +1136,37 @@ struct UnpackBatch {
 
 __device__ void unpack_one(const UnpackArgs &a, int side);
 
-__global__ void k_unpack(UnpackBatch b)
+__device__ inline void publish_counters(const PublishBatch &b)
 {
-    if (blockIdx.x == 0) {
+    static_assert(sizeof(PopCounters) == 64, "one word per lane below");
+    const int e = threadIdx.x >> 4, w = threadIdx.x & 15;
+    if (threadIdx.x < 64) {
+        if (e < b.n) reinterpret_cast<volatile unsigned *>(&b.dst[e]->c)[w] = reinterpret_cast<const unsigned *>(b.src[e])[w];
+        __threadfence_system();
+        if (e < b.n && w == 0) b.dst[e]->seq = b.seq[e];
+    }
+}
+
+template <int NT, bool ADV>
+__global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
+{
+    static_assert(!ADV || NT == ADV_TILE, "the field solve's workgroups are ADV_TILE threads");
+    __shared__ double s_adv[ADV ? 2 * 5 * (ADV_EDGE + 2 * ADV_HALO) : 1];
+    const unsigned n_unpack = b.n ? 2u * (unsigned)b.n : 1u;
+    if (ADV && blockIdx.x > n_unpack) {
+        // an interior tile of the field solve: nothing synchronize or the neighbours' messages touch -- no waiting
+        advance_interior(b.adv, (int)(blockIdx.x - n_unpack) - 1, s_adv);
+        return;
+    }
+    // the workgroup that runs synchronize (workgroup 0 where none does) also keeps the link's books.  It is the one
+    // that SENDS over a peer link: it reads this subdomain's edge cells for the halo, and must have done so before it
+    // overlays the neighbours' halos on them
+    const bool boss = b.has_sync ? blockIdx.x == n_unpack : blockIdx.x == 0;
+    if (b.peer.enabled) {
+        if (boss) peer_send(b.peer);  // (ends behind a barrier: the send messages have been read)
+        peer_wait(b.peer);
+    }
+    if (boss) {
         if (b.bounds && threadIdx.x < 6) {
             const int side = threadIdx.x / 3, sp = threadIdx.x % 3;
             b.bounds->mine[side][sp] = b.send_head[side] ? b.send_head[side][LINK_H_ZONE + sp] : 0u;
@@ -1142,10 +1181,11 @@ __global__ void k_unpack(UnpackBatch b)
             if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
             if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
         }
+        if (b.pub.n) publish_counters(b.pub);
     }
-    const unsigned n_unpack = b.n ? 2u * (unsigned)b.n : 1u;
     if (blockIdx.x >= n_unpack) {  // (only launched when has_sync)
         synchronize_body(b.sync);
+        if (ADV && b.has_adv) advance_edges(b.adv, s_adv);  // the cells synchronize wrote, and their stencil neighbours
         return;
     }
     if (b.n) unpack_one(b.a[blockIdx.x >> 1], blockIdx.x & 1);
@@ -1672,10 +1712,16 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     return OPAL_OK;
 }
 
-// appends what the neighbours sent (already in the link's recv buffers) to the populations, one launch;
-// with zero_counts the send messages' leaver counts are reset for the next step (instead of link_begin)
+// appends what the neighbours sent to the populations, one launch (k_link_tail); with zero_counts the send messages'
+// leaver counts are reset for the next step (instead of link_begin).
+//   sync          YeeGrid::synchronize runs in the same launch (its own workgroup)
+//   adv           ... followed there by the field solve (small grids)
+//   peer_exchange the launch makes the exchange itself over the link's peer-mapped mailboxes (the messages are NOT in
+//                 the recv buffers yet: nothing has been called since the push); otherwise they have been moved already
+//   pub           counters the re-binning policy wants published by this launch
 int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g, bool zero_counts,
-                    const SyncArgs *sync = nullptr)
+                    const SyncArgs *sync = nullptr, const AdvArgs *adv = nullptr, bool peer_exchange = false,
+                    const PublishBatch *pub = nullptr)
 {
     if (g->left_bdy != OPAL_BDY_INTERNAL && g->right_bdy != OPAL_BDY_INTERNAL) {
         if (sync) {
@@ -1690,6 +1736,12 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.has_sync = 1;
         b.sync = *sync;
     }
+    if (adv && sync && adv->edge_left <= ADV_EDGE && adv->edge_right <= ADV_EDGE) {
+        b.has_adv = 1;
+        b.adv = *adv;
+    }
+    if (pub) b.pub = *pub;
+    const bool nb[2] = {g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL};
     hipStream_t st = nullptr;
     for (int i = 0; i < npops && b.n < 3; i++) {
         if (!pops[i]) continue;
@@ -1698,12 +1750,22 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.n++;
     }
     if (!b.n) st = link->stream;  // nobody to unpack for: the kernel still files this exchange's bounds (link.cpp)
+    if (peer_exchange) {
+        HaloSrc hs{g->d_eb[g->cur], g->j(), g->lenp, (int)g->len};
+        if (int rc = link_peer_next(link, nb[0], nb[1], false, &hs, b.peer)) return rc;
+        link->xseq++;
+        for (int side = 0; side < 2; side++) {
+            const char *msg = b.peer.box[side] ? b.peer.box[side] + PEER_FLAG_BYTES : nullptr;
+            for (int i = 0; i < b.n; i++) b.a[i].recv[side] = msg;
+            const double *halo = msg ? reinterpret_cast<const double *>(msg + LINK_HEADER_BYTES) : nullptr;
+            if (sync) (side == 0 ? b.sync.recv_left : b.sync.recv_right) = halo;
+        }
+    }
     if (zero_counts) {
         b.zero[0] = reinterpret_cast<unsigned *>(link_send(link, 0));
         b.zero[1] = reinterpret_cast<unsigned *>(link_send(link, 1));
     }
-    if (link->d_bounds && link->xseq) {  // the exchange just made is number xseq - 1
-        const bool nb[2] = {g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL};
+    if (link->d_bounds && link->xseq && !link_is_peer(link)) {  // the exchange just made is number xseq - 1
         for (int side = 0; side < 2; side++) {
             b.send_head[side] = nb[side] ? reinterpret_cast<const unsigned *>(link_send(link, side)) : nullptr;
             b.recv_head[side] = nb[side] ? reinterpret_cast<const unsigned *>(link_recv(link, side)) : nullptr;
@@ -1711,7 +1773,9 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.bounds = &link->d_bounds[(link->xseq - 1) % LINK_RING];
         b.seq = link->xseq;
     }
-    k_unpack<<<(b.n ? 2 * b.n : 1) + b.has_sync, 256, 0, st>>>(b);
+    const unsigned nblk = (b.n ? 2 * b.n : 1) + b.has_sync;
+    if (b.has_adv) k_link_tail<ADV_TILE, true><<<nblk + grid_interior_tiles(b.adv), ADV_TILE, 0, st>>>(b);
+    else k_link_tail<256, false><<<nblk, 256, 0, st>>>(b);
     OPAL_HIP(hipGetLastError());
     if (zero_counts) link->counts_clean = true;
     // (only once the reservations since the last snapshot add up to a few per cent of the population: a
@@ -1924,12 +1988,17 @@ int wait_published(const opal_pop_t *p)
     return OPAL_OK;
 }
 
-int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
+// One step of the re-binning policy for `p`: counts the step, reads the counters published a check ago, asks for the
+// next publication (into the PublishScope alive around the call, or by a launch of its own) and says whether the
+// population should be re-binned now.  The caller re-bins (do_sort) -- after anything it still has to launch for this
+// step (the linked step's tail kernel carries the publication and must see the slots where the push left them).
+int policy_step(opal_pop_t *p, bool &sort_now)
 {
+    sort_now = false;
     p->steps_since_sort++;
     if (p->sort_interval == 0) return OPAL_OK;
     if (p->sort_interval > 0) {
-        if (p->steps_since_sort >= p->sort_interval) return do_sort(p, g);
+        sort_now = p->steps_since_sort >= p->sort_interval;
         return OPAL_OK;
     }
     // adaptive ("rent or buy"): every few steps read the tile-miss counters; once the time lost to misses since the
@@ -1980,13 +2049,20 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
         p->dead_cost += (double)seen.n_dead * 36.0 * check_every;
         if (p->dead_cost > 100.0 * (double)seen.n_slots && seen.n_dead > 0) {
             p->dead_cost = 0.0;
-            return do_sort(p, g);
+            sort_now = true;
         }
         return OPAL_OK;
     }
     double lost_ms = ((double)seen.n_slow_pass * pass_ns + (double)seen.n_slow * miss_ns) * 1e-6;
-    if (lost_ms > sort_ms) return do_sort(p, g);
+    sort_now = lost_ms > sort_ms;
     return OPAL_OK;
+}
+
+int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
+{
+    bool sort_now;
+    if (int rc = policy_step(p, sort_now)) return rc;
+    return sort_now ? do_sort(p, g) : OPAL_OK;
 }
 
 }  // namespace
@@ -2590,14 +2666,27 @@ int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opa
 {
     return unpack_arrivals(pops, npops, link, g, true);
 }
+// ... `sync` (and `adv`: the field solve of a small grid) run in the same launch; with `peer_exchange` that launch also
+// makes the exchange (peer-mapped mailboxes).  The policy's counters are published by it too.
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g,
-                               const SyncArgs *sync)
+                               const SyncArgs *sync, const AdvArgs *adv, bool peer_exchange)
 {
-    if (int rc = unpack_arrivals(pops, npops, link, g, true, sync)) return rc;
-    PublishScope scope;  // the species' counters go out in one launch
-    for (int i = 0; i < npops; i++)
-        if (pops[i])
-            if (int rc = maybe_sort(pops[i], g)) return rc;
+    bool sort_now[4] = {};
+    PublishBatch pub{};
+    {
+        PublishScope scope;  // collects what the species ask to have published ...
+        for (int i = 0; i < npops && i < 4; i++)
+            if (pops[i])
+                if (int rc = policy_step(pops[i], sort_now[i])) return rc;
+        if (scope.b.n && scope.stream == (pops[0] ? pops[0]->stream : link->stream)) {
+            pub = scope.b;  // ... and hands it to the tail kernel instead of launching
+            scope.b.n = 0;
+        }
+    }
+    if (int rc = unpack_arrivals(pops, npops, link, g, true, sync, adv, peer_exchange, &pub)) return rc;
+    for (int i = 0; i < npops && i < 4; i++)
+        if (pops[i] && sort_now[i])
+            if (int rc = do_sort(pops[i], g)) return rc;
     return OPAL_OK;
 }
 }

@@ -1,0 +1,238 @@
+// Host side of the peer-mapped mailboxes (peer_device.hpp) and the stand-alone exchange kernel that lets every
+// existing exchange point (opal_grid_synchronize's halo-only exchange, the separate-operator step's whole
+// messages) run over them unchanged; the fused linked step does the same inside its own tail kernel
+// (particles.hip: k_link_tail).
+#include "peer_device.hpp"
+
+#include <cstring>
+
+using namespace opal;
+
+struct opal_peer {
+    char *box_mem = nullptr;   // my four mailboxes: [from left | from right] x [parity 0 | 1], each `stride` bytes
+    size_t stride = 0;         // flag line + message, rounded up to 256
+    char *peer_base[2] = {nullptr, nullptr};  // where my messages go: the left neighbour's from-right pair, the right neighbour's from-left pair
+    void *mapped[2] = {nullptr, nullptr};     // hipIpcOpenMemHandle mappings to close (null: the neighbour is in this process)
+    unsigned *d_err = nullptr;
+    unsigned seq = 0;          // exchanges made so far
+    bool connected = false;
+    int alloc_kind = 0;        // 0 uncached, 1 fine-grained, 2 plain device memory
+};
+
+namespace {
+
+// One workgroup: send both messages, wait for the neighbours', copy what arrived into the link's recv buffers (the
+// unpack and synchronize kernels of the unfused paths read them there).
+__global__ __launch_bounds__(1024) void k_peer_move(PeerArgs a, char *recv_left, char *recv_right)
+{
+    peer_send(a);
+    peer_wait(a);
+    for (int side = 0; side < 2; side++) {
+        if (!a.box[side]) continue;
+        const char *msg = a.box[side] + PEER_FLAG_BYTES;
+        const unsigned words = peer_prefix_words(msg, a);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(side == 0 ? recv_left : recv_right);
+        for (unsigned i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+int peer_exchange2(void *user, const void *send_left, const void *send_right, void *recv_left, void *recv_right,
+                   size_t n_left, size_t n_right)
+{
+    opal_link_t *l = static_cast<opal_link_t *>(user);
+    PeerArgs a;
+    const bool head_only = (send_left ? n_left : n_right) == LINK_HEAD_BYTES;
+    if (link_peer_next(l, send_left != nullptr, send_right != nullptr, head_only, nullptr, a)) return 1;
+    a.send[0] = static_cast<const char *>(send_left);
+    a.send[1] = static_cast<const char *>(send_right);
+    k_peer_move<<<1, 1024, 0, l->stream>>>(a, static_cast<char *>(recv_left), static_cast<char *>(recv_right));
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+int peer_exchange(void *user, const void *send_left, const void *send_right, void *recv_left, void *recv_right, size_t nbytes)
+{
+    return peer_exchange2(user, send_left, send_right, recv_left, recv_right, nbytes, nbytes);
+}
+
+}  // namespace
+
+namespace opal {
+
+bool link_is_peer(const opal_link_t *l) { return l && l->peer && l->peer->connected; }
+
+int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, const HaloSrc *halo, PeerArgs &a)
+{
+    opal_peer *p = l->peer;
+    if (!p || !p->connected) {
+        set_error("peer link: not connected (opal_link_peer_connect)");
+        return OPAL_ERR_LINK;
+    }
+    memset(&a, 0, sizeof a);
+    const unsigned par = p->seq & 1u;
+    p->seq++;
+    a.enabled = 1;
+    a.seq = p->seq;
+    a.layout = l->layout;
+    a.cap = (unsigned)l->cap;
+    a.head_only = head_only;
+    a.err = p->d_err;
+    if (halo) {
+        a.pack_halo = 1;
+        a.halo = *halo;
+    }
+    // what I send left lands in the left neighbour's from-right mailbox, and the other way round
+    if (to_left) {
+        a.send[0] = l->d_send_left;
+        a.dst[0] = p->peer_base[0] + par * p->stride;
+        a.box[0] = p->box_mem + (0 * 2 + par) * p->stride;
+    }
+    if (to_right) {
+        a.send[1] = l->d_send_right;
+        a.dst[1] = p->peer_base[1] + par * p->stride;
+        a.box[1] = p->box_mem + (1 * 2 + par) * p->stride;
+    }
+    return OPAL_OK;
+}
+
+void link_peer_free(opal_link_t *l)
+{
+    opal_peer *p = l->peer;
+    if (!p) return;
+    for (int s = 0; s < 2; s++)
+        if (p->mapped[s] && (s == 0 || p->mapped[1] != p->mapped[0])) hipIpcCloseMemHandle(p->mapped[s]);
+    if (p->box_mem) hipFree(p->box_mem);
+    if (p->d_err) hipFree(p->d_err);
+    delete p;
+    l->peer = nullptr;
+}
+
+}  // namespace opal
+
+extern "C" {
+
+int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges);
+
+int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle_capacity, int species_slots,
+                          int fields_per_particle, void *hip_stream)
+{
+    if (!out) {
+        set_error("opal_link_create_peer: null output");
+        return OPAL_ERR_ARG;
+    }
+    int rc = opal_link_create_layout(out, rank, size, 1, particle_capacity, species_slots, fields_per_particle, peer_exchange,
+                                     nullptr, hip_stream);
+    if (rc) return rc;
+    opal_link_t *l = *out;
+    l->user = l;
+    l->exchange2 = peer_exchange2;
+    l->bounded = false;  // nothing to plan: the sending kernel ships what the leavers occupy
+    opal_peer *p = new opal_peer();
+    l->peer = p;
+    p->stride = (PEER_FLAG_BYTES + l->nbytes + 255) / 256 * 256;
+    const size_t total = 4 * p->stride;
+    // memory both ends see coherently: uncached, else fine-grained; OPAL_PEER_ALLOC=plain|fine|uncached overrides
+    const char *want = getenv("OPAL_PEER_ALLOC");
+    hipError_t e = hipErrorUnknown;
+    if (!want || !strcmp(want, "uncached")) {
+        e = hipExtMallocWithFlags((void **)&p->box_mem, total, hipDeviceMallocUncached);
+        p->alloc_kind = 0;
+    }
+    if (e != hipSuccess && (!want || !strcmp(want, "fine"))) {
+        e = hipExtMallocWithFlags((void **)&p->box_mem, total, hipDeviceMallocFinegrained);
+        p->alloc_kind = 1;
+    }
+    if (e != hipSuccess && want && !strcmp(want, "plain")) {
+        e = hipMalloc((void **)&p->box_mem, total);
+        p->alloc_kind = 2;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        p->box_mem = nullptr;
+        opal_link_free(l);
+        *out = nullptr;
+        return hip_fail(e, "allocating the peer mailboxes");
+    }
+    OPAL_HIP(hipMemset(p->box_mem, 0, total));
+    OPAL_HIP(hipMalloc((void **)&p->d_err, sizeof(unsigned)));
+    OPAL_HIP(hipMemset(p->d_err, 0, sizeof(unsigned)));
+    OPAL_HIP(hipDeviceSynchronize());
+    return OPAL_OK;
+}
+
+int opal_link_peer_export(opal_link_t *l, void *handle64)
+{
+    if (!l || !l->peer || !handle64) {
+        set_error("opal_link_peer_export: not a link made by opal_link_create_peer");
+        return OPAL_ERR_ARG;
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == OPAL_PEER_HANDLE_BYTES, "IPC handle size");
+    hipIpcMemHandle_t h;
+    OPAL_HIP(hipIpcGetMemHandle(&h, l->peer->box_mem));
+    memcpy(handle64, &h, sizeof h);
+    return OPAL_OK;
+}
+
+int opal_link_peer_connect(opal_link_t *l, const void *left_handle64, const void *right_handle64)
+{
+    if (!l || !l->peer) {
+        set_error("opal_link_peer_connect: not a link made by opal_link_create_peer");
+        return OPAL_ERR_ARG;
+    }
+    opal_peer *p = l->peer;
+    if (p->connected) {
+        set_error("opal_link_peer_connect: already connected");
+        return OPAL_ERR_ARG;
+    }
+    const void *hs[2] = {left_handle64, right_handle64};
+    char *base[2];
+    for (int s = 0; s < 2; s++) {
+        if (!hs[s]) {
+            base[s] = p->box_mem;  // the neighbour on that side is this very link (a lone periodic subdomain)
+        } else if (s == 1 && hs[0] && !memcmp(hs[0], hs[1], OPAL_PEER_HANDLE_BYTES)) {
+            p->mapped[1] = p->mapped[0];  // two subdomains: both neighbours are the same one, mapped once
+            base[1] = base[0];
+        } else {
+            hipIpcMemHandle_t h;
+            memcpy(&h, hs[s], sizeof h);
+            OPAL_HIP(hipIpcOpenMemHandle(&p->mapped[s], h, hipIpcMemLazyEnablePeerAccess));
+            base[s] = static_cast<char *>(p->mapped[s]);
+        }
+    }
+    p->peer_base[0] = base[0] + 2 * p->stride;  // the left neighbour's from-right pair
+    p->peer_base[1] = base[1];                  // the right neighbour's from-left pair
+    p->connected = true;
+    return OPAL_OK;
+}
+
+int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n)
+{
+    if (!l) {
+        set_error("opal_link_self_test: null link");
+        return OPAL_ERR_ARG;
+    }
+    for (int k = 0; k < n; k++)
+        if (int rc = link_exchange_halo(l, to_left != 0, to_right != 0, l->stream)) return rc;
+    OPAL_HIP(hipStreamSynchronize(l->stream));
+    return l->peer ? opal_link_peer_status(l, nullptr, nullptr, nullptr) : OPAL_OK;
+}
+
+int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges)
+{
+    if (!l || !l->peer) {
+        set_error("opal_link_peer_status: not a link made by opal_link_create_peer");
+        return OPAL_ERR_ARG;
+    }
+    unsigned err = 0;
+    OPAL_HIP(hipMemcpyAsync(&err, l->peer->d_err, sizeof err, hipMemcpyDeviceToHost, l->stream));
+    OPAL_HIP(hipStreamSynchronize(l->stream));
+    if (timeouts) *timeouts = (int)(err & 1u);
+    if (alloc_kind) *alloc_kind = l->peer->alloc_kind;
+    if (exchanges) *exchanges = l->peer->seq;
+    if (err) {
+        set_error("peer link: a neighbour's message did not arrive within %.0f s", (double)PEER_TIMEOUT_TICKS / 1e8);
+        return OPAL_ERR_LINK;
+    }
+    return OPAL_OK;
+}
+
+}  // extern "C"

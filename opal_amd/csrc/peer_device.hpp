@@ -1,0 +1,126 @@
+// Peer-mapped mailboxes: the neighbour exchange done BY the kernels of the step, without a transport in between.
+//
+// Replaces, on one node, the reference's blocking MPI point-to-point traffic (yee.rs:351-409 for the halo,
+// particle/mod.rs:303-354 for migrating particles) and this library's own RCCL send/recv pair: every subdomain owns
+// four mailboxes in device memory that its neighbours can address (hipIpcOpenMemHandle across processes, the plain
+// pointer inside one) -- from the left and from the right neighbour, two of each, used alternately.  A step's kernel
+// writes its message (64-byte header, 640-byte halo, the row blocks the leavers occupy) straight into the
+// neighbour's mailbox over xGMI, publishes it with a sequence number stored behind a system-scope release, and
+// then waits for the sequence number in its own mailbox.  No launch, no host call and no size negotiation stands
+// between a push and the arrivals it exchanges: the message is as long as the leavers it carries.
+//
+// Why two mailboxes per direction suffice without acknowledgements: exchange k uses mailbox k & 1.  A neighbour
+// writes exchange k + 2 into the same mailbox only after it has finished its own exchange k + 1, which needed my
+// message k + 1, which I send after my unpack of exchange k has completed (stream order).  So the mailbox is
+// never overwritten before it has been read.
+//
+// Memory model.  The mailboxes are allocated uncached / fine-grained (peer.hip); payload words are written with
+// system-scope relaxed atomic stores (write-through), then the workgroup's barrier, then ONE lane issues a
+// system-scope fence and stores the sequence number (release).  The receiver's lane 0 polls it with system-scope
+// acquire loads, fences, and releases the rest of its workgroup through a barrier; payload loads follow.
+// Every wait is bounded (PEER_TIMEOUT_TICKS of the 100 MHz wall clock): a neighbour that never sends makes the
+// kernel raise an error word and carry on, so that every wave reaches its exit.
+#pragma once
+#include "link.hpp"
+
+namespace opal {
+constexpr size_t PEER_FLAG_BYTES = 64;          // the sequence number's line, in front of the message
+constexpr long long PEER_TIMEOUT_TICKS = 2000000000LL;  // 20 s of wall_clock64() (100 MHz)
+
+// what a packed halo is read from (grid rows), when the sending kernel packs it itself
+struct HaloSrc {
+    const double *eb, *jr;
+    size_t lenp;
+    int len;
+};
+
+struct PeerArgs {
+    int enabled;
+    const char *send[2];   // my outgoing messages (device buffers the push packed the leavers into); null: no neighbour there
+    char *dst[2];          // the neighbour's mailbox for this exchange: flag line, then the message
+    const char *box[2];    // my mailboxes for this exchange: [0] from the left neighbour, [1] from the right one
+    unsigned seq;          // this exchange's sequence number (>= 1, monotonic)
+    LinkLayout layout;
+    unsigned cap;          // slots per species a message has room for
+    int head_only;         // halo-only exchange (yee.rs:358-409 on its own): header + halo, no leavers
+    int pack_halo;         // the halo is taken from the grid rows (HaloSrc) instead of the send message
+    HaloSrc halo;
+    unsigned *err;         // device word: bit 0 = a neighbour's message never came
+};
+
+#ifdef __HIPCC__
+__device__ inline double halo_value(const HaloSrc &h, int side, int r)
+{
+    // yee.rs:353-354: send_left = cell[0..8], send_right = cell[len-8..len]; per cell rho j[3] E[3] B[3]
+    const int k = r / 10, comp = r % 10;
+    const int cellidx = side == 0 ? k : h.len - 8 + k;
+    if (comp == 0) return h.jr[3 * h.lenp + cellidx];
+    if (comp < 4) return h.jr[(size_t)(comp - 1) * h.lenp + cellidx];
+    return h.eb[(size_t)(comp - 4) * h.lenp + cellidx];
+}
+
+// bytes of a message that carry something: header + halo + the row blocks its leavers reach into
+__device__ inline unsigned peer_prefix_words(const char *msg, const PeerArgs &a)
+{
+    if (a.head_only) return (unsigned)(LINK_HEAD_BYTES / 8);
+    const unsigned *head = reinterpret_cast<const unsigned *>(msg);
+    unsigned m = 0;
+    for (unsigned s = 0; s < a.layout.nslots; s++) {
+        unsigned c = head[LINK_H_COUNT + s];
+        c = c < a.cap ? c : a.cap;
+        m = m > c ? m : c;
+    }
+    const unsigned blocks = (m + LINK_ROWS - 1) / LINK_ROWS;
+    return (unsigned)((LINK_HEAD_BYTES + (size_t)blocks * a.layout.nslots * a.layout.blk) / 8);
+}
+
+// Called by every thread of ONE workgroup: writes both outgoing messages into the neighbours' mailboxes and
+// publishes them.  Contains barriers.
+__device__ inline void peer_send(const PeerArgs &a)
+{
+    for (int side = 0; side < 2; side++) {
+        const char *msg = a.send[side];
+        if (!msg) continue;
+        const unsigned words = peer_prefix_words(msg, a);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES);
+        for (unsigned i = threadIdx.x; i < words; i += blockDim.x) {
+            unsigned long long v;
+            if (a.pack_halo && i >= LINK_HEADER_BYTES / 8 && i < LINK_HEAD_BYTES / 8)
+                v = (unsigned long long)__double_as_longlong(halo_value(a.halo, side, (int)(i - LINK_HEADER_BYTES / 8)));
+            else
+                v = src[i];
+            __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();  // (waits for every wave's stores to have left it)
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        for (int side = 0; side < 2; side++)
+            if (a.send[side])
+                __hip_atomic_store(reinterpret_cast<unsigned *>(a.dst[side]), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Called by every thread of a workgroup that is about to read what the neighbours sent.  Contains a barrier.
+__device__ inline void peer_wait(const PeerArgs &a)
+{
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        for (int side = 0; side < 2; side++) {
+            if (!a.box[side]) continue;
+            const unsigned *flag = reinterpret_cast<const unsigned *>(a.box[side]);
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+                if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+                    atomicOr(a.err, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+}
+#endif
+}  // namespace opal

@@ -25,8 +25,7 @@ int pop_check_err(opal_pop_t *p);
 int pop_push_fused_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_push_advance_noexchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt);
 int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g,
-                               const SyncArgs *sync);
-void grid_sync_args(const opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, SyncArgs &a);
+                               const SyncArgs *sync, const AdvArgs *adv, bool peer_exchange);
 int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
@@ -672,8 +671,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
             double ly, lz;
             laser_now(ly, lz);
-            if (int rc = grid_apply_sync(g, rl, rr, ly, lz)) return rc;
-            if (int rc = opal_grid_advance(g, s->dt)) return rc;
+            if (int rc = grid_sync_advance(g, rl, rr, ly, lz, s->dt)) return rc;
             s->t += s->dt;
             s->step_index++;
             continue;
@@ -688,6 +686,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             if (int rc = link_begin(s->link, st)) return rc;  // free after the first step: the unpack kernel re-zeroes
             const double *rl = nullptr, *rr = nullptr;
             const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
+            const bool peer = link_is_peer(s->link);
+            bool overlapped = false;
             // Overlap: only the particles within a few cells of the subdomain's ends can leave it or deposit
             // into the cells the halo carries, and after a re-binning they sit in the first and last chunks
             // of the arrays.  Those chunks are pushed on a second stream, BESIDE the bulk (the two launches share the
@@ -705,6 +705,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 OPAL_HIP(hipEventRecord(s->ev_comm, s->comm_stream));
                 OPAL_HIP(hipStreamWaitEvent(st, s->ev_comm, 0));
                 s->n_overlapped++;
+                overlapped = true;
             } else {
                 if (s->electrons && s->ions) {
                     if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, s->link, g, s->dt)) return rc;
@@ -714,19 +715,28 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                     if (s->ions)
                         if (int rc = pop_push_fused_noexchange(s->ions, s->link, g, s->dt)) return rc;
                 }
-                if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
-                if (int rc = link_exchange_particles(s->link, to_left, to_right, st)) return rc;
+                // a peer link needs nothing here: the tail kernel below packs the halo, writes both messages into the
+                // neighbours' mailboxes and waits for theirs (peer_device.hpp)
+                if (!peer) {
+                    if (int rc = grid_exchange_halo(g, s->link, false, &rl, &rr, nullptr)) return rc;
+                    if (int rc = link_exchange_particles(s->link, to_left, to_right, st)) return rc;
+                }
             }
             double ly, lz;
             laser_now(ly, lz);
             {
-                // synchronize's kernel and the unpack do not touch each other's data: one launch for both
+                // the arrivals, synchronize and the field solve: one launch (the tiles synchronize does not touch
+                // are advanced by workgroups of their own, beside the unpack)
                 SyncArgs sa;
                 grid_sync_args(g, rl, rr, ly, lz, sa);
+                AdvArgs adv;
+                grid_advance_args(g, s->dt, adv);
+                const bool fits = adv.edge_left <= ADV_EDGE && adv.edge_right <= ADV_EDGE;
                 opal_pop_t *pops[2] = {s->electrons, s->ions};
-                if (int rc = pops_unpack_and_maybe_sort(pops, 2, s->link, g, &sa)) return rc;
+                if (int rc = pops_unpack_and_maybe_sort(pops, 2, s->link, g, &sa, fits ? &adv : nullptr, peer && !overlapped)) return rc;
+                if (fits) grid_advance_done(g);
+                else if (int rc = opal_grid_advance(g, s->dt)) return rc;
             }
-            if (int rc = opal_grid_advance(g, s->dt)) return rc;
             s->t += s->dt;
             s->step_index++;
             continue;
@@ -796,12 +806,19 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
         }
         s->step_index++;
-        if (s->has_laser) {
-            if (int rc = opal_grid_synchronize(s->grid, s->link, laser_y_cb, laser_z_cb, &lp, s->t, s->dt)) return rc;
+        if (!linked) {
+            // a lone subdomain: synchronize and the field solve in one launch
+            double ly, lz;
+            laser_now(ly, lz);
+            if (int rc = grid_sync_advance(s->grid, nullptr, nullptr, ly, lz, s->dt)) return rc;
         } else {
-            if (int rc = opal_grid_synchronize(s->grid, s->link, nullptr, nullptr, nullptr, s->t, s->dt)) return rc;
+            if (s->has_laser) {
+                if (int rc = opal_grid_synchronize(s->grid, s->link, laser_y_cb, laser_z_cb, &lp, s->t, s->dt)) return rc;
+            } else {
+                if (int rc = opal_grid_synchronize(s->grid, s->link, nullptr, nullptr, nullptr, s->t, s->dt)) return rc;
+            }
+            if (int rc = opal_grid_advance(s->grid, s->dt)) return rc;
         }
-        if (int rc = opal_grid_advance(s->grid, s->dt)) return rc;
         s->t += s->dt;
     }
     return OPAL_OK;

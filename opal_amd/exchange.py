@@ -198,6 +198,77 @@ class RcclLink:
         return n.value
 
 
+class PeerLink:
+    """opal_link_t over peer-mapped mailboxes (peer.hip, peer_device.hpp): the kernels of the step write their
+    messages straight into the neighbours' device memory (xGMI between the GPUs of a node) and wait for theirs --
+    no transport call, no extra launch, no host work per exchange.  torch.distributed is used once, to hand the
+    64-byte IPC handles of the mailboxes around (any backend).  All subdomains must live on one node."""
+
+    def __init__(self, rank, world, device=None, particle_capacity=4096, group=None, stream=None, photon_emission=False,
+                 photon_absorption=False):
+        self._lib = _lib.load()
+        slots, fields = (3, 15) if photon_absorption else (3, 12) if photon_emission else (2, 6)
+        h = C.c_void_p()
+        rc = self._lib.opal_link_create_peer(C.byref(h), rank, world, particle_capacity, slots, fields, stream)
+        if rc:
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        self.h = h
+        self.nbytes = self._lib.opal_link_message_bytes(h)
+        mine = C.create_string_buffer(64)
+        if self._lib.opal_link_peer_export(h, mine):
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        left = right = None
+        if world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, mine.raw, group=group)
+            left = C.create_string_buffer(handles[(rank - 1 + world) % world], 64)
+            right = C.create_string_buffer(handles[(rank + 1) % world], 64)
+        err = None
+        if self._lib.opal_link_peer_connect(h, left, right):
+            err = self._lib.opal_last_error().decode()
+        if world > 1:
+            # every mailbox is mapped before anybody's first step writes into one -- and if mapping failed anywhere
+            # (no peer access between two GPUs, say) every subdomain learns it here instead of waiting for a
+            # neighbour that has already given up
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+            err = next((f"subdomain {r}: {e}" for r, e in enumerate(errs) if e), None)
+        if err:
+            self._lib.opal_link_free(h)
+            self.h = None
+            raise RuntimeError("peer link: " + err)
+        self.world, self.group = world, group
+
+    def self_test(self, to_left=True, to_right=True, n=4):
+        """n halo-only exchanges with the neighbours; True only if they completed on EVERY subdomain (collective)."""
+        ok = self._lib.opal_link_self_test(self.h, 1 if to_left else 0, 1 if to_right else 0, n) == 0
+        if self.world > 1:
+            oks = [None] * self.world
+            dist.all_gather_object(oks, ok, group=self.group)
+            ok = all(oks)
+        return ok
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._lib.opal_link_free(self.h)
+            self.h = None
+
+    def status(self):
+        """(mailbox memory kind, exchanges so far); raises if a wait for a neighbour ever timed out."""
+        t, k, n = C.c_int(), C.c_int(), C.c_uint32()
+        if self._lib.opal_link_peer_status(self.h, C.byref(t), C.byref(k), C.byref(n)):
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        return ("uncached", "fine-grained", "plain")[k.value], n.value
+
+    def last_exchange_bytes(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        self._lib.opal_link_last_exchange_bytes(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def set_bounded(self, on=True):
+        pass  # nothing to plan: a message is as long as the leavers it carries
+
+
 class TorchCollectives:
     """The output-time reductions of a decomposed run (opal_sim_set_collectives) on torch.distributed:
     energies and histograms are all-reduced, grid rows gathered to rank 0 (the reference's MPI_Reduce /

@@ -2,16 +2,17 @@
 fields do nothing, so every particle must end up exactly where N ballistic steps put it -- a particle pushed twice, or
 not at all, in any one step (the failure mode of shared chunks, races at re-binning, lost or duplicated leavers) is off
 by a fifth of a cell.  Particles are matched by their momentum, which nothing changes.
-usage: soak_linked.py [steps] [cold|hot]      (environment: NX cells, NPC per cell and species, MODES="linked,in place")"""
+usage: soak_linked.py [steps] [cold|hot]      (environment: NX cells, NPC per cell and species, MODES="linked,peer,in place";
+linked = RCCL self-exchange, peer = peer-mapped mailboxes written by the step's own kernels)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
 import opal_amd as oa
-from opal_amd.exchange import RcclLink
+from opal_amd.exchange import PeerLink, RcclLink
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 hot = len(sys.argv) > 2 and sys.argv[2] == "hot"
 NX, NPC = int(os.environ.get("NX", "2048")), int(os.environ.get("NPC", "48"))
-MODES = os.environ.get("MODES", "linked,in place").split(",")
+MODES = os.environ.get("MODES", "linked,peer,in place").split(",")
 YAML = f"""---
 control:
  dx: 1.0e-8
@@ -49,7 +50,9 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 C = 2.997925e8
 bad = 0
 for mode in MODES:
-    link = RcclLink(0, 1, dev, particle_capacity=4096) if mode == "linked" else None
+    stream = torch.cuda.current_stream().cuda_stream
+    link = (RcclLink(0, 1, dev, particle_capacity=4096) if mode == "linked" else
+            PeerLink(0, 1, dev, particle_capacity=4096, stream=stream) if mode == "peer" else None)  # peer: mailboxes, no transport
     sim = oa.Simulation(yaml_text=YAML, rank=0, numtasks=1, link=link, stream=torch.cuda.current_stream().cuda_stream)
     if link is not None:
         sim.grid.set_self_exchange(True)
@@ -71,6 +74,8 @@ for mode in MODES:
         d = np.abs(got - want); d = np.minimum(d, NX - d)
         print(mode, n, "max |position - ballistic| in cells:", d.max(), "steps since the last re-binning:", p.counters()["steps_since_sort"], flush=True)
         bad += int(d.max() > 1e-6)
+    if mode == "peer":
+        print("peer link:", link.status(), flush=True)
     del sim, link
 dist.destroy_process_group()
 print("SOAK", "FAILED" if bad else "OK")

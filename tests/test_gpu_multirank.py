@@ -35,8 +35,16 @@ def _by_w(d, prefix):
     return {k: d[f"{prefix}_{k}"][order] for k in ("cell", "x", "ux", "w")}
 
 
+@pytest.fixture(params=["gloo", "peer"])
+def link_kind(request, monkeypatch):
+    """gloo: host-staged messages through torch.distributed; peer: the step's own kernels write into mailboxes in the
+    neighbouring process's device memory (hipIpc), the transport bench.py uses between the GPUs of a node."""
+    monkeypatch.setenv("OPAL_TEST_LINK", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("world,fused", [(2, 1), (2, 0), (3, 1)])
-def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused):
+def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused, link_kind):
     o = oracle
     nx, npc, steps = 48, 12, 12
     dx = 1.0e-8
@@ -66,7 +74,7 @@ def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused
 
 @pytest.mark.parametrize("world,fused,nx,mode", [(2, 1, 64, "sim"), (2, 0, 64, "sim"), (2, 1, 512, "sim"), (3, 1, 768, "sim"),
                                                  (2, 1, 64, "sim_es"), (3, 1, 768, "sim_es"), (2, 1, 512, "sim_half")])
-def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx, mode):
+def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx, mode, link_kind):
     """The YAML driver's linked step: leavers of both species + halo in ONE message per neighbour (fused), or
     the reference's operator order with the leavers in one message and the halo in a second (fused = 0)."""
     o = oracle
@@ -98,7 +106,7 @@ def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_decomposed_thin_plasma_is_ballistic(tmp_path, world):
+def test_decomposed_thin_plasma_is_ballistic(tmp_path, world, link_kind):
     """A plasma too thin to act on itself, cut into 2 and 3 subdomains, 700 steps under the adaptive re-binning policy:
     every particle of the union must be where 700 free steps put it (matched by its momentum, which nothing changes).
     A leaver lost or duplicated, an arrival pushed twice or skipped, is off by half a cell."""
@@ -162,7 +170,7 @@ def test_receiving_subdomain_grows_its_storage(oracle, tmp_path):
 
 
 @pytest.mark.parametrize("world,deposit", [(2, 0), (3, 0), (2, 1)])
-def test_photon_emission_across_subdomains(oracle, tmp_path, world, deposit):
+def test_photon_emission_across_subdomains(oracle, tmp_path, world, deposit, link_kind):
     """Config C5's physics decomposed: electrons carry their optical depths and ids across the cuts, photons
     (emitted and pre-loaded) migrate and leave through the open ends; against the oracle with the same
     decomposition, started from the driver's own initial state."""
@@ -309,14 +317,16 @@ def test_self_exchange_through_rccl_equals_in_place_wrap(tmp_path):
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["OPAL_ROOT"]); sys.path.insert(0, os.path.join(os.environ["OPAL_ROOT"], "tests"))
 import opal_amd as oa
-from opal_amd.exchange import RcclLink, TorchLink
+from opal_amd.exchange import PeerLink, RcclLink, TorchLink
 from _gloo_hip_worker import YAML
 dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 stream = torch.cuda.current_stream().cuda_stream
 out = {}
-for mode in ("wrap", "self", "native", "fixed"):
+for mode in ("wrap", "self", "native", "fixed", "peer"):
     link = None
+    if mode == "peer":                                          # mailboxes written by the step's own kernels
+        link = PeerLink(0, 1, dev, particle_capacity=512, stream=stream)
     if mode == "self":
         link = TorchLink(0, 1, dev, particle_capacity=512)      # torch.distributed P2P callback
     if mode == "native":
@@ -343,17 +353,19 @@ for mode in ("wrap", "self", "native", "fixed"):
         s = p.soa(); o = np.lexsort((s["x"], s["ux"], s["w"]))
         out[mode][name] = {k: v[o] for k, v in s.items()}
     out[mode]["calls"] = getattr(link, "calls", 0)
-    if link is not None:
+    if mode == "peer":
+        assert link.status()[1] == 25, link.status()           # one exchange per step, none timed out
+    elif link is not None:
         full = oa._lib.load().opal_link_message_bytes(link.h)
         moved = link.last_exchange_bytes()
         # messages follow the particles: 16 per cell and species within 3 cells of the cut, plus slack, in blocks
         # of 64 -> 128 slots of the 512 (self, native); the fixed link ships all 16384
         assert moved[0] == moved[1] and ((moved[0] == full) if mode == "fixed" else (704 < moved[0] < full // 3)), (mode, moved, full)
     # the native link (and it alone here: TorchLink's RCCL ops are tied to torch's stream) takes the overlapped step
-    assert mode == "fixed" or (sim.overlapped_steps >= 20) == (mode == "native"), (mode, sim.overlapped_steps)
+    assert mode in ("fixed", "peer") or (sim.overlapped_steps >= 20) == (mode == "native"), (mode, sim.overlapped_steps)
     del sim, link
 assert out["self"]["calls"] == 25, out["self"]["calls"]            # one exchange per step
-for mode in ("self", "native", "fixed"):
+for mode in ("self", "native", "fixed", "peer"):
     for k in ("Ex", "Ey", "Ez", "By", "Bz"):
         a, b = out[mode][k], out["wrap"][k]
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), (mode, k)
