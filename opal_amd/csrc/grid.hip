@@ -297,7 +297,7 @@ int opal_grid_build(opal_grid_t **out, int id, int numtasks, int left, int right
     OPAL_HIP(hipMalloc(&g->d_scalar, sizeof(double) * 8));
     OPAL_HIP(hipMalloc(&g->d_err, sizeof(int)));
     OPAL_HIP(hipHostMalloc(&g->h_pin, sizeof(double) * 11 * g->lenp));
-    OPAL_HIP(hipHostMalloc(&g->h_esflag, sizeof(int), hipHostMallocMapped));
+    OPAL_HIP(hipHostMalloc(&g->h_esflag, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     *g->h_esflag = 0;  // the fields start at zero
     OPAL_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_esflag), g->h_esflag, 0));
     OPAL_HIP(hipMemsetAsync(g->d_eb[0], 0, 6 * nb, g->stream));

@@ -18,13 +18,15 @@
 //
 // How m follows the particles without the host waiting for the device.  A particle moves less than a cell per
 // step, so the leavers of step k through an edge are among the particles that stood within LINK_ZONE cells of
-// it after step k - LINK_ZONE.  Every push counts those into its message's header; the counts travel with the
-// message, and the unpack kernel copies both ends' counts of every exchange into mapped host memory.  When
-// exchange X is planned the host reads what exchanges X - LINK_ZONE - 2 .. X - LINK_ZONE left there (long since
-// written: the host merely cannot run more than LINK_ZONE exchanges ahead of the device) and sizes each edge to
-// the larger of the two ends' bounds plus LINK_SLACK.  Both ends of an edge hold the same numbers, so they agree
-// on the size without talking; a front that reaches a cut is seen LINK_ZONE cells before it arrives.  Transports
-// that cannot take a size per edge (opal_exchange_fn) keep shipping all `particle_capacity` slots.
+// it -- on either side -- after step k - LINK_ZONE.  Every push counts those into its message's header; the counts
+// travel with the message, and the unpack kernel copies both ends' counts of every exchange into mapped host memory.
+// When exchange X is planned the host reads what the most recent exchange <= X - LINK_ZONE that counted each species
+// left there (long since written: the host merely cannot run more than LINK_ZONE exchanges ahead of the device) and
+// sizes each edge to the SUM of the two ends' counts plus LINK_SLACK (link_plan has the argument).  Both ends of an
+// edge hold the same numbers, so they agree on the size without talking; a front that reaches a cut is seen LINK_ZONE
+// cells before it arrives.  Transports that cannot take a size per edge (opal_exchange_fn) keep shipping all
+// `particle_capacity` slots; so do links that carry stimulated emission, and peer links need none of it (the sending
+// kernel reads the leaver counts itself).
 // A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes.
 // What a subdomain sends left arrives as its left neighbour's "recv_right".
 #include <hip/hip_runtime_api.h>
@@ -49,46 +51,78 @@ size_t link_prefix_bytes(const opal_link_t *l, unsigned slots)
 // Leaver counts of the send messages start a step at zero.  The kernel that unpacks a step's arrivals also
 // re-zeroes them (they have been shipped by then) and marks the link clean, so only the first step -- or one
 // after an aborted exchange -- pays for the two memsets.
-int link_begin(opal_link_t *l, hipStream_t st)
+int link_begin(opal_link_t *l, hipStream_t st, unsigned species_mask)
 {
     if (!l->counts_clean) {
         OPAL_HIP(hipMemsetAsync(l->d_send_left, 0, LINK_HEADER_BYTES, st));
         OPAL_HIP(hipMemsetAsync(l->d_send_right, 0, LINK_HEADER_BYTES, st));
     }
     l->counts_clean = false;  // a push is about to count leavers into them
-    return link_plan(l);
+    return link_plan(l, species_mask);
 }
 
-int link_plan(opal_link_t *l)
+// How many slots per species the exchange about to be made (number xseq) ships on each edge, for the species in
+// `species_mask` (bit s = species slot s is pushed, and counted, before this exchange).
+//
+// The bound.  A particle moves less than a cell per push.  A leaver of species s through an edge at exchange X was,
+// LINK_ZONE pushes of s earlier at the most, within LINK_ZONE cells of that edge ON EITHER SIDE of it (it may have
+// crossed into this subdomain meanwhile and be on its way back): it was counted by this subdomain's push (`mine`) or by
+// the neighbour's (`theirs`).  So need(s) = mine + theirs of the most recent exchange e_s <= X - LINK_ZONE that counted
+// s -- between e_s and X the species is pushed at most LINK_ZONE times, whatever mix of per-species and combined
+// exchanges the caller makes (the ring remembers which species each exchange counted).  Photons born since the count
+// (photon emission: links with >= 12 fields) come from electrons that were within the same LINK_ZONE cells, one photon
+// per electron and step at most: need(photons) += LINK_ZONE x need(electrons).  Stimulated emission (15 fields) has
+// no such bound (several photons may copy themselves off one electron): those links ship every slot.  No usable entry
+// in the ring (start-up; more than LINK_RING - LINK_ZONE exchanges since the species was last counted): every slot.
+int link_plan(opal_link_t *l, unsigned species_mask)
 {
     const unsigned full = (unsigned)l->cap;
     l->send_cap[0] = l->send_cap[1] = full;
-    if (!l->bounded || !l->exchange2 || !l->h_bounds || l->xseq < (unsigned)LINK_ZONE) return OPAL_OK;
-    const unsigned newest = l->xseq - LINK_ZONE;  // exchange whose bounds cover the one being planned
+    const unsigned X = l->xseq;
+    l->ring_mask[X % LINK_RING] = species_mask;
+    if (!l->bounded || !l->exchange2 || !l->h_bounds || l->nfields >= 15) return OPAL_OK;
+    if (X < (unsigned)LINK_ZONE) return OPAL_OK;
     unsigned need[2] = {0, 0};
-    for (unsigned back = 0; back < 3 && back <= newest; back++) {
-        const unsigned e = newest - back;
-        const LinkBounds *b = &l->h_bounds[e % LINK_RING];
-        // Written by the unpack kernel of exchange e, at least LINK_ZONE exchanges ago: normally there already.
-        // The wait must not have a timing-dependent way out -- a subdomain that gave up and shipped another
-        // size than its neighbour expects would hang the transport -- so it only ends in the entry or an error.
-        if (b->seq != e + 1) {
-            const auto t0 = std::chrono::steady_clock::now();
-            unsigned long spins = 0;
-            while (b->seq != e + 1) {
-                if ((++spins & 0xfffff) == 0 &&
-                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
-                    set_error("link: the particle bounds of exchange %u never arrived (every whole-message exchange must "
-                              "be followed by the unpack of its arrivals on the link's stream)", e);
-                    return OPAL_ERR_LINK;
+    auto entry_of = [&](int sp, const LinkBounds **out) -> int {  // most recent usable entry that counted species sp
+        *out = nullptr;
+        for (unsigned e = X - LINK_ZONE;; e--) {
+            if (X - e >= (unsigned)LINK_RING) break;  // overwritten since (or about to be)
+            if (l->ring_mask[e % LINK_RING] & (1u << sp)) {
+                const LinkBounds *b = &l->h_bounds[e % LINK_RING];
+                // Written by the unpack kernel of exchange e, at least LINK_ZONE exchanges ago: normally there already.
+                // The wait must not have a timing-dependent way out -- a subdomain that gave up and shipped another
+                // size than its neighbour expects would hang the transport -- so it only ends in the entry or an error.
+                const auto t0 = std::chrono::steady_clock::now();
+                unsigned long spins = 0;
+                while (__atomic_load_n(&b->seq, __ATOMIC_ACQUIRE) != e + 1) {
+                    if ((++spins & 0xfffff) == 0 &&
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                        set_error("link: the particle bounds of exchange %u never arrived (every whole-message exchange must "
+                                  "be followed by the unpack of its arrivals on the link's stream)", e);
+                        return OPAL_ERR_LINK;
+                    }
                 }
+                *out = b;
+                return OPAL_OK;
             }
+            if (e == 0) break;
         }
-        for (int side = 0; side < 2; side++)
-            for (int sp = 0; sp < 3; sp++) {
-                need[side] = need[side] > b->mine[side][sp] ? need[side] : b->mine[side][sp];
-                need[side] = need[side] > b->theirs[side][sp] ? need[side] : b->theirs[side][sp];
-            }
+        return OPAL_OK;
+    };
+    const LinkBounds *be = nullptr;
+    const bool qed = l->nfields >= 12 && l->nslots >= 3;
+    if (qed && (species_mask & 4u))
+        if (int rc = entry_of(0, &be)) return rc;
+    for (int sp = 0; sp < l->nslots; sp++) {
+        if (!(species_mask & (1u << sp))) continue;
+        const LinkBounds *b;
+        if (int rc = entry_of(sp, &b)) return rc;
+        if (!b || (sp == 2 && qed && !be)) return OPAL_OK;  // no history to go by: every slot
+        for (int side = 0; side < 2; side++) {
+            unsigned n = b->mine[side][sp] + b->theirs[side][sp];
+            if (sp == 2 && qed) n += (unsigned)LINK_ZONE * (be->mine[side][0] + be->theirs[side][0]);
+            need[side] = need[side] > n ? need[side] : n;
+        }
     }
     for (int side = 0; side < 2; side++) {
         unsigned slots = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
@@ -194,7 +228,7 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
     l->nbytes = link_prefix_bytes(l, (unsigned)particle_capacity);
     l->send_cap[0] = l->send_cap[1] = (unsigned)particle_capacity;
     l->bounded = true;  // takes effect once a per-edge transport is set (opal_link_set_exchange2, native links)
-    OPAL_HIP(hipHostMalloc((void **)&l->h_bounds, sizeof(LinkBounds) * LINK_RING, hipHostMallocMapped));
+    OPAL_HIP(hipHostMalloc((void **)&l->h_bounds, sizeof(LinkBounds) * LINK_RING, hipHostMallocMapped | hipHostMallocCoherent));
     memset((void *)l->h_bounds, 0, sizeof(LinkBounds) * LINK_RING);
     OPAL_HIP(hipHostGetDevicePointer((void **)&l->d_bounds, (void *)l->h_bounds, 0));
     char **dev[4] = {&l->d_send_left, &l->d_send_right, &l->d_recv_left, &l->d_recv_right};

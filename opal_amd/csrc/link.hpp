@@ -11,7 +11,7 @@ constexpr size_t LINK_HEAD_BYTES = LINK_HEADER_BYTES + LINK_HALO_BYTES;  // 704
 constexpr int LINK_H_COUNT = 0, LINK_H_ZONE = 4;
 constexpr int LINK_ZONE = 3;        // cells; also the lag (in exchanges) with which message sizes follow the bound
 constexpr unsigned LINK_ROWS = 64;  // particles per row block
-constexpr unsigned LINK_SLACK = 64; // slots beyond the bound (arrivals that turn round inside the zone)
+constexpr unsigned LINK_SLACK = 64; // slots beyond the bound (nothing relies on it: the bound itself is rigorous, link_plan)
 constexpr int LINK_RING = 8;        // exchanges whose bounds the host keeps
 
 // Row-blocked body: block (b, s) = particles [64 b, 64 b + 64) of species slot s: int32 cell[64] then `nfields`
@@ -73,6 +73,7 @@ struct opal_link {
     // message sizes that follow the particles (link.cpp): bounds of the last LINK_RING exchanges, written by the device
     opal::LinkBounds *h_bounds, *d_bounds;  // the same mapped pinned memory, host and device view
     unsigned xseq;           // whole-message exchanges so far
+    unsigned ring_mask[opal::LINK_RING];  // which species' pushes counted into exchange e's headers, at e % LINK_RING (link_plan)
     unsigned send_cap[2];    // slots (a multiple of 64) the next exchange ships per species: left / right edge
     bool bounded;            // sizes follow the bounds (needs exchange2); else every exchange ships all `cap` slots
     size_t last_bytes[2];    // what the last whole-message exchange moved per edge (diagnostic)
@@ -83,10 +84,11 @@ struct opal_link {
 namespace opal {
 char *link_send(opal_link_t *l, int side);
 char *link_recv(opal_link_t *l, int side);
-int link_begin(opal_link_t *l, hipStream_t st);
+// species_mask: bit s = species slot s (0 electrons, 1 ions, 2 photons) is pushed before the coming exchange
+int link_begin(opal_link_t *l, hipStream_t st, unsigned species_mask);
 // decides how many slots per species the coming exchange ships on each edge (send_cap), from the bounds the device
-// reported LINK_ZONE exchanges ago; call before the push that packs the leavers
-int link_plan(opal_link_t *l);
+// reported at least LINK_ZONE exchanges ago; call before the push that packs the leavers
+int link_plan(opal_link_t *l, unsigned species_mask);
 size_t link_prefix_bytes(const opal_link_t *l, unsigned slots);
 // halo-only exchange (the first LINK_HEAD_BYTES of each message)
 int link_exchange_halo(opal_link_t *l, bool to_left, bool to_right, hipStream_t st);

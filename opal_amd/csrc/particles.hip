@@ -1181,8 +1181,10 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
             if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
             if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
         }
-        if (b.pub.n) publish_counters(b.pub);
     }
+    // (the policy's counters go out from workgroup 0: where another workgroup runs synchronize and the field solve's
+    // edges -- the longest chain of the launch -- the ~2 us of the write to host memory are off it)
+    if (blockIdx.x == 0 && b.pub.n) publish_counters(b.pub);
     if (blockIdx.x >= n_unpack) {  // (only launched when has_sync)
         synchronize_body(b.sync);
         if (ADV && b.has_adv) advance_edges(b.adv, s_adv);  // the cells synchronize wrote, and their stencil neighbours
@@ -1294,7 +1296,9 @@ int check_pop_err(opal_pop_t *p)
     if (err) {
         OPAL_HIP(hipMemsetAsync(&p->d_ctr->err, 0, sizeof(int), p->stream));
         if (err & 8) {
-            set_error("leaver buffer overflow: more particles crossed a subdomain edge in one step than the link holds");
+            set_error("leaver buffer overflow: more particles crossed a subdomain edge in one step than this step's message had "
+                      "room for -- the link's particle_capacity, or the size predicted from the particles near the edge "
+                      "(link.cpp: link_plan; opal_link_set_bounded(link, 0) ships every slot instead)");
             return OPAL_ERR_CAPACITY;
         }
         if (err & 16) {
@@ -1818,7 +1822,7 @@ int advance_with_exchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, doub
         set_error("%d subdomains: particle migration needs a link", g->ngrids);
         return OPAL_ERR_ARG;
     }
-    if (int rc = link_begin(link, p->stream)) return rc;
+    if (int rc = link_begin(link, p->stream, 1u << p->species)) return rc;
     if (int rc = run_push(p, link, g, dt, mode)) return rc;
     if (int rc = pack_leaver_extras(p, link, g)) return rc;
     if (int rc = link_exchange_particles(link, g->left_bdy == OPAL_BDY_INTERNAL, g->right_bdy == OPAL_BDY_INTERNAL, p->stream)) return rc;
@@ -1975,7 +1979,8 @@ int wait_published(const opal_pop_t *p)
     // the kernel that writes it was launched check_every steps ago: normally long done
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (p->h_pub->seq != p->pub_seq) {
+    // (acquire: the counters in front of the sequence number are read only after it has been seen)
+    while (__atomic_load_n(&p->h_pub->seq, __ATOMIC_ACQUIRE) != p->pub_seq) {
         if ((++spins & 0xffff) == 0) {
             hipError_t q = hipStreamQuery(p->stream);  // surfaces a device fault instead of spinning on it
             if (q != hipSuccess && q != hipErrorNotReady) OPAL_HIP(q);
@@ -2096,7 +2101,7 @@ int opal_pop_create(opal_pop_t **out, int species, size_t capacity, void *hip_st
     if (int rc = alloc_set(p, 0)) return rc;
     OPAL_HIP(hipMalloc(&p->d_ctr, sizeof(PopCounters)));
     OPAL_HIP(hipHostMalloc(&p->h_ctr, sizeof(PopCounters)));
-    OPAL_HIP(hipHostMalloc(&p->h_pub, sizeof(PubCounters), hipHostMallocMapped));
+    OPAL_HIP(hipHostMalloc(&p->h_pub, sizeof(PubCounters), hipHostMallocMapped | hipHostMallocCoherent));
     memset((void *)p->h_pub, 0, sizeof(PubCounters));
     OPAL_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_pub), p->h_pub, 0));
     OPAL_HIP(hipMemsetAsync(p->d_ctr, 0, sizeof(PopCounters), p->stream));

@@ -15,9 +15,9 @@
 // never overwritten before it has been read.
 //
 // Memory model.  The mailboxes are allocated uncached / fine-grained (peer.hip); payload words are written with
-// system-scope relaxed atomic stores (write-through), then the workgroup's barrier, then ONE lane issues a
-// system-scope fence and stores the sequence number (release).  The receiver's lane 0 polls it with system-scope
-// acquire loads, fences, and releases the rest of its workgroup through a barrier; payload loads follow.
+// system-scope relaxed atomic stores (write-through), then the workgroup's barrier, then ONE lane stores the
+// sequence number with a system-scope release.  The receiver's lane 0 polls it with system-scope relaxed loads,
+// issues one system-scope acquire fence, and releases the rest of its workgroup through a barrier; payload loads follow.
 // Every wait is bounded (PEER_TIMEOUT_TICKS of the 100 MHz wall clock): a neighbour that never sends makes the
 // kernel raise an error word and carry on, so that every wave reaches its exit.
 #pragma once
@@ -78,28 +78,34 @@ __device__ inline unsigned peer_prefix_words(const char *msg, const PeerArgs &a)
 // publishes them.  Contains barriers.
 __device__ inline void peer_send(const PeerArgs &a)
 {
+    constexpr unsigned HEAD_WORDS = (unsigned)(LINK_HEAD_BYTES / 8), HEADER_WORDS = (unsigned)(LINK_HEADER_BYTES / 8);
+    // header and halo first: their loads depend on nothing (the rows' extent is read from the header)
+    for (int side = 0; side < 2; side++) {
+        const char *msg = a.send[side];
+        if (!msg || threadIdx.x >= HEAD_WORDS) continue;
+        const unsigned i = threadIdx.x;
+        unsigned long long v;
+        if (a.pack_halo && i >= HEADER_WORDS)
+            v = (unsigned long long)__double_as_longlong(halo_value(a.halo, side, (int)(i - HEADER_WORDS)));
+        else
+            v = reinterpret_cast<const unsigned long long *>(msg)[i];
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES) + i, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (int side = 0; side < 2; side++) {
         const char *msg = a.send[side];
         if (!msg) continue;
         const unsigned words = peer_prefix_words(msg, a);
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES);
-        for (unsigned i = threadIdx.x; i < words; i += blockDim.x) {
-            unsigned long long v;
-            if (a.pack_halo && i >= LINK_HEADER_BYTES / 8 && i < LINK_HEAD_BYTES / 8)
-                v = (unsigned long long)__double_as_longlong(halo_value(a.halo, side, (int)(i - LINK_HEADER_BYTES / 8)));
-            else
-                v = src[i];
-            __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        for (unsigned i = HEAD_WORDS + threadIdx.x; i < words; i += blockDim.x)
+            __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __syncthreads();  // (waits for every wave's stores to have left it)
-    if (threadIdx.x == 0) {
-        __threadfence_system();
+    __syncthreads();  // (every wave waits for its stores before it arrives)
+    if (threadIdx.x == 0)
         for (int side = 0; side < 2; side++)
-            if (a.send[side])
+            if (a.send[side])  // release: everything stored above is visible before the sequence number is
                 __hip_atomic_store(reinterpret_cast<unsigned *>(a.dst[side]), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // Called by every thread of a workgroup that is about to read what the neighbours sent.  Contains a barrier.
@@ -110,15 +116,15 @@ __device__ inline void peer_wait(const PeerArgs &a)
         for (int side = 0; side < 2; side++) {
             if (!a.box[side]) continue;
             const unsigned *flag = reinterpret_cast<const unsigned *>(a.box[side]);
-            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
                 if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
                     atomicOr(a.err, 1u);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
             }
         }
-        __threadfence_system();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope: what the neighbours stored before their sequence numbers
     }
     __syncthreads();
 }

@@ -642,7 +642,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             hipStream_t st = (hipStream_t)s->stream;
             opal_pop_t *pops[3] = {s->electrons, s->ions, qed ? s->photons : nullptr};
             const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
-            if (int rc = link_begin(s->link, st)) return rc;
+            if (int rc = link_begin(s->link, st, (s->electrons ? 1u : 0u) | (s->ions ? 2u : 0u) | (qed && s->photons ? 4u : 0u))) return rc;
             for (opal_pop_t *p : pops)
                 if (p)
                     if (int rc = pop_push_advance_noexchange(p, s->link, g, s->dt)) return rc;
@@ -683,7 +683,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             opal_grid_t *g = s->grid;
             hipStream_t st = (hipStream_t)s->stream;
             if (int rc = opal_grid_clear(g)) return rc;
-            if (int rc = link_begin(s->link, st)) return rc;  // free after the first step: the unpack kernel re-zeroes
+            // (free after the first step: the unpack kernel re-zeroes the leaver counts)
+            if (int rc = link_begin(s->link, st, (s->electrons ? 1u : 0u) | (s->ions ? 2u : 0u))) return rc;
             const double *rl = nullptr, *rr = nullptr;
             const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
             const bool peer = link_is_peer(s->link);
