@@ -365,7 +365,10 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     oa.set_device(dev_index)
-    link_kind = os.environ.get("OPAL_BENCH_LINK", "peer") if backend == "nccl" else "gloo"
+    # peer: mailboxes in the neighbours' device memory written by the step's own kernels (falls back to rccl, then to
+    # torch.distributed); a rehearsal with fewer GPUs than ranks uses the same mailboxes between the processes that
+    # share a card (falls back to host-staged gloo messages)
+    link_kind = os.environ.get("OPAL_BENCH_LINK", "peer")
 
     weak = args.weak or args.cells_per_gpu is not None
     if args.workload == "laser_plasma":
@@ -424,9 +427,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
             link = make_link(rank, world, torch.device("cuda", dev_index))
         else:
-            from opal_amd.exchange import TorchLink
+            from opal_amd.exchange import PeerLink, TorchLink
             dist.init_process_group(backend, rank=rank, world_size=world)
-            link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=link_capacity)
+            if link_kind == "peer":
+                lp_open = args.workload == "laser_plasma"
+                try:
+                    link = PeerLink(rank, world, particle_capacity=link_capacity, stream=torch.cuda.current_stream().cuda_stream)
+                    if not link.self_test(to_left=not (lp_open and rank == 0), to_right=not (lp_open and rank == world - 1)):
+                        link = None
+                except Exception as e:
+                    print(f"[bench] peer link unavailable ({e}); using host-staged gloo messages", file=sys.stderr)
+                    link = None
+            if link is None:
+                link_kind = "gloo"
+                link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=link_capacity)
     red_dev = "cuda" if backend == "nccl" else "cpu"
     rccl_ranks = None
     if link is not None and hasattr(link, "rccl_ranks"):
@@ -658,7 +672,9 @@ def main():
         if link is None:
             link_desc = "none (one periodic subdomain wraps in place)"
         elif backend != "nccl":
-            link_desc = f"REHEARSAL: {world} ranks share {ndev} GPU(s), host-staged gloo exchange"
+            link_desc = f"REHEARSAL: {world} ranks share {ndev} GPU(s), " + (
+                "peer-mapped mailboxes between the processes, written and awaited by the step's own kernels"
+                if link_kind == "peer" else "host-staged gloo exchange")
         else:
             link_desc = link_kind_desc() + (", self-exchange (multi-GPU step rehearsed on one GPU)" if args.self_exchange and world == 1 else "")
         out = {

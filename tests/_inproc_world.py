@@ -1,0 +1,126 @@
+"""N subdomains of a decomposed HIP run inside ONE process, one host thread and one HIP stream each, exchanging through
+host buffers: how the 8-way partitions of BASELINE configs[2]-[3] are executed on a box with a single GPU (which
+admits at most 6 processes on its card, so 8 ranks cannot be 8 processes there).
+
+The link is the library's ordinary callback transport (opal_link_create_layout with host staging, the path gloo ranks
+use); the callback is a rendezvous between the threads: every subdomain posts its two send buffers, waits at a
+barrier, copies what its neighbours posted, waits again.  ctypes releases the GIL around the C calls, so the
+subdomains' steps really interleave as separate ranks' would.
+"""
+import ctypes as C
+import sys
+import threading
+import traceback
+
+import numpy as np
+
+import opal_amd as oa
+from opal_amd import _lib
+
+
+class World:
+    def __init__(self, n, timeout=120.0):
+        self.n = n
+        self.barrier = threading.Barrier(n, timeout=timeout)
+        self.slots = [None] * n
+        self.errors = []
+
+
+class InProcLink:
+    """opal_link_t whose transport is a rendezvous of the threads of `world` (host-staged messages)."""
+
+    def __init__(self, world, rank, particle_capacity=1024, stream=None, photon_emission=False, periodic=True):
+        self._lib = _lib.load()
+        self.world, self.rank = world, rank
+        self.periodic = periodic
+        self._cb = _lib.EXCHANGE_FN(self._exchange)
+        self._cb2 = _lib.EXCHANGE2_FN(self._exchange2)
+        slots, fields = (3, 12) if photon_emission else (2, 6)
+        h = C.c_void_p()
+        if self._lib.opal_link_create_layout(C.byref(h), rank, world.n, 0, particle_capacity, slots, fields, self._cb, None, stream):
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        self.h = h
+        if self._lib.opal_link_set_exchange2(h, self._cb2):
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        self.calls = 0
+        self.bytes = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._lib.opal_link_free(self.h)
+            self.h = None
+
+    def _exchange(self, user, sl, sr, rl, rr, n):
+        return self._exchange2(user, sl, sr, rl, rr, n, n)
+
+    def _exchange2(self, user, sl, sr, rl, rr, n_left, n_right):
+        try:
+            w, r = self.world, self.rank
+            w.slots[r] = (sl, sr, n_left, n_right)
+            w.barrier.wait()
+            if rl:  # what my left neighbour sent to the right
+                lsl, lsr, lnl, lnr = w.slots[(r - 1) % w.n]
+                assert lsr and lnr == n_left, (r, lnr, n_left)   # both ends of an edge agree on its message size
+                C.memmove(rl, lsr, n_left)
+                self.bytes += n_left
+            if rr:
+                rsl, rsr, rnl, rnr = w.slots[(r + 1) % w.n]
+                assert rsl and rnl == n_right, (r, rnl, n_right)
+                C.memmove(rr, rsl, n_right)
+                self.bytes += n_right
+            w.barrier.wait()  # nobody refills a send buffer before its neighbours have copied it
+            self.calls += 1
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            traceback.print_exc(file=sys.stderr)
+            self.world.barrier.abort()
+            return 1
+
+
+def run_world(n, body, timeout=600.0):
+    """Runs body(rank, world) -> result on n threads; returns the results in rank order, or raises the first error."""
+    import torch
+    world = World(n)
+    results = [None] * n
+
+    def target(r):
+        try:
+            oa.set_device(0)
+            results[r] = body(r, world)
+        except BaseException as e:  # noqa: BLE001
+            world.errors.append((r, e, traceback.format_exc()))
+            world.barrier.abort()
+
+    threads = [threading.Thread(target=target, args=(r,), daemon=True) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout)
+        if t.is_alive():
+            world.barrier.abort()
+            raise TimeoutError("a subdomain thread did not finish")
+    torch.cuda.synchronize()
+    if world.errors:
+        r, e, tb = world.errors[0]
+        raise RuntimeError(f"subdomain {r} failed:\n{tb}")
+    return results
+
+
+def soa_dump(sim, prefix=""):
+    out = {}
+    for name, p in (("e", sim.electrons), ("i", sim.ions)):
+        if p is None:
+            continue
+        for k, v in p.soa().items():
+            out[f"{prefix}{name}_{k}"] = v
+    return out
+
+
+def grid_dump(g):
+    return {k: g.raw(k) for k in ("Ex", "Ey", "Ez", "By", "Bz", "jx", "jy", "jz", "rho")}
+
+
+def by_position(d, name):
+    """A population's arrays ordered by (cell, x): a canonical order for comparing two runs particle by particle."""
+    order = np.lexsort((d[f"{name}_x"], d[f"{name}_cell"]))
+    return {k: d[f"{name}_{k}"][order] for k in ("cell", "x", "ux", "uy", "uz", "w")}

@@ -1,0 +1,198 @@
+"""The N = 8 partitions of BASELINE configs[2] and configs[3], executed: eight subdomains of a decomposed HIP run, one
+host thread and one stream each inside one process (tests/_inproc_world.py: a one-GPU box admits at most 6 processes
+on its card), against the oracle run with the same decomposition.
+
+* configs[2]'s cut -- 32 768 cells into 8 x 4096, periodic through the wrap 7 <-> 0 -- at reduced particles per cell:
+  cells exact, positions and fields 1e-9;
+* configs[3]'s `balance: true` on laser-plasma physics, 4 and 8 subdomains of DIFFERENT sizes (the vacuum in front of
+  the slab goes to subdomain 0): arrivals are re-based by the sender's size on one side and the receiver's on the other
+  (particle/mod.rs:291-293, 366-368), GridDesign::balanced (grid/mod.rs:157-206), laser and absorbing ends, a
+  relativistic front that sweeps the electrons of the first subdomains across three cuts: fields and energies 1e-6.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _decomp_common import A_POSITRON, C  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+COMPS = ("Ex", "Ey", "Ez", "By", "Bz")
+
+# laser-plasma physics (examples/hole_boring.yaml's set-up) on 1600 cells: 400 of vacuum, then a slab to the right
+# end, thin enough (2 n_c against a0 = 30) for the pulse to plough through it
+LASER_PLASMA = """---
+control:
+ dx: micro / 200
+ nx: 1600
+ xmin: -2*micro
+ start: -4.0e-6/c
+ end: {end}e-6/c
+ current_deposition: true
+ n_outputs: 2
+ balance: true
+qed:
+ photon_emission: false
+ photon_absorption: false
+electrons:
+ npc: 4
+ ne: density * critical(omega) * step(x,xmin,xmax)
+ ux: sqrt(kT/(m*c^2)) * nrand
+ uy: sqrt(kT/(m*c^2)) * nrand
+ uz: sqrt(kT/(m*c^2)) * nrand
+ output: [x:px]
+ions:
+ name: carbon
+ npc: 4
+ Z: Z
+ A: A
+ ni: density * critical(omega) * step(x,xmin,xmax) / Z
+ ux: sqrt(kT/(A*mp*c^2)) * nrand
+ uy: sqrt(kT/(A*mp*c^2)) * nrand
+ uz: sqrt(kT/(A*mp*c^2)) * nrand
+ output: [x:px]
+laser:
+ Ey: (a0*me*c*omega/e) * gauss_pulse_re(t,x,omega,sigma)
+ Ez: (a0*me*c*omega/e) * gauss_pulse_im(t,x,omega,sigma)
+constants:
+ density: 2.0
+ a0: 30.0
+ omega: 2*pi*c/0.8e-6
+ sigma: pi
+ xmin: 0.0 * micro
+ xmax: 6.0 * micro
+ Z: 6.0
+ A: 12.0
+ kT: 500 * eV
+"""
+
+
+def _run_hip_world(world, text, steps, capacity, sort_interval=None, fused=True):
+    import torch
+    import opal_amd as oa
+    from _inproc_world import InProcLink, grid_dump, run_world, soa_dump
+    streams = [torch.cuda.Stream() for _ in range(world)]
+
+    def body(r, w):
+        st = streams[r].cuda_stream
+        link = InProcLink(w, r, particle_capacity=capacity, stream=st)
+        sim = oa.Simulation(yaml_text=text, rank=r, numtasks=world, link=link, stream=st)
+        sim.set_fused(fused)
+        if sort_interval:
+            sim.electrons.set_sort_interval(sort_interval)
+            sim.ions.set_sort_interval(sort_interval)
+        out = soa_dump(sim, "init_")
+        out["size"] = sim.grid.size
+        n = steps if steps else sim.total_steps
+        sim.step(n)
+        sim.sync()
+        out.update(soa_dump(sim))
+        out.update(grid_dump(sim.grid))
+        out["energies"] = sim.energies()
+        out["steps"], out["t"], out["dt"] = n, sim.t, sim.dt
+        out["calls"], out["bytes"] = link.calls, link.bytes
+        out["rebins"] = sim.electrons.counters()["steps_since_sort"]
+        del sim, link
+        return out
+
+    return run_world(world, body)
+
+
+def test_configs2_cut_into_8_subdomains(oracle):
+    """32 768 cells -> 8 x 4096 (GridDesign::unbalanced, periodic), the fused linked step with one message per
+    neighbour and step, across re-binnings, through the wrap 7 <-> 0."""
+    import opal_amd as oa
+    from _gloo_hip_worker import YAML
+    from _inproc_world import by_position
+    o = oracle
+    world, nx, npc, steps = 8, 32768, 3, 40
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    got = _run_hip_world(world, YAML.format(nx=nx, npc=npc), steps, capacity=256, sort_interval=16)
+    nxs, offs = o.design_unbalanced(world, nx, dx)
+    assert list(nxs) == [4096] * 8 and [g["size"] for g in got] == [4096] * 8
+    assert all(g["calls"] == steps for g in got)  # one exchange per step
+    grids = [o.Grid(r, world, 0, 0, 0.0, dx, nxs, offs) for r in range(world)]
+    keys = ("cell", "x", "ux", "uy", "uz", "w")
+    pes = [o.Population.from_soa(o.ELECTRON, *[g[f"init_e_{k}"] for k in keys], dx, dt) for g in got]
+    pis = [o.Population.from_soa(o.ION, *[g[f"init_i_{k}"] for k in keys], dx, dt) for g in got]
+    for p in pis:
+        p.set_charge_state(1.0, 1.0, A_POSITRON)
+    t = 0.0
+    for _ in range(steps):
+        assert o.world_step(grids, pes, pis, True, t, dt) == 0
+        t += dt
+    crossed = 0
+    for r in range(world):
+        for k in COMPS:
+            ref = grids[r].raw(k)
+            assert np.max(np.abs(got[r][k] - ref)) <= 1e-9 * max(np.max(np.abs(ref)), 1e-300), (r, k)
+        for name, p in (("e", pes[r]), ("i", pis[r])):
+            ref = p.soa()
+            ref = {f"{name}_{k}": v for k, v in ref.items()}
+            a, b = by_position(got[r], name), by_position(ref, name)
+            assert len(a["x"]) == len(b["x"]), (r, name)
+            assert np.array_equal(a["cell"], b["cell"].astype(np.int32)), (r, name)   # the same particles in the same cells
+            assert np.max(np.abs(a["x"] - b["x"])) < 1e-9 and np.max(np.abs(a["ux"] - b["ux"])) < 1e-9
+        crossed += abs(len(got[r]["e_x"]) - len(got[r]["init_e_x"]))
+    assert sum(len(g["e_x"]) for g in got) == nx * npc  # periodic: nobody lost on the way round
+    # particles really went through the cuts (0.19 cells per step for 40 steps: ~7 cells x 3 per cell x 2 directions x 8 cuts)
+    moved = sum(g["bytes"] for g in got) / steps / world
+    assert moved > 704 * 2
+
+
+@pytest.mark.parametrize("world,end", [(4, 3.0), (8, 3.0)])
+def test_balanced_laser_plasma_world(oracle, tmp_path, world, end):
+    import opal_amd as oa
+    o = oracle
+    text = LASER_PLASMA.format(end=end)
+    got = _run_hip_world(world, text, 0, capacity=4096)
+    cfgp = tmp_path / "lp.yaml"
+    cfgp.write_text(text)
+    cfg = oa.Config(path=cfgp)
+    ly, lz = cfg.func("laser", "Ey", ["t", "x"]), cfg.func("laser", "Ez", ["t", "x"])
+    ne = cfg.func("electrons", "ne", ["x"])
+    dx, nx, xmin = 1.0e-6 / 200, 1600, -2.0e-6
+    dt = got[0]["dt"]
+    steps = got[0]["steps"]
+    nxs, offs = o.design_balanced(world, nx, xmin, dx, ne)
+    assert [g["size"] for g in got] == [int(v) for v in nxs]
+    assert len(set(int(v) for v in nxs)) >= 2 and int(nxs[0]) > 2 * int(nxs[1])  # neighbours of different sizes
+    grids = [o.Grid(r, world, o.BDY_LASER, o.BDY_ABSORBING, xmin, dx, nxs, offs) for r in range(world)]
+    keys = ("cell", "x", "ux", "uy", "uz", "w")
+    pes = [o.Population.from_soa(o.ELECTRON, *[g[f"init_e_{k}"] for k in keys], dx, dt) for g in got]
+    pis = [o.Population.from_soa(o.ION, *[g[f"init_i_{k}"] for k in keys], dx, dt) for g in got]
+    for p in pis:
+        p.set_charge_state(6.0, 6.0, 12.0)
+    n0 = [len(p) for p in pes]
+    t = -4.0e-6 / C
+    for _ in range(steps):
+        assert o.world_step(grids, pes, pis, True, t, dt, laser_y=ly, laser_z=lz) == 0
+        t += dt
+    assert abs(got[0]["t"] - t) <= 1e-12 * abs(t)
+    # the front swept the electrons of the first subdomains forward, across the cuts
+    n1 = [len(p) for p in pes]
+    gained = [r for r in range(world) if n1[r] > 1.2 * n0[r]]
+    lost = [r for r in range(world) if n1[r] < 0.8 * n0[r]]
+    assert lost and gained and max(gained) >= (3 if world == 8 else 1), (n0, n1)
+    amp = max(np.max(np.abs(g.raw("Ey"))) for g in grids)
+    lit = [r for r in range(world) if np.max(np.abs(grids[r].raw("Ey"))) > 0.01 * amp]
+    assert len(lit) >= (4 if world == 8 else 2), lit  # the pulse itself is past that many cuts
+    fe = sum(g["energies"][0] for g in got)
+    ke = sum(g["energies"][1] for g in got)
+    ki = sum(g["energies"][2] for g in got)
+    ofe = sum(g.em_field_energy() for g in grids)
+    oke = sum(p.total_kinetic_energy() for p in pes)
+    oki = sum(p.total_kinetic_energy() for p in pis)
+    # north_star's tolerance: fields (and the particle moments) within 1e-6 relative of the CPU path
+    assert abs(fe - ofe) / ofe < 1e-6 and abs(ke - oke) / oke < 1e-6 and abs(ki - oki) / oki < 1e-6
+    for r in range(world):
+        assert len(got[r]["e_x"]) == n1[r] and len(got[r]["i_x"]) == len(pis[r]), r
+        for k in COMPS:
+            ref = grids[r].raw(k)
+            scale = max(np.max(np.abs(g.raw(k))) for g in grids)
+            assert np.max(np.abs(got[r][k] - ref)) <= 1e-6 * scale, (r, k)
