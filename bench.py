@@ -158,6 +158,21 @@ constants:
 """
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup this process runs in may use (None: unlimited)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]      # cgroup v2: "max 100000" or "1600000 100000"
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())     # cgroup v1
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def host_cpu():
     """(model name, physical cores this process may run on, logical cpus it may run on)."""
     allowed = sorted(os.sched_getaffinity(0))
@@ -215,34 +230,40 @@ def _time_oracle(o, grids, pes, pis, dt, threads, target_seconds, max_steps):
     bad = o.world_run_periodic(grids, pes, pis, True, 0.0, dt, 2, threads)
     per_step = (time.perf_counter() - t0) / 2
     steps = int(max(3, min(max_steps, target_seconds / max(per_step, 1e-6))))
+    o.phase_times()
     t0 = time.perf_counter()
     bad += o.world_run_periodic(grids, pes, pis, True, 2 * dt, dt, steps, threads)
     el = time.perf_counter() - t0
     assert bad == 0
-    return n, steps, n * steps / el
+    ph = o.phase_times()
+    S = len(grids)
+    # push, sort and the two deposit phases are summed over the subdomains, which run side by side
+    per_step_ms = {k: 1e3 * v / steps / (S if k in ("push", "sort", "deposit_scatter", "deposit_reduce") else 1) for k, v in ph.items()}
+    return n, steps, n * steps / el, per_step_ms, 1e3 * el / steps
 
 
 def cpu_baseline(oa, cells, npc, target_seconds=14.0):
     """Times the oracle in reference-algorithm mode on a bounded sample of the workload: 4096 cells at the
     FULL particles-per-cell (what one of configs[2]'s 8 ranks holds, or all of configs[1]) as S subdomains x
-    T threads = all physical cores (the reference's MPI x Rayon layout); then configs[0] on 1 x 1."""
+    T threads = the cores this process may use (the reference's MPI x Rayon layout); then configs[0] on 1 x 1."""
     from oracle import oracle as o
 
     o.build()
-    o.set_sort_mode(1)   # comparison sort of the AoS structs every step, as the reference's par_sort_unstable_by_key
+    o.set_sort_mode(1)   # the AoS structs sorted by cell every step with the restatement of rayon's par_sort_unstable_by_key
     o.set_parallel_subdomains(True)
     try:
         model, phys, logical = host_cpu()
-        cores = max(1, min(o.max_threads(), phys))
+        quota = cpu_quota()
+        cores = max(1, min(o.max_threads(), phys, int(quota) if quota else phys))
         S = 8 if cores >= 16 else 1
         T = max(1, cores // S)
         dx = 500.0
         cells_s = min(cells, 4096)
         grids, pes, pis, dt = _oracle_world(oa, o, YAML.format(nx=cells_s, npc=npc), dx, cells_s, S)
-        n, steps, rate = _time_oracle(o, grids, pes, pis, dt, T, target_seconds, 200)
+        n, steps, rate, phases, step_ms = _time_oracle(o, grids, pes, pis, dt, T, target_seconds, 200)
         del grids, pes, pis
         g1, pe1, _, dt1 = _oracle_world(oa, o, C1_YAML, dx, 1000, 1)
-        n1, steps1, rate1 = _time_oracle(o, g1, pe1, None, dt1, 1, 5.0, 2000)
+        n1, steps1, rate1, phases1, step1_ms = _time_oracle(o, g1, pe1, None, dt1, 1, 5.0, 2000)
     finally:
         o.set_sort_mode(0)
         o.set_parallel_subdomains(False)
@@ -254,18 +275,26 @@ def cpu_baseline(oa, cells, npc, target_seconds=14.0):
         "cpu_model": model,
         "physical_cores": phys,
         "logical_cpus": logical,
+        "cgroup_cpu_quota": quota,
         "S": S,
         "T": T,
+        "ms_per_step": step_ms,
+        "ms_per_step_by_phase": phases,
+        "sort_share_of_step": phases["sort"] / step_ms,
         "sample": f"two_stream e-+e+, {cells_s} of {cells} cells at the full {npc}+{npc} per cell ({n} particles), "
                   f"{steps} steps; CPU restatement of opal's algorithm (C oracle, not the opal binary): AoS structs, "
-                  f"parallel comparison sort by cell every step, per-thread private current arrays + serial reduce, "
-                  f"serial field solve per subdomain; {S} subdomains x {T} OpenMP threads (MPI x Rayon layout)",
+                  f"the whole population sorted by cell every step with a restatement of rayon's par_sort_unstable_by_key "
+                  f"(pattern-defeating quicksort, parallel joins), per-thread private current arrays + serial reduce, "
+                  f"serial field solve per subdomain; {S} subdomains x {T} OpenMP threads (MPI x Rayon layout) = the "
+                  f"{S * T} cores this process may use (affinity {logical} logical CPUs, cgroup quota {quota})",
         "config0_1x1": {
             "value": rate1,
             "unit": "particle-updates/s",
             "cores": 1,
             "S": 1,
             "T": 1,
+            "ms_per_step_by_phase": phases1,
+            "sort_share_of_step": phases1["sort"] / step1_ms,
             "sample": f"BASELINE configs[0] (examples/two_stream.yaml's parameters: 1000 cells, {n1} electrons), "
                       f"{steps1} steps, same restatement on 1 subdomain x 1 thread",
         },
@@ -311,6 +340,10 @@ def launch_ranks(n, argv):
 
 
 def main():
+    # the CPU baseline's OpenMP teams (subdomains x threads, plus the sort's task teams) must not spin when idle: a
+    # spinning team member takes the core another team's worker needs (read by the OpenMP runtime when it is loaded)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -653,9 +686,9 @@ def main():
         if not args.unfused and not args.no_default_path:
             m_default = measure(sim, half, args.warmup, workload_key=wkey)
         oa.set_elision(False)
-        if m_default is not None:
+        if m_default is not None or os.environ.get("OPAL_BENCH_REGROUP"):  # (the latter: a diagnostic)
             regroup(sim)
-        m = measure(sim, args.steps, args.warmup, preheat=m_default is None, workload_key=wkey)
+        m = measure(sim, args.steps, args.warmup, workload_key=wkey)  # (pre-heated again: another kernel, another power state)
     t_end = sim.t
 
     if rank == 0:
@@ -721,7 +754,7 @@ def main():
             oa.set_elision(False)
             if m2d is not None:
                 regroup(sim2)
-            m2 = measure(sim2, args.steps, args.warmup, preheat=m2d is None, workload_key=k2)
+            m2 = measure(sim2, args.steps, args.warmup, workload_key=k2)
             del sim2
             out["secondary"] = block(m2, f"two_stream, {C2_NPC} e- + {C2_NPC} e+ per cell, {C2_CELLS} cells (BASELINE configs[1]), "
                                          f"1 GPU; " + CONTRACT, args.steps,

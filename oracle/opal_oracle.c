@@ -1197,11 +1197,17 @@ static inline void pshift(Population *p, void *store, size_t i, long delta)
     else ((Photon *)store)[i].cell += delta;
 }
 
-/* The reference sorts the AoS structs with rayon's par_sort_unstable_by_key (mod.rs:288): a parallel
- * comparison sort, O(N log N) moves of 104-112 byte structs every step.  Sort mode 1 does that class of
- * work, for bench.py's CPU baseline: qsort of one chunk per thread, then log2(T) rounds of pairwise
- * merges, each merge split by key among the threads.  Mode 0 (default, what the parity tests use) is the
- * stable counting sort below; the reference leaves tie order unspecified, so both are "its" result. */
+/* The reference sorts the AoS structs with rayon's par_sort_unstable_by_key (mod.rs:288; rayon 1.2.1
+ * src/slice/quicksort.rs, itself a parallel port of the standard library's pattern-defeating quicksort): an
+ * unstable, in-place comparison sort that is adaptive -- median-of-three / ninther pivots chosen with a count of
+ * the swaps that took, a partial insertion sort that finishes slices which turn out to be nearly sorted, a
+ * partition that puts the elements EQUAL to a repeated pivot aside in one pass (cell indices repeat thousands of
+ * times), heapsort when the recursion degenerates -- and that recurses on both sides in parallel (rayon::join) above
+ * 2000 elements.  Sort mode 1 is a restatement of that algorithm from its published description (the crate is a
+ * dependency that is not under /root/reference), with OpenMP tasks for the joins, for bench.py's CPU baseline; on
+ * the almost-sorted arrays of a PIC step it does ~log2(cells) passes of key comparisons and moves few structs.
+ * Mode 0 (default, what the parity tests use) is the stable counting sort below; the reference leaves tie order
+ * unspecified, so both are "its" result. */
 static int g_sort_mode = 0;
 void oracle_set_sort_mode(int mode) { g_sort_mode = mode; }
 /* S subdomains x T threads, the reference's MPI x Rayon layout, inside one process: with this on, the
@@ -1212,75 +1218,250 @@ void oracle_set_parallel_subdomains(int on)
 {
     g_parallel_subdomains = on;
 #ifdef _OPENMP
-    omp_set_max_active_levels(on ? 2 : 1);
+    omp_set_max_active_levels(on ? 3 : 1);
 #endif
 }
 
-static int cmp_cell(const void *a, const void *b)
+/* wall-clock seconds per phase of oracle_world_step since the last reset, summed over the calls (the maximum over
+ * the subdomains where they run side by side): 0 push, 1 sort, 2 migrate, 3 deposit (scatter into per-thread
+ * arrays), 4 deposit's serial reduce, 5 synchronize + field solve */
+static double g_phase[6];
+static double now_s(void)
 {
-    long x = *(const long *)a, y = *(const long *)b; /* `cell` is the first member of every species struct */
-    return (x > y) - (x < y);
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
 }
-/* first index in [lo, hi) whose cell is >= key */
-static size_t lower_bound_cell(const char *base, size_t sz, size_t lo, size_t hi, long key)
+void oracle_phase_times(double *out, int reset)
 {
-    while (lo < hi) {
-        size_t mid = lo + (hi - lo) / 2;
-        if (*(const long *)(base + mid * sz) < key) lo = mid + 1; else hi = mid;
+    for (int k = 0; k < 6; k++) {
+        out[k] = g_phase[k];
+        if (reset) g_phase[k] = 0.0;
     }
-    return lo;
 }
-static void merge_runs(const char *src, char *dst, size_t sz, size_t a, size_t ae, size_t b, size_t be, size_t out)
+
+#define PDQ_KEY(i) (*(const long *)(base + (size_t)(i) * sz))
+static inline void pdq_swap(char *base, size_t sz, size_t i, size_t j)
 {
-    while (a < ae && b < be) {
-        if (*(const long *)(src + b * sz) < *(const long *)(src + a * sz)) memcpy(dst + (out++) * sz, src + (b++) * sz, sz);
-        else memcpy(dst + (out++) * sz, src + (a++) * sz, sz);
+    if (i == j) return;
+    char tmp[128];
+    memcpy(tmp, base + i * sz, sz);
+    memcpy(base + i * sz, base + j * sz, sz);
+    memcpy(base + j * sz, tmp, sz);
+}
+static void pdq_insertion(char *base, size_t sz, size_t lo, size_t hi)
+{
+    char tmp[128];
+    for (size_t i = lo + 1; i < hi; i++) {
+        long k = PDQ_KEY(i);
+        if (!(k < PDQ_KEY(i - 1))) continue;
+        memcpy(tmp, base + i * sz, sz);
+        size_t j = i;
+        while (j > lo && k < PDQ_KEY(j - 1)) {
+            memcpy(base + j * sz, base + (j - 1) * sz, sz);
+            j--;
+        }
+        memcpy(base + j * sz, tmp, sz);
     }
-    if (a < ae) memcpy(dst + out * sz, src + a * sz, (ae - a) * sz), out += ae - a;
-    if (b < be) memcpy(dst + out * sz, src + b * sz, (be - b) * sz);
+}
+/* fixes up to five out-of-order pairs by shifting them into place; 1 if the slice ended up sorted */
+static int pdq_partial_insertion(char *base, size_t sz, size_t lo, size_t hi)
+{
+    const size_t len = hi - lo;
+    size_t i = lo + 1;
+    char tmp[128];
+    for (int step = 0; step < 5; step++) {
+        while (i < hi && !(PDQ_KEY(i) < PDQ_KEY(i - 1))) i++;
+        if (i == hi) return 1;
+        if (len < 50) return 0;
+        pdq_swap(base, sz, i - 1, i);
+        /* shift the smaller one left through [lo, i) ... */
+        if (i - lo >= 2) {
+            size_t j = i - 1;
+            long k = PDQ_KEY(j);
+            if (k < PDQ_KEY(j - 1)) {
+                memcpy(tmp, base + j * sz, sz);
+                while (j > lo && k < PDQ_KEY(j - 1)) {
+                    memcpy(base + j * sz, base + (j - 1) * sz, sz);
+                    j--;
+                }
+                memcpy(base + j * sz, tmp, sz);
+            }
+        }
+        /* ... and the greater one right through [i, hi) */
+        if (hi - i >= 2) {
+            size_t j = i;
+            long k = PDQ_KEY(j);
+            if (PDQ_KEY(j + 1) < k) {
+                memcpy(tmp, base + j * sz, sz);
+                while (j + 1 < hi && PDQ_KEY(j + 1) < k) {
+                    memcpy(base + j * sz, base + (j + 1) * sz, sz);
+                    j++;
+                }
+                memcpy(base + j * sz, tmp, sz);
+            }
+        }
+    }
+    return 0;
+}
+static void pdq_heapsort(char *base, size_t sz, size_t lo, size_t hi)
+{
+    const size_t n = hi - lo;
+    char *b = base + lo * sz;
+#define HK(i) (*(const long *)(b + (size_t)(i) * sz))
+    for (size_t start = n / 2; start-- > 0;) {
+        size_t node = start;
+        for (;;) {
+            size_t child = 2 * node + 1;
+            if (child >= n) break;
+            if (child + 1 < n && HK(child) < HK(child + 1)) child++;
+            if (!(HK(node) < HK(child))) break;
+            pdq_swap(b, sz, node, child);
+            node = child;
+        }
+    }
+    for (size_t end = n; end-- > 1;) {
+        pdq_swap(b, sz, 0, end);
+        size_t node = 0;
+        for (;;) {
+            size_t child = 2 * node + 1;
+            if (child >= end) break;
+            if (child + 1 < end && HK(child) < HK(child + 1)) child++;
+            if (!(HK(node) < HK(child))) break;
+            pdq_swap(b, sz, node, child);
+            node = child;
+        }
+    }
+#undef HK
+}
+/* index of a good pivot in [lo, hi) and whether the slice looks sorted already (no swaps were needed) */
+static size_t pdq_choose_pivot(char *base, size_t sz, size_t lo, size_t hi, int *likely_sorted)
+{
+    const size_t len = hi - lo;
+    size_t a = lo + len / 4, b = lo + len / 4 * 2, c = lo + len / 4 * 3;
+    int swaps = 0;
+#define SORT2(x, y) do { if (PDQ_KEY(y) < PDQ_KEY(x)) { size_t t_ = x; x = y; y = t_; swaps++; } } while (0)
+#define SORT3(x, y, z) do { SORT2(x, y); SORT2(y, z); SORT2(x, y); } while (0)
+    if (len >= 8) {
+        if (len >= 50) {
+            size_t a0 = a - 1, a1 = a + 1, b0 = b - 1, b1 = b + 1, c0 = c - 1, c1 = c + 1;
+            SORT3(a0, a, a1);
+            SORT3(b0, b, b1);
+            SORT3(c0, c, c1);
+        }
+        SORT3(a, b, c);
+    }
+#undef SORT3
+#undef SORT2
+    if (swaps < 12) {
+        *likely_sorted = swaps == 0;
+        return b;
+    }
+    /* descending: reverse, as the original does */
+    for (size_t i = lo, j = hi - 1; i < j; i++, j--) pdq_swap(base, sz, i, j);
+    *likely_sorted = 1;
+    return lo + (hi - 1 - b);
+}
+/* moves the pivot to the front, partitions the rest into (< pivot | >= pivot), puts the pivot between them; returns
+ * its final index and whether no element had to move */
+static size_t pdq_partition(char *base, size_t sz, size_t lo, size_t hi, size_t pivot, int *was_partitioned)
+{
+    pdq_swap(base, sz, lo, pivot);
+    const long pk = PDQ_KEY(lo);
+    size_t l = lo + 1, r = hi;
+    while (l < r && PDQ_KEY(l) < pk) l++;
+    while (l < r && !(PDQ_KEY(r - 1) < pk)) r--;
+    *was_partitioned = l >= r;
+    while (l < r) {
+        pdq_swap(base, sz, l, r - 1);
+        l++;
+        r--;
+        while (l < r && PDQ_KEY(l) < pk) l++;
+        while (l < r && !(PDQ_KEY(r - 1) < pk)) r--;
+    }
+    pdq_swap(base, sz, lo, l - 1);
+    return l - 1;
+}
+/* the slice holds no element smaller than the pivot: puts those EQUAL to it first; returns one past them */
+static size_t pdq_partition_equal(char *base, size_t sz, size_t lo, size_t hi, size_t pivot)
+{
+    pdq_swap(base, sz, lo, pivot);
+    const long pk = PDQ_KEY(lo);
+    size_t l = lo + 1, r = hi;
+    for (;;) {
+        while (l < r && !(pk < PDQ_KEY(l))) l++;
+        while (l < r && pk < PDQ_KEY(r - 1)) r--;
+        if (l >= r) break;
+        r--;
+        pdq_swap(base, sz, l, r);
+        l++;
+    }
+    return l;
+}
+static void pdq_recurse(char *base, size_t sz, size_t lo, size_t hi, int has_pred, long pred, int limit)
+{
+    int was_balanced = 1, was_partitioned = 1;
+    for (;;) {
+        const size_t len = hi - lo;
+        if (len <= 20) {
+            pdq_insertion(base, sz, lo, hi);
+            return;
+        }
+        if (limit == 0) {
+            pdq_heapsort(base, sz, lo, hi);
+            return;
+        }
+        if (!was_balanced) {  /* break patterns: swap three elements around the middle with pseudo-random ones */
+            unsigned long long rnd = (unsigned long long)len;
+            size_t pos = lo + len / 4 * 2;
+            for (int i = 0; i < 3; i++) {
+                rnd ^= rnd << 13; rnd ^= rnd >> 7; rnd ^= rnd << 17;
+                pdq_swap(base, sz, pos - 1 + (size_t)i, lo + (size_t)(rnd % len));
+            }
+            limit--;
+        }
+        int likely_sorted;
+        size_t pivot = pdq_choose_pivot(base, sz, lo, hi, &likely_sorted);
+        if (was_balanced && was_partitioned && likely_sorted)
+            if (pdq_partial_insertion(base, sz, lo, hi)) return;
+        if (has_pred && !(pred < PDQ_KEY(pivot))) {  /* the pivot equals the predecessor: it is this slice's minimum */
+            lo = pdq_partition_equal(base, sz, lo, hi, pivot);
+            continue;
+        }
+        size_t mid = pdq_partition(base, sz, lo, hi, pivot, &was_partitioned);
+        const size_t nl = mid - lo, nr = hi - mid - 1;
+        was_balanced = (nl < nr ? nl : nr) >= len / 8;
+        const long pk = PDQ_KEY(mid);
+        if ((nl > nr ? nl : nr) <= 2000) {  /* rayon: MAX_SEQUENTIAL -- the shorter side first, then loop on the longer */
+            if (nl < nr) {
+                pdq_recurse(base, sz, lo, mid, has_pred, pred, limit);
+                lo = mid + 1; has_pred = 1; pred = pk;
+            } else {
+                pdq_recurse(base, sz, mid + 1, hi, 1, pk, limit);
+                hi = mid;
+            }
+        } else {  /* rayon::join */
+#pragma omp task default(none) firstprivate(base, sz, lo, mid, has_pred, pred, limit)
+            pdq_recurse(base, sz, lo, mid, has_pred, pred, limit);
+            pdq_recurse(base, sz, mid + 1, hi, 1, pk, limit);
+#pragma omp taskwait
+            return;
+        }
+    }
 }
 static void comparison_sort(char *base, size_t num, size_t sz, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
-    size_t nchunk = (size_t)nthreads;
-    if (num < 4096 * nchunk) nchunk = 1;
-    size_t *lo = (size_t *)malloc((nchunk + 1) * sizeof(size_t));
-    for (size_t k = 0; k <= nchunk; k++) lo[k] = num / nchunk * k + (k == nchunk ? num % nchunk : 0);
-#pragma omp parallel for schedule(static) num_threads(nthreads)
-    for (size_t k = 0; k < nchunk; k++) qsort(base + lo[k] * sz, lo[k + 1] - lo[k], sz, cmp_cell);
-    if (nchunk > 1) {
-        char *tmp = (char *)malloc(num * sz), *src = base, *dst = tmp;
-        for (size_t width = 1; width < nchunk; width *= 2) {
-            size_t npairs = (nchunk + 2 * width - 1) / (2 * width);
-            size_t split = ((size_t)nthreads + npairs - 1) / npairs; /* key ranges per merge */
-#pragma omp parallel for schedule(static) num_threads(nthreads) collapse(2)
-            for (size_t pr = 0; pr < npairs; pr++) {
-                for (size_t part = 0; part < split; part++) {
-                    size_t k = pr * 2 * width;
-                    size_t a = lo[k], m = lo[k + width < nchunk ? k + width : nchunk], b = lo[k + 2 * width < nchunk ? k + 2 * width : nchunk];
-                    if (a == b) continue;
-                    long kmin = *(const long *)(src + a * sz), kmax = *(const long *)(src + (m - 1) * sz);
-                    if (m < b) {
-                        long k2 = *(const long *)(src + m * sz), k3 = *(const long *)(src + (b - 1) * sz);
-                        if (k2 < kmin) kmin = k2;
-                        if (k3 > kmax) kmax = k3;
-                    }
-                    long span = kmax - kmin + 1;
-                    long key_lo = kmin + span * (long)part / (long)split, key_hi = kmin + span * (long)(part + 1) / (long)split;
-                    size_t a0 = part == 0 ? a : lower_bound_cell(src, sz, a, m, key_lo);
-                    size_t a1 = part + 1 == split ? m : lower_bound_cell(src, sz, a, m, key_hi);
-                    size_t b0 = part == 0 ? m : lower_bound_cell(src, sz, m, b, key_lo);
-                    size_t b1 = part + 1 == split ? b : lower_bound_cell(src, sz, m, b, key_hi);
-                    merge_runs(src, dst, sz, a0, a1, b0, b1, a + (a0 - a) + (b0 - m));
-                }
-            }
-            char *t = src; src = dst; dst = t;
-        }
-        if (src != base) memcpy(base, src, num * sz);
-        free(tmp);
-    }
-    free(lo);
+    int limit = 0;
+    for (size_t n = num; n; n >>= 1) limit++;  /* floor(log2(len)) + 1 imbalanced partitions before heapsort */
+    if (sz > 128) abort();
+#pragma omp parallel num_threads(nthreads)
+#pragma omp single
+    pdq_recurse(base, sz, 0, num, 0, 0, limit);
 }
+#undef PDQ_KEY
 
 /* particle/mod.rs:247-293: gather + push every particle, count leavers, sort
  * by cell, re-base right-leavers.  The sort is a stable counting sort (the
@@ -1293,6 +1474,7 @@ size_t oracle_pop_push_and_sort(Population *p, const YeeGrid *grid, double dt, i
     long max = (long)grid->size;
     size_t num = p->n, bad = 0, gl = 0, gr = 0;
     (void)nthreads;
+    const double t_push0 = now_s();
 #pragma omp parallel for reduction(+ : bad, gl, gr) schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
     for (size_t i = 0; i < num; i++) {
         double E[3], B[3];
@@ -1319,6 +1501,12 @@ size_t oracle_pop_push_and_sort(Population *p, const YeeGrid *grid, double dt, i
         if (c < 0) gl++;
         else if (c >= max) gr++;
     }
+    const double t_sort0 = now_s();
+    {
+        const double dt_ = t_sort0 - t_push0;
+#pragma omp atomic
+        g_phase[0] += dt_;
+    }
     if (num && g_sort_mode == 1) {
         comparison_sort((char *)p->store, num, psize(p->species), nthreads);
     } else if (num) {
@@ -1340,6 +1528,11 @@ size_t oracle_pop_push_and_sort(Population *p, const YeeGrid *grid, double dt, i
         memcpy(p->store, out, num * sz);
         free(out);
         free(count);
+    }
+    {
+        const double dt_ = now_s() - t_sort0;
+#pragma omp atomic
+        g_phase[1] += dt_;
     }
     for (size_t i = num - gr; i < num; i++) pshift(p, p->store, i, -max); /* mod.rs:291-293 */
     p->gone_left = gl;
@@ -1365,15 +1558,19 @@ void oracle_pop_splice(Population *p, const YeeGrid *grid, const void *recv_left
     size_t sz = psize(p->species), num = p->n, gl = p->gone_left, gr = p->gone_right;
     long max = (long)grid->size;
     size_t keep = num - gl - gr, newn = nl + keep + nr;
-    char *out = (char *)malloc((newn ? newn : 1) * sz);
-    if (nl) memcpy(out, recv_left, nl * sz);
-    memcpy(out + nl * sz, (char *)p->store + gl * sz, keep * sz);
-    if (nr) memcpy(out + (nl + keep) * sz, recv_right, nr * sz);
-    for (size_t i = nl + keep; i < newn; i++) pshift(p, out, i, max);
-    free(p->store);
-    p->store = out;
+    /* Vec::splice twice, in place as the reference does it (mod.rs:369-370: "eat the cost, which is not so bad"): the
+     * arrivals from the right replace the leavers at the end, then the arrivals from the left replace those at the
+     * front, the kept particles moving by the difference of the two counts (not at all when they are equal) */
+    if (newn > p->cap) {
+        p->store = realloc(p->store, (newn + newn / 64 + 16) * sz);
+        p->cap = newn + newn / 64 + 16;
+    }
+    char *st = (char *)p->store;
+    if (nl != gl && keep) memmove(st + nl * sz, st + gl * sz, keep * sz);
+    if (nl) memcpy(st, recv_left, nl * sz);
+    if (nr) memcpy(st + (nl + keep) * sz, recv_right, nr * sz);
+    for (size_t i = nl + keep; i < newn; i++) pshift(p, st, i, max);
     p->n = newn;
-    p->cap = newn ? newn : 1;
     p->gone_left = p->gone_right = 0;
 }
 
@@ -1387,6 +1584,7 @@ size_t oracle_world_pop_advance(Population **pops, YeeGrid **grids, int n, doubl
 #pragma omp parallel for reduction(+ : bad) schedule(static, 1) num_threads(n) if (g_parallel_subdomains && n > 1)
     for (int r = 0; r < n; r++) bad += oracle_pop_push_and_sort(pops[r], grids[r], dt, nthreads);
     /* snapshot all send buffers first */
+    const double t_mig0 = now_s();
     void **sl = (void **)calloc((size_t)n, sizeof(void *)), **sr = (void **)calloc((size_t)n, sizeof(void *));
     size_t *nl = (size_t *)calloc((size_t)n, sizeof(size_t)), *nr = (size_t *)calloc((size_t)n, sizeof(size_t));
     for (int r = 0; r < n; r++) {
@@ -1406,6 +1604,7 @@ size_t oracle_world_pop_advance(Population **pops, YeeGrid **grids, int n, doubl
     }
     for (int r = 0; r < n; r++) { free(sl[r]); free(sr[r]); }
     free(sl); free(sr); free(nl); free(nr);
+    g_phase[2] += now_s() - t_mig0;
     return bad;
 }
 
@@ -1421,6 +1620,7 @@ size_t oracle_grid_deposit(YeeGrid *g, const Population *p, double dt, int nthre
     if (nthreads < 1) nthreads = 1;
     size_t chunk_len = p->n > (size_t)nthreads ? p->n / (size_t)nthreads : p->n;
     size_t nchunks = (p->n + chunk_len - 1) / chunk_len;
+    const double t_dep0 = now_s();
     double(*jall)[4] = (double(*)[4])calloc(size * nchunks, sizeof(double[4]));
 #pragma omp parallel for reduction(+ : bad) schedule(static) num_threads(nthreads)
     for (size_t k = 0; k < nchunks; k++) {
@@ -1471,6 +1671,12 @@ size_t oracle_grid_deposit(YeeGrid *g, const Population *p, double dt, int nthre
         }
     }
     /* yee.rs:616-640 */
+    const double t_red0 = now_s();
+    {
+        const double dt_ = t_red0 - t_dep0;
+#pragma omp atomic
+        g_phase[3] += dt_;
+    }
     for (size_t i = 0; i < size; i++) {
         double total[4] = {0.0, 0.0, 0.0, 0.0};
         for (size_t k = 0; k < nchunks; k++) {
@@ -1485,6 +1691,11 @@ size_t oracle_grid_deposit(YeeGrid *g, const Population *p, double dt, int nthre
         g->cell[i].rho += total[3];
     }
     free(jall);
+    {
+        const double dt_ = now_s() - t_red0;
+#pragma omp atomic
+        g_phase[4] += dt_;
+    }
     return bad;
 }
 
@@ -1505,9 +1716,11 @@ size_t oracle_world_step(YeeGrid **grids, Population **pops_e, Population **pops
             if (pops_i) bad += oracle_grid_deposit(grids[r], pops_i[r], dt, nthreads);
         }
     }
+    const double t_f0 = now_s();
     oracle_world_synchronize(grids, n, laser_y, laser_z, user, t, dt);
 #pragma omp parallel for schedule(static, 1) num_threads(n) if (g_parallel_subdomains && n > 1)
     for (int r = 0; r < n; r++) oracle_grid_advance(grids[r], dt);
+    g_phase[5] += now_s() - t_f0;
     return bad;
 }
 

@@ -132,6 +132,7 @@ def lib():
             "oracle_world_run_periodic": (C.c_size_t, [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t, C.c_int]),
             "oracle_max_threads": (C.c_int, []),
             "oracle_set_sort_mode": (None, [C.c_int]),
+            "oracle_phase_times": (None, [vp, C.c_int]),
             "oracle_set_parallel_subdomains": (None, [C.c_int]),
             "oracle_pwmci_evaluate": (C.c_int, [C.c_double, vp, C.c_size_t, dp]),
             "oracle_pwmci_invert": (C.c_int, [C.c_double, vp, C.c_size_t, dp, C.POINTER(C.c_int)]),
@@ -328,6 +329,14 @@ def set_parallel_subdomains(on):
     """S subdomains x T threads (the reference's MPI x Rayon layout) in one process: subdomain loops of the
     world_* functions run concurrently, each with its own nested `nthreads` team.  bench.py's CPU baseline."""
     lib().oracle_set_parallel_subdomains(1 if on else 0)
+
+
+def phase_times(reset=True):
+    """Seconds since the last reset spent in push, sort, migrate, deposit (scatter), deposit (serial reduce),
+    synchronize + field solve; the four particle phases are summed over the subdomains of the world calls."""
+    out = (C.c_double * 6)()
+    lib().oracle_phase_times(out, 1 if reset else 0)
+    return dict(zip(("push", "sort", "migrate", "deposit_scatter", "deposit_reduce", "fields"), [float(v) for v in out]))
 
 
 def set_sort_mode(mode):

@@ -143,3 +143,42 @@ def test_rate(oracle, chi, target):
     """photon_emission.rs:299-336"""
     value = oracle.rate(chi, 1000.0)
     assert abs((value - target) / target) < 1.0e-3
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_comparison_sort_mode_is_a_sort_and_changes_no_physics(oracle, threads):
+    """Sort mode 1 (the restatement of rayon's par_sort_unstable_by_key used by bench.py's CPU baseline: pattern-defeating
+    quicksort, OpenMP tasks for the joins) against the counting sort of mode 0: after a push the particles are ordered by
+    cell, nobody is lost or duplicated, and a world run gives the same fields (summation order aside)."""
+    import numpy as np
+    o = oracle
+    C0 = 2.997925e8
+    nx, npc, dx = 256, 200, 1.0e-8
+    dt = 0.95 * dx / C0
+    rng = np.random.default_rng(21)
+    n = nx * npc
+    cell = np.repeat(np.arange(nx, dtype=np.int64), npc)
+    state = (cell, rng.random(n), 0.6 * rng.standard_normal(n), 0.05 * rng.standard_normal(n), 0.05 * rng.standard_normal(n),
+             1.0e3 * (1.0 + 1e-9 * np.arange(n)))
+    res = {}
+    for mode in (0, 1):
+        o.set_sort_mode(mode)
+        try:
+            g = o.Grid.single(nx, 0.0, dx)
+            p = o.Population.from_soa(o.ELECTRON, *state, dx, dt)
+            t = 0.0
+            for _ in range(6):
+                assert o.world_step([g], [p], None, True, t, dt, nthreads=threads) == 0
+                s = p.soa()
+                assert np.all(np.diff(s["cell"]) >= 0)          # sorted by cell after every step (mod.rs:288)
+                t += dt
+            res[mode] = (p.soa(), g.raw("Ex"), g.raw("Ey"))
+        finally:
+            o.set_sort_mode(0)
+    a, b = res[0][0], res[1][0]
+    ia, ib = np.argsort(a["w"], kind="stable"), np.argsort(b["w"], kind="stable")
+    assert np.array_equal(a["w"][ia], b["w"][ib]) and len(a["w"]) == n      # the same particles
+    assert np.array_equal(a["cell"][ia], b["cell"][ib])
+    assert np.max(np.abs(a["x"][ia] - b["x"][ib])) < 1e-12
+    for k in (1, 2):
+        assert np.max(np.abs(res[0][k] - res[1][k])) <= 1e-11 * np.max(np.abs(res[0][k]))
