@@ -360,9 +360,14 @@ def emit_radiation(electrons, photons, seed, step, t, min_energy=None, max_angle
 TRACK_CHI, TRACK_WORK, TRACK_YZ, TRACK_EMISSION, TRACK_ID, TRACK_ABSORPTION = 1, 2, 4, 8, 16, 32
 
 
-def absorb(electrons, photons, grid, seed, step, t, dt, max_displacement=None, stop_time=None):
-    """absorb (particle/interactions.rs:145-340); returns (photons absorbed, emissions stimulated)."""
+def absorb(electrons, photons, grid, seed, step, t, dt, max_displacement=None, stop_time=None, count=True):
+    """absorb (particle/interactions.rs:145-340); returns (photons absorbed, emissions stimulated) -- or, with
+    count=False, nothing: the form the time loop uses, in which no count is read back from the device."""
     f = lambda v: -1.0 if v is None else float(v)
+    if not count:
+        _check(_lib.load().opal_absorb(electrons.h, photons.h, grid.h, seed, step, t, dt, f(max_displacement), f(stop_time),
+                                       None, None))
+        return None
     na, ns = C.c_size_t(), C.c_size_t()
     _check(_lib.load().opal_absorb(electrons.h, photons.h, grid.h, seed, step, t, dt, f(max_displacement), f(stop_time),
                                    C.byref(na), C.byref(ns)))

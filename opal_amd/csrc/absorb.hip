@@ -27,6 +27,8 @@ namespace opal {
 int pop_check_err(opal_pop_t *p);
 int pop_reserve(opal_pop_t *p, size_t extra);
 int pop_sort_exact(opal_pop_t *p, const opal_grid_t *g);
+int pop_tighten_upper(opal_pop_t *p);
+int pop_snapshot_upper(opal_pop_t *p, size_t just_added);
 }
 
 namespace {
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void k_absorb_decide(AbsorbArgs a)
 {
     const unsigned n = a.pctr->n_slots;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) a.counts[3] = n;  // for an apply pass that sizes itself on the device
     if (i >= n) return;
     a.event[i] = EVENT_NONE;
     const int cell = a.pcell[i];
@@ -163,13 +166,13 @@ __global__ __launch_bounds__(256) void k_absorb_decide(AbsorbArgs a)
         double prob_abs = 0.0, prob_st = 0.0, sigma;
         if (scaled_cross_section(k, p, chi_gamma, chi_e, false, sigma)) {
             const double partial = we * a.dt_factor * sigma;
-            if (!(partial >= 0.0)) { atomicAdd(&a.counts[2], 1u); break; }  // photon.rs:325 assert
+            if (!(partial >= 0.0)) { atomicAdd(&a.counts[2], 1u); atomicOr(&a.pctr->err, 64); break; }  // photon.rs:325 assert
             tau_abs -= partial;
             prob_abs = partial;
         }
         if (scaled_cross_section(k, p, chi_gamma, chi_e, true, sigma)) {
             const double partial = we * a.dt_factor * sigma;
-            if (!(partial >= 0.0)) { atomicAdd(&a.counts[2], 1u); break; }  // photon.rs:336 assert
+            if (!(partial >= 0.0)) { atomicAdd(&a.counts[2], 1u); atomicOr(&a.pctr->err, 64); break; }  // photon.rs:336 assert
             tau_st -= partial;
             prob_st = partial;
         }
@@ -203,9 +206,12 @@ __global__ __launch_bounds__(256) void k_absorb_decide(AbsorbArgs a)
 
 // pass 2: interactions.rs:290-332 -- absorbed photons go, stimulated ones are appended (copy of the stimulating
 // photon with the electron's weight, fresh optical depths, born now), the electrons are kicked
+// (n_before: the photon slots in use when the decide pass ran -- the host's count, or, when it did not read one back,
+// what the decide pass left in counts[3])
 __global__ __launch_bounds__(256) void k_absorb_apply(AbsorbArgs a, unsigned n_before)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_before == 0xffffffffu) n_before = a.counts[3];
     if (i >= n_before) return;
     const int state = a.event[i];
     if (state == EVENT_NONE) return;
@@ -229,8 +235,8 @@ __global__ __launch_bounds__(256) void k_absorb_apply(AbsorbArgs a, unsigned n_b
         atomicAdd(&a.pctr->n_lost, 1u);
         return;
     }
-    unsigned long long eid;
-    memcpy(&eid, &a.eid[j], sizeof eid);
+    unsigned long long pid;
+    memcpy(&pid, &a.pid[i], sizeof pid);
     a.pcell[slot] = a.pcell[i];
     a.px[slot] = a.px[i];
     a.pkx[slot] = kx; a.pky[slot] = ky; a.pkz[slot] = kz;
@@ -239,11 +245,12 @@ __global__ __launch_bounds__(256) void k_absorb_apply(AbsorbArgs a, unsigned n_b
     a.py[slot] = a.py[i];
     a.pz[slot] = a.pz[i];
     double od[2];
-    birth_randoms(a.seed, eid, a.step, od);  // .with_optical_depths(rng).at_time(t), :311
+    uint64_t nid;
+    stimulated_birth(a.seed, pid, a.pbirth[i], a.step, nid, od);  // .with_optical_depths(rng).at_time(t), :311
     a.ptau_abs[slot] = -log(1.0 - od[0]);
     a.ptau_st[slot] = -log(1.0 - od[1]);
     a.pbirth[slot] = a.t;
-    memcpy(&a.pid[slot], &eid, sizeof eid);
+    memcpy(&a.pid[slot], &nid, sizeof nid);
 }
 
 __global__ void k_airy_batch(int n, const double *x, double *out)
@@ -310,18 +317,38 @@ int opal_absorb(opal_pop_t *e, opal_pop_t *ph, const opal_grid_t *grid, uint64_t
     // electrons exactly binned by cell; the sort's cursors are the cell ends
     if (int rc = pop_sort_exact(e, grid)) return rc;
     if (e->n_upper == 0) return OPAL_OK;
-    if (int rc = pop_check_err(ph)) return rc;  // also brings the photons' slot count to the host
-    const unsigned nph = ph->h_ctr->n_slots;
-    ph->n_upper = nph;
+    // The caller that wants the event counts gets them (one read-back); the time loop does not ask, and then
+    // nothing is read back at all: the passes size themselves on the device from the photons' slot counter, room is
+    // reserved for the most that can happen (every photon stimulates one emission; HBM is plentiful), the host's bound
+    // on the photon slots in use is tightened from counter snapshots that arrive a step or two later (as
+    // opal_emit_radiation does), and a tripped reference assert is reported by the next status check.
+    const bool readback = n_absorbed || n_stimulated;
+    unsigned nph;
+    if (readback) {
+        if (int rc = pop_check_err(ph)) return rc;  // also brings the photons' slot count to the host
+        nph = ph->h_ctr->n_slots;
+        ph->n_upper = nph;
+    } else {
+        if (int rc = pop_tighten_upper(ph)) return rc;
+        nph = (unsigned)ph->n_upper;
+        if (int rc = pop_reserve(ph, nph)) return rc;
+    }
     if (nph == 0) return OPAL_OK;
 
-    unsigned char *d_event = nullptr;
-    unsigned *d_partner = nullptr, *d_counts = nullptr;
-    OPAL_HIP(hipMalloc(&d_event, nph));
-    OPAL_HIP(hipMalloc(&d_partner, sizeof(unsigned) * nph));
-    OPAL_HIP(hipMalloc(&d_counts, sizeof(unsigned) * 4));
+    // scratch that lives with the photon population: what happened to each photon slot and with which electron
+    if (ph->abs_cap < nph) {
+        if (ph->d_abs_event) hipFree(ph->d_abs_event);
+        if (ph->d_abs_partner) hipFree(ph->d_abs_partner);
+        ph->d_abs_event = nullptr; ph->d_abs_partner = nullptr;
+        const size_t cap = std::max<size_t>(ph->cap, nph);
+        OPAL_HIP(hipMalloc(&ph->d_abs_event, cap));
+        OPAL_HIP(hipMalloc(&ph->d_abs_partner, sizeof(unsigned) * cap));
+        ph->abs_cap = cap;
+    }
+    if (!ph->d_abs_counts) OPAL_HIP(hipMalloc(&ph->d_abs_counts, sizeof(unsigned) * 4));
+    unsigned char *d_event = ph->d_abs_event;
+    unsigned *d_partner = ph->d_abs_partner, *d_counts = ph->d_abs_counts;
     OPAL_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned) * 4, e->stream));
-    auto release = [&]() { hipFree(d_event); hipFree(d_partner); hipFree(d_counts); };
 
     AbsorbArgs a;
     memset(&a, 0, sizeof a);
@@ -346,42 +373,38 @@ int opal_absorb(opal_pop_t *e, opal_pop_t *ph, const opal_grid_t *grid, uint64_t
     a.dt_factor = SPEED_OF_LIGHT * dt / grid->dx;
     a.max_displacement = max_displacement; a.stop_time = stop_time;
     k_absorb_decide<<<(nph + 255) / 256, 256, 0, e->stream>>>(a);
-    unsigned counts[4] = {0, 0, 0, 0};
-    hipError_t herr = hipGetLastError();
-    if (herr == hipSuccess) herr = hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, e->stream);
-    if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
-    if (herr != hipSuccess) {
-        release();
-        set_error("HIP error %d (%s) in opal_absorb", (int)herr, hipGetErrorString(herr));
-        return OPAL_ERR_HIP;
+    OPAL_HIP(hipGetLastError());
+    if (!readback) {
+        k_absorb_apply<<<(nph + 255) / 256, 256, 0, e->stream>>>(a, 0xffffffffu);
+        OPAL_HIP(hipGetLastError());
+        ph->n_upper += nph;  // upper bound: one stimulated emission per photon at the most
+        ph->sorted_exact = false;
+        ph->emit_list_valid = false;
+        e->emit_list_valid = false;
+        return pop_snapshot_upper(ph, nph);
     }
+    unsigned counts[4] = {0, 0, 0, 0};
+    OPAL_HIP(hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, e->stream));
+    OPAL_HIP(hipStreamSynchronize(e->stream));
     if (counts[2]) {
-        release();
+        OPAL_HIP(hipMemsetAsync(&ph->d_ctr->err, 0, sizeof(int), e->stream));
         set_error("%u photon-electron pairs gave a negative or non-finite interaction probability "
                   "(photon.rs:325,336 assert!(partial_prob >= 0.0))", counts[2]);
         return OPAL_ERR_ASSERT;
     }
     if (counts[0] || counts[1]) {
         if (counts[1]) {
-            if (int rc = pop_reserve(ph, counts[1])) {  // may move the photon arrays
-                release();
-                return rc;
-            }
+            if (int rc = pop_reserve(ph, counts[1])) return rc;  // may move the photon arrays
             bind_photons();
         }
         k_absorb_apply<<<(nph + 255) / 256, 256, 0, e->stream>>>(a, nph);
-        herr = hipGetLastError();
-        if (herr == hipSuccess) herr = hipStreamSynchronize(e->stream);
-        if (herr != hipSuccess) {
-            release();
-            set_error("HIP error %d (%s) in opal_absorb", (int)herr, hipGetErrorString(herr));
-            return OPAL_ERR_HIP;
-        }
+        OPAL_HIP(hipGetLastError());
+        OPAL_HIP(hipStreamSynchronize(e->stream));
         ph->n_upper = (size_t)nph + counts[1];
+        ph->sorted_exact = false;
         ph->emit_list_valid = false;
         e->emit_list_valid = false;  // (the re-binning above already said so)
     }
-    release();
     if (n_absorbed) *n_absorbed = counts[0];
     if (n_stimulated) *n_stimulated = counts[1];
     return OPAL_OK;

@@ -161,6 +161,10 @@ struct opal_pop {
     // Every uy and uz uploaded was zero and only electrostatic launches (particles.hip, ES) have pushed the
     // population since: they keep it so, or raise d_ctr->hot_yz and the grid's flag when they cannot.
     bool cold_yz;
+    // opal_absorb's scratch (photon populations): per photon slot what happened and with which electron; event counts
+    unsigned char *d_abs_event;
+    unsigned int *d_abs_partner, *d_abs_counts;
+    size_t abs_cap;
     unsigned int *d_count;     // sort scratch: ncells + 2
     size_t count_cap;
     double *d_partial;

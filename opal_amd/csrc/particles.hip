@@ -1305,6 +1305,11 @@ int check_pop_err(opal_pop_t *p)
             set_error("population capacity exceeded by arrivals from a neighbouring subdomain");
             return OPAL_ERR_CAPACITY;
         }
+        if (err & 64) {
+            set_error("a photon-electron pair gave a negative or non-finite interaction probability in absorb "
+                      "(photon.rs:325,336 assert!(partial_prob >= 0.0))");
+            return OPAL_ERR_ASSERT;
+        }
         if (err & 32) {
             set_error("photon emission at chi >= 100, which the reference's sampler does not implement "
                       "(photon_emission.rs:143-144 unimplemented!())");
@@ -2126,6 +2131,9 @@ int opal_pop_free(opal_pop_t *p)
     if (p->d_emit_list) hipFree(p->d_emit_list);
     if (p->d_tab_slot) hipFree(p->d_tab_slot);
     if (p->d_dbg) hipFree(p->d_dbg);
+    if (p->d_abs_event) hipFree(p->d_abs_event);
+    if (p->d_abs_partner) hipFree(p->d_abs_partner);
+    if (p->d_abs_counts) hipFree(p->d_abs_counts);
     free(p->h_tab_slot);
     free(p->h_cell_end);
     if (p->upper_event) hipEventDestroy(p->upper_event);

@@ -106,4 +106,22 @@ __device__ inline void absorption_randoms(uint64_t seed, uint64_t id, double bir
     out[2] = u53(d[0], d[1]);
 }
 
+// A photon created by stimulated emission (interactions.rs:243, 311): its identity and the optical depths it is born
+// with.  Keyed by the STIMULATING photon (its id and birth time) and the step -- not by the emitting electron, which
+// may radiate spontaneously in the same step (birth_randoms) and may be stimulated by several photons at once: every
+// new photon gets an id of its own, so that its later draws (absorption_randoms) are independent of its siblings'.
+__device__ inline void stimulated_birth(uint64_t seed, uint64_t parent_id, double parent_birth, uint32_t step, uint64_t &id,
+                                        double (&depth)[2])
+{
+    const uint64_t bt = (uint64_t)__double_as_longlong(parent_birth);
+    const uint32_t k0 = (uint32_t)seed ^ (uint32_t)bt, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(bt >> 32);
+    uint32_t c[4] = {(uint32_t)parent_id, (uint32_t)(parent_id >> 32), step, 32u};
+    philox(c, k0, k1);
+    id = ((uint64_t)c[1] << 32) | c[0];
+    depth[0] = u53(c[2], c[3]);
+    uint32_t d[4] = {(uint32_t)parent_id, (uint32_t)(parent_id >> 32), step, 33u};
+    philox(d, k0, k1);
+    depth[1] = u53(d[0], d[1]);
+}
+
 }  // namespace opal

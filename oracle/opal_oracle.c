@@ -959,6 +959,21 @@ void oracle_absorption_randoms(uint64_t seed, uint64_t id, double birth_time, ui
     oracle_philox(d, key, r);
     out[2] = u53(r[0], r[1]);
 }
+/* identity and optical depths of a photon created by stimulated emission, keyed by the stimulating photon and the
+ * step (qed_device.hpp: stimulated_birth) */
+void oracle_stimulated_birth(uint64_t seed, uint64_t parent_id, double parent_birth, uint32_t step, uint64_t *id, double *depth)
+{
+    uint64_t bt;
+    memcpy(&bt, &parent_birth, sizeof bt);
+    uint32_t key[2] = {(uint32_t)seed ^ (uint32_t)bt, (uint32_t)(seed >> 32) ^ (uint32_t)(bt >> 32)}, r[4];
+    uint32_t c[4] = {(uint32_t)parent_id, (uint32_t)(parent_id >> 32), step, 32u};
+    oracle_philox(c, key, r);
+    *id = ((uint64_t)r[1] << 32) | r[0];
+    depth[0] = u53(r[2], r[3]);
+    uint32_t d[4] = {(uint32_t)parent_id, (uint32_t)(parent_id >> 32), step, 33u};
+    oracle_philox(d, key, r);
+    depth[1] = u53(r[0], r[1]);
+}
 
 /* vec3.rs:115-122 */
 static Vec3 vnormalize(Vec3 a) { return vdivs(a, sqrt(vdot(a, a))); }
@@ -2139,8 +2154,8 @@ static int photon_interacts_with(Photon *ph, const Electron *e, double dt, doubl
  * Population::advance); each photon meets the electrons of its cell in slot order and stops at the first
  * event.  max_displacement / stop_time < 0 mean None.  Photons absorbed are removed (the survivors keep their
  * order: the reference's swap_remove permutes them, and the next push sorts them anyway); photons whose emission
- * was stimulated are appended behind, in photon order, with the emitting electron's weight and id, fresh
- * optical depths and birth time t.  counts[0] = absorbed, counts[1] = stimulated.  Returns the number of
+ * was stimulated are appended behind, in photon order, with the emitting electron's weight, an id of their own,
+ * fresh optical depths and birth time t.  counts[0] = absorbed, counts[1] = stimulated.  Returns the number of
  * reference asserts tripped. */
 size_t oracle_absorb(Population *e, Population *ph, uint64_t seed, uint32_t step, double t, double dt, double dx,
                      double max_displacement, double stop_time, size_t *counts)
@@ -2196,11 +2211,13 @@ size_t oracle_absorb(Population *e, Population *ph, uint64_t seed, uint32_t step
         for (size_t q = 0; q < ne; q++) {
             Photon np = emitted[q].photon;
             double od[2];
-            oracle_birth_randoms(seed, es[emitted[q].electron].id, step, od);  /* .with_optical_depths(rng).at_time(t) */
+            uint64_t nid;
+            /* .with_optical_depths(rng).at_time(t): keyed by the stimulating photon, which also names the new one */
+            oracle_stimulated_birth(seed, np.id, np.birth_time, step, &nid, od);
             np.tau_abs = -log(1.0 - od[0]);
             np.tau_st = -log(1.0 - od[1]);
             np.birth_time = t;
-            np.id = es[emitted[q].electron].id;
+            np.id = nid;
             np.flag = 0;
             ps[ph->n++] = np;
         }

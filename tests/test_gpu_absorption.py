@@ -174,6 +174,36 @@ def test_absorb_event_parity(oa, oracle):
     assert oa.absorb(e, ph, g, seed=9, step=5, t=t, dt=dt) == o.absorb(oe, oph, 9, 5, t, dt, dx)
 
 
+def test_absorb_without_reading_counts_back(oa, oracle):
+    """The form the time loop calls (no counts asked for: nothing is read back, the apply pass sizes itself on the
+    device, room is reserved for the most that can happen), three steps in a row against the oracle, event for event."""
+    o = oracle
+    g, e, oe, ph, oph, dx, dt = _setup(oa, o, 3000, 5000, 24, 5, tau_abs=4e-6, tau_st=4e-6)
+    total = [0, 0]
+    for step in (4, 5, 6):
+        _align_oracle_electrons(e, oe, g)
+        t = 2.0e-15 + step * dt
+        assert oa.absorb(e, ph, g, seed=9, step=step, t=t, dt=dt, count=False) is None
+        na, ns = o.absorb(oe, oph, 9, step, t, dt, dx)
+        total[0] += na
+        total[1] += ns
+    assert total[0] > 300 and total[1] > 100
+    assert len(ph) == len(oph) == 5000 - total[0] + total[1]
+    pid = ph.ids()
+    ta, ts, pb = ph.absorption_state()
+    oex = oph.photon_extras()
+    a, ia, ba = _photons_by_key(ph.soa(), pid, pb)
+    b, ib, bb = _photons_by_key({k: v for k, v in oph.soa().items() if k in ("cell", "x", "ux", "uy", "uz", "w")}, oex["id"], oex["birth_time"])
+    assert np.array_equal(ia, ib) and np.array_equal(ba, bb)
+    assert len(np.unique(ia)) == len(ia)   # every photon, stimulated ones included, has an identity of its own
+    for c in ("cell", "x", "ux", "uy", "uz", "w"):
+        assert np.array_equal(a[c], b[c]), c
+    s, os_ = e.soa(), oe.soa()
+    ea, eb = np.argsort(e.ids()), np.argsort(oe.electron_ids())
+    for c in ("ux", "uy", "uz"):
+        assert np.max(np.abs(s[c][ea] - os_[c][eb])) < 1e-12 * 200.0, c
+
+
 def test_absorb_filters(oa, oracle):
     o = oracle
     t = 1.5e-15
