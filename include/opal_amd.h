@@ -391,6 +391,10 @@ int opal_sim_set_fused(opal_sim_t *s, int fused);
  * it is there for links whose latency is larger than that. */
 int opal_sim_set_overlap(opal_sim_t *s, int on);
 size_t opal_sim_overlapped_steps(const opal_sim_t *s); /* how many steps so far ran that way (diagnostic) */
+/* A HIP stream of the library's own runtime, for hosts that have none to hand in (several subdomains inside one
+ * process, one stream each: tests/_inproc_world.py).  Every `hip_stream` argument of this header takes it. */
+int opal_stream_create(void **out);
+int opal_stream_destroy(void *stream);
 /* per-kernel timing with HIP events on the library's stream: stride 0 = off, n = time every n-th
  * launch of each tracked kernel (an odd n samples both species, which alternate) */
 int opal_prof_enable(int stride);

@@ -53,6 +53,17 @@ def set_device(i):
     _check(_lib.load().opal_set_device(i))
 
 
+def stream_create():
+    """A HIP stream of the library's own runtime (an integer handle for every `stream=` argument here)."""
+    h = C.c_void_p()
+    _check(_lib.load().opal_stream_create(C.byref(h)))
+    return h.value
+
+
+def stream_destroy(stream):
+    _check(_lib.load().opal_stream_destroy(C.c_void_p(stream)))
+
+
 def design_unbalanced(numtasks, size, dx, min_subsize=8):
     """GridDesign::unbalanced (grid/mod.rs:126-151)."""
     nx = np.zeros(numtasks, dtype=np.uint64)

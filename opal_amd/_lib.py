@@ -142,6 +142,8 @@ SIGNATURES = {
     "opal_grid_write_rows": (C.c_int, [vp, sz, C.c_char_p, sz]),
     "opal_sim_energies": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]),
     "opal_sim_set_fused": (C.c_int, [vp, C.c_int]),
+    "opal_stream_create": (C.c_int, [pp]),
+    "opal_stream_destroy": (C.c_int, [vp]),
     "opal_prof_enable": (C.c_int, [C.c_int]),
     "opal_prof_reset": (C.c_int, []),
     "opal_prof_seen": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),

@@ -128,6 +128,24 @@ int opal_set_device(int device)
     return OPAL_OK;
 }
 
+int opal_stream_create(void **out)
+{
+    if (!out) {
+        set_error("opal_stream_create: null output");
+        return OPAL_ERR_ARG;
+    }
+    hipStream_t st;
+    OPAL_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out = st;
+    return OPAL_OK;
+}
+
+int opal_stream_destroy(void *stream)
+{
+    if (stream) OPAL_HIP(hipStreamDestroy((hipStream_t)stream));
+    return OPAL_OK;
+}
+
 int opal_prof_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);

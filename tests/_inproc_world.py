@@ -79,7 +79,6 @@ class InProcLink:
 
 def run_world(n, body, timeout=600.0):
     """Runs body(rank, world) -> result on n threads; returns the results in rank order, or raises the first error."""
-    import torch
     world = World(n)
     results = [None] * n
 
@@ -99,7 +98,6 @@ def run_world(n, body, timeout=600.0):
         if t.is_alive():
             world.barrier.abort()
             raise TimeoutError("a subdomain thread did not finish")
-    torch.cuda.synchronize()
     if world.errors:
         r, e, tb = world.errors[0]
         raise RuntimeError(f"subdomain {r} failed:\n{tb}")

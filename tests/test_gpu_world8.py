@@ -72,13 +72,12 @@ constants:
 
 
 def _run_hip_world(world, text, steps, capacity, sort_interval=None, fused=True):
-    import torch
     import opal_amd as oa
     from _inproc_world import InProcLink, grid_dump, run_world, soa_dump
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    streams = [oa.stream_create() for _ in range(world)]
 
     def body(r, w):
-        st = streams[r].cuda_stream
+        st = streams[r]
         link = InProcLink(w, r, particle_capacity=capacity, stream=st)
         sim = oa.Simulation(yaml_text=text, rank=r, numtasks=world, link=link, stream=st)
         sim.set_fused(fused)
@@ -99,7 +98,11 @@ def _run_hip_world(world, text, steps, capacity, sort_interval=None, fused=True)
         del sim, link
         return out
 
-    return run_world(world, body)
+    try:
+        return run_world(world, body)
+    finally:
+        for st in streams:
+            oa.stream_destroy(st)
 
 
 def test_configs2_cut_into_8_subdomains(oracle):
