@@ -50,14 +50,18 @@ __global__ __launch_bounds__(FT) void k_advance(AdvArgs a)
     advance_tile<FT>(a, blockIdx.x * FT, a.len, threadIdx.x, lds);
 }
 
+__global__ void k_publish_only(PublishBatch pub) { publish_counters(pub); }
+
 constexpr int ADV_LDS = 2 * 5 * (ADV_EDGE + 2 * ADV_HALO);  // doubles: the synchronize workgroup's two edge tiles
 static_assert(ADV_LDS >= 5 * (ADV_TILE + 2 * ADV_HALO), "an interior tile fits the same array");
 
 // synchronize + advance in ONE launch: workgroup 0 runs synchronize and then advances the cells it touched (and their
 // stencil neighbours); the other workgroups advance the tiles in between, which depend on nothing synchronize writes
-__global__ __launch_bounds__(ADV_TILE) void k_sync_advance(SyncArgs sa, AdvArgs a)
+__global__ __launch_bounds__(ADV_TILE) void k_sync_advance(SyncArgs sa, AdvArgs a, PublishBatch pub)
 {
     __shared__ double lds[ADV_LDS];
+    // (the policy's counters leave from the last workgroup: off the synchronize workgroup's longer chain where there is another)
+    if (pub.n && blockIdx.x == gridDim.x - 1) publish_counters(pub);
     if (blockIdx.x == 0) {
         synchronize_body(sa);
         advance_edges(a, lds);
@@ -188,18 +192,21 @@ void grid_advance_done(opal_grid_t *g)
 }
 
 // synchronize + advance in one launch
-int grid_sync_advance(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, double dt)
+int grid_sync_advance(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, double dt,
+                      const PublishBatch *pub)
 {
     SyncArgs sa;
     grid_sync_args(g, recv_left, recv_right, ly, lz, sa);
     AdvArgs a;
     grid_advance_args(g, dt, a);
     if (a.edge_left > ADV_EDGE || a.edge_right > ADV_EDGE) {  // (a grid too short to have an interior, yet longer than one workgroup's edges)
+        if (pub && pub->n) k_publish_only<<<1, 64, 0, g->stream>>>(*pub);
         if (int rc = grid_apply_sync(g, recv_left, recv_right, ly, lz)) return rc;
         return opal_grid_advance(g, dt);
     }
+    PublishBatch none{};
     prof_begin(KERNEL_FIELD, g->stream);
-    k_sync_advance<<<1 + grid_interior_tiles(a), ADV_TILE, 0, g->stream>>>(sa, a);
+    k_sync_advance<<<1 + grid_interior_tiles(a), ADV_TILE, 0, g->stream>>>(sa, a, pub ? *pub : none);
     prof_end(KERNEL_FIELD, g->stream);
     OPAL_HIP(hipGetLastError());
     grid_advance_done(g);

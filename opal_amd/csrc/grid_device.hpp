@@ -44,12 +44,26 @@ void grid_sync_args(const opal_grid_t *g, const double *recv_left, const double 
 void grid_advance_args(const opal_grid_t *g, double dt, AdvArgs &a);  // with the edge split for a synchronize workgroup
 void grid_advance_done(opal_grid_t *g);  // after a launch that ran the field solve with grid_advance_args
 int grid_interior_tiles(const AdvArgs &a);  // workgroups of ADV_TILE cells between the two edges
-int grid_sync_advance(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, double dt);
+// (pub: counters the re-binning policy wants published by this launch, or null)
+int grid_sync_advance(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz, double dt,
+                      const PublishBatch *pub = nullptr);
 
 constexpr int ADV_TILE = 1024;  // cells per interior workgroup of the launches that also run synchronize
 constexpr int ADV_EDGE = 512;   // at most this many cells per end for the synchronize workgroup (half its threads each)
 
 #ifdef __HIPCC__
+// called by (at least) the first wave of a workgroup
+__device__ inline void publish_counters(const PublishBatch &b)
+{
+    static_assert(sizeof(PopCounters) == 64, "one word per lane below");
+    const int e = threadIdx.x >> 4, w = threadIdx.x & 15;
+    if (threadIdx.x < 64) {
+        if (e < b.n) reinterpret_cast<volatile unsigned *>(&b.dst[e]->c)[w] = reinterpret_cast<const unsigned *>(b.src[e])[w];
+        __threadfence_system();
+        if (e < b.n && w == 0) b.dst[e]->seq = b.seq[e];
+    }
+}
+
 constexpr int ADV_HALO = 2;  // halo cells recomputed on each side of a tile
 
 // YeeGrid::advance, yee.rs:345-349 = advance_B(dt/2) (:839-848), advance_E(dt) (:852-867), advance_B(dt/2), fused,

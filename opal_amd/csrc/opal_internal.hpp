@@ -39,7 +39,8 @@ struct PopCounters {
     unsigned int w_mixed;      // an arrival brought a weight other than the population's uniform one (see opal_pop::w_uniform)
     unsigned int hot_yz;       // some slot may hold a non-zero uy or uz (see opal_pop::cold_yz)
     unsigned int n_slow_pass;  // wave passes through the slow path since last sort (what the misses cost, see maybe_sort)
-    unsigned int pad[2];
+    unsigned int n_sorted;     // slots [0, n_sorted) are where the last re-binning put them (chunk table); behind: appended since
+    unsigned int pad[1];
 };
 
 // EX_TAU_ABS, EX_TAU_ST, EX_BIRTH: a photon's optical depths against absorption / stimulated emission and its birth
@@ -48,6 +49,15 @@ struct PubCounters {
     PopCounters c;
     volatile unsigned seq;  // written after c, behind a system-scope fence
     unsigned pad[15];
+};
+
+// the re-binning policy's view of the counters: the 16 words of up to four populations go to mapped host memory, each
+// followed by the sequence number the host waits for (written by whichever kernel of the step carries the batch)
+struct PublishBatch {
+    const PopCounters *src[4];
+    PubCounters *dst[4];
+    unsigned seq[4];
+    int n;
 };
 
 enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, EX_TAU_ABS = 6, EX_TAU_ST = 7, EX_BIRTH = 8, NEX = 9 };
@@ -141,6 +151,10 @@ struct opal_pop {
     bool ctr_pending;
     int sort_interval;         // 0 never, >0 fixed, <0 adaptive
     int steps_since_sort;
+    // the adaptive policy's memory of the previous interval between re-binnings (policy_step): at how many steps the
+    // first tile misses were seen, at how many the misses had cost a re-binning; and, from those, the step of this
+    // interval at which to re-bin BEFORE the misses come (0: wait for them)
+    int miss_onset, last_onset, last_trigger, preempt_at;
     int ppt;                   // particles per thread in the push kernels (uniform chunks: before the first
                                // re-binning, and for slots appended since the last one)
     // Chunk table, rebuilt by every re-binning: the push workgroups' slot ranges, cut both every 256 x 8 slots and
@@ -150,7 +164,13 @@ struct opal_pop {
     unsigned int *d_tab_slot;
     unsigned int *h_tab_slot;  // host copy of d_tab_slot (pop_plan_split)
     size_t tab_cap;
+    // (n_sorted on the host: a LOWER bound of the device's ctr->n_sorted -- 0 from a re-binning that did not wait for the
+    // device until the count arrives with the next counter snapshot; the pushes read the device's)
     unsigned int n_tab, n_sorted;
+    bool sorted_count_pending; // the snapshot in flight (upper_event) carries the slot count a re-binning left: it is n_sorted
+    unsigned int count_cells;  // d_count holds the cell ends of this many cells (set by a re-binning)
+    bool want_host_maps;       // keep h_cell_end / h_tab_slot current (the overlapped step's edge / bulk split reads them):
+                               // re-binnings then wait for the device
     int *d_dbg;                // opal_pop_debug_misses
     // Every particle uploaded so far carries the same weight w0 (a uniform plasma loaded with a fixed number per
     // cell): the pushes then take it from their arguments instead of streaming 8 bytes per particle.  Arrivals

@@ -108,9 +108,9 @@ struct PushArgs {
     unsigned send_nextra;  // extras carried behind the 6 base fields (0 for a plain link)
     unsigned *emit_list;   // EXTRAS == 2: slots whose optical depth ran out in this push (count in ctr->n_emit)
     // chunk table of the last re-binning (see opal_pop): workgroups [0, n_tab) take tab_slot[b] .. tab_slot[b+1],
-    // the rest uniform chunks of BLOCK x ppt slots from n_sorted on.  n_tab = 0: uniform chunks throughout.
+    // the rest uniform chunks of BLOCK x ppt slots from ctr->n_sorted on.  n_tab = 0: uniform chunks throughout.
     const unsigned *tab_slot;
-    unsigned n_tab, n_sorted;
+    unsigned n_tab;
     int tail_sides;  // 2: the chunks behind the sorted slots are each taken by two workgroups (see push_body)
     int w_uniform;  // every slot's weight is w0 unless ctr->w_mixed says otherwise (opal_pop::w_uniform)
     double w0;
@@ -408,7 +408,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     } else {
         const unsigned n = a.ctr->n_slots;
         const unsigned tb = block - a.n_tab;
-        chunk0 = (size_t)a.n_sorted + (size_t)(a.tail_sides == 2 ? tb >> 1 : tb) * BLOCK * a.ppt;
+        chunk0 = (size_t)a.ctr->n_sorted + (size_t)(a.tail_sides == 2 ? tb >> 1 : tb) * BLOCK * a.ppt;
         if (chunk0 >= n) return;
         nloc = (unsigned)min((size_t)BLOCK * a.ppt, (size_t)n - chunk0);
         if (OPAL_TWO_SIDED_TAIL && a.tail_sides == 2) my_half = (int)(tb & 1u);
@@ -983,13 +983,26 @@ __device__ inline unsigned b2_at(const unsigned *cell_end, int ncells, unsigned 
 {
     return cell_end[min((int)(CHUNK_CELLS * j), ncells) - 1];
 }
-__global__ void k_chunk_table(const unsigned *__restrict__ cell_end, int ncells, unsigned chunk, unsigned N, unsigned K1,
-                              unsigned K2, unsigned *__restrict__ tab)
+// N, K1: read from the device (ctr->n_live).  The host sizes the table and the launch with K1_ub >= K1 from its upper
+// bound of the slot count (a re-binning need not wait for the device to tell it the true one): the K1_ub - K1 entries
+// behind the merged list are set to N -- empty chunks, whose workgroups leave at once.
+__global__ void k_chunk_table(const unsigned *__restrict__ cell_end, int ncells, unsigned chunk, const PopCounters *ctr,
+                              unsigned K1_ub, unsigned K2, unsigned *__restrict__ tab)
 {
+    const unsigned N = ctr->n_live;
+    const unsigned K1 = (N + chunk - 1) / chunk;
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) tab[0] = 0;
-    if (t < K1) {
+    if (N == 0) {
+        if (t < K1_ub + K2) tab[t + 1] = 0;
+        return;
+    }
+    if (t < K1_ub) {
         const unsigned k = t + 1;
+        if (k > K1) {
+            tab[k + K2] = N;
+            return;
+        }
         const unsigned b = k == K1 ? N : k * chunk;
         unsigned lo = 1, hi = K2 + 1;  // number of j in [1, K2] with B2_j < b: B2 is non-decreasing in j
         while (lo < hi) {
@@ -997,21 +1010,13 @@ __global__ void k_chunk_table(const unsigned *__restrict__ cell_end, int ncells,
             if (b2_at(cell_end, ncells, mid) < b) lo = mid + 1; else hi = mid;
         }
         tab[k + (lo - 1)] = b;
-    } else if (t < K1 + K2) {
-        const unsigned j = t - K1 + 1;
+    } else if (t < K1_ub + K2) {
+        const unsigned j = t - K1_ub + 1;
         const unsigned b = b2_at(cell_end, ncells, j);
         const unsigned before = min(K1 - 1, b / chunk) + (b >= N ? 1u : 0u);  // number of k with B1_k <= b
         tab[j + before] = b;
     }
 }
-// the policy's view of the counters (maybe_sort): the 16 words of up to four populations into mapped host memory, each
-// followed by the sequence number the host waits for
-struct PublishBatch {
-    const PopCounters *src[4];
-    PubCounters *dst[4];
-    unsigned seq[4];
-    int n;
-};
 __global__ void k_publish_counters(PublishBatch b)
 {
     static_assert(sizeof(PopCounters) == 64, "one word per lane below");
@@ -1024,6 +1029,7 @@ __global__ void k_publish_counters(PublishBatch b)
 __global__ void k_sort_finish(PopCounters *ctr)
 {
     ctr->n_slots = ctr->n_live;
+    ctr->n_sorted = ctr->n_live;
     ctr->n_slow = 0;
     ctr->n_slow_pass = 0;
     ctr->n_dead = 0;
@@ -1145,17 +1151,6 @@ struct UnpackBatch {
 };
 
 __device__ void unpack_one(const UnpackArgs &a, int side);
-
-__device__ inline void publish_counters(const PublishBatch &b)
-{
-    static_assert(sizeof(PopCounters) == 64, "one word per lane below");
-    const int e = threadIdx.x >> 4, w = threadIdx.x & 15;
-    if (threadIdx.x < 64) {
-        if (e < b.n) reinterpret_cast<volatile unsigned *>(&b.dst[e]->c)[w] = reinterpret_cast<const unsigned *>(b.src[e])[w];
-        __threadfence_system();
-        if (e < b.n && w == 0) b.dst[e]->seq = b.seq[e];
-    }
-}
 
 template <int NT, bool ADV>
 __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
@@ -1473,6 +1468,8 @@ void launch_push(const PushArgs &a, unsigned nblk, int extras, hipStream_t s)
 int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mode, PushArgs &a, unsigned &nblk)
 {
     memset(&a, 0, sizeof a);
+    if (p->upper_pending)  // (a counter snapshot on its way: the slot count a re-binning left, for one)
+        if (int rc = opal::pop_tighten_upper(p)) return rc;
     int k = p->cur;
     a.cell = p->d_cell[k]; a.x = p->d_x[k]; a.ux = p->d_ux[k]; a.uy = p->d_uy[k]; a.uz = p->d_uz[k]; a.w = p->d_w[k];
     a.prev_x = (mode == MODE_ADVANCE && !p->keep_prev) ? nullptr : p->d_prev_x;
@@ -1522,7 +1519,6 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     a.dbg = p->d_dbg;
     a.tab_slot = p->d_tab_slot;
     a.n_tab = p->n_tab;
-    a.n_sorted = p->n_sorted;
     const size_t behind = p->n_upper > p->n_sorted ? p->n_upper - p->n_sorted : 0;  // appended since the re-binning
     // arrivals from both neighbours behind a sorted population: two workgroups per chunk of them (push_body)
     // (safe while no arrival can have reached the middle of the subdomain: less than a cell per step since the last
@@ -1550,6 +1546,7 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     PushArgs a;
     unsigned nblk;
     if (int rc = build_args(p, link, g, dt, mode, a, nblk)) return rc;
+    if (p->n_upper == 0 || nblk == 0) return OPAL_OK;  // (a counter snapshot that landed in build_args: every slot has been vacated)
     if (mode != MODE_DEPOSIT) p->sorted_exact = false;
     if (mode != MODE_DEPOSIT) p->cold_yz = false;  // only the paired electrostatic launch keeps that promise
     if (p->species == OPAL_ELECTRON && p->extras == 2 && p->d_ex[EX_TAU] && mode != MODE_DEPOSIT) {
@@ -1681,7 +1678,7 @@ int run_push_pair(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t
     return OPAL_OK;
 }
 
-int do_sort(opal_pop_t *p, const opal_grid_t *g);
+int do_sort(opal_pop_t *p, const opal_grid_t *g, bool wait = true);
 
 // room for a step's arrivals and the kernel arguments that append them to one population
 int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, UnpackArgs &u)
@@ -1846,9 +1843,18 @@ int advance_with_exchange(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, doub
     return unpack_arrivals(&p, 1, link, g, true);
 }
 
-int do_sort(opal_pop_t *p, const opal_grid_t *g)
+// Re-binning: counting sort by cell into the spare set of arrays, the chunk table rebuilt.
+// wait = true: the host waits for the device and comes back knowing the slot count, the cell map and the chunk table
+// (callers that need them: explicit opal_pop_sort, compaction for room, the overlapped step's edge / bulk split).
+// wait = false (the policy's re-binnings): nothing is read back here.  The host keeps its upper bound of the slots in
+// use and sizes the chunk table and the launches with it; the pushes take the number of sorted slots from the device
+// (ctr->n_sorted); the true count arrives with a counter snapshot a step or two later (pop_tighten_upper).  A
+// re-binning then costs its kernels and no bubble (measured in the laser-plasma interaction: 0.1-0.2 ms of idle device
+// per re-binning, 140 re-binnings per 2000 steps).
+int do_sort(opal_pop_t *p, const opal_grid_t *g, bool wait)
 {
     if (p->n_upper == 0) return OPAL_OK;
+    if (p->want_host_maps) wait = true;
     if (!p->have_alt) {
         if (int rc = alloc_set(p, p->cur ^ 1)) return rc;
         p->have_alt = true;
@@ -1887,7 +1893,8 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     k_sort_finish<<<1, 1, 0, p->stream>>>(p->d_ctr);
     prof_end(KERNEL_SORT, p->stream);
     OPAL_HIP(hipGetLastError());
-    if (int rc = fetch_counters(p)) return rc;
+    if (wait)
+        if (int rc = fetch_counters(p)) return rc;
     if (d_prev_alt) {
         hipFree(p->d_prev_x);
         p->d_prev_x = d_prev_alt;
@@ -1895,24 +1902,37 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
     for (int q = 0; q < NEX; q++)
         if (sa.oex[q]) std::swap(p->d_ex[q], p->d_ex_alt[q]);
     p->cur = o;
-    p->n_upper = p->h_ctr->n_slots;
-    // after the scatter the cursor of cell c stands one past its last particle: the host keeps that map
-    if (p->n_cell_end != ncells) {
-        free(p->h_cell_end);
-        p->h_cell_end = (unsigned *)malloc(sizeof(unsigned) * ncells);
-        p->n_cell_end = p->h_cell_end ? ncells : 0;
-    }
-    if (p->h_cell_end) OPAL_HIP(hipMemcpy(p->h_cell_end, p->d_count, sizeof(unsigned) * ncells, hipMemcpyDeviceToHost));
+    p->count_cells = (unsigned)ncells;
     if (p->upper_pending) {  // a snapshot from before the compaction: no longer a bound worth having
         hipEventSynchronize(p->upper_event);
         p->upper_pending = false;
     }
+    p->sorted_count_pending = false;
+    if (wait) {
+        p->n_upper = p->h_ctr->n_slots;
+        // after the scatter the cursor of cell c stands one past its last particle: the host keeps that map
+        if (p->n_cell_end != ncells) {
+            free(p->h_cell_end);
+            p->h_cell_end = (unsigned *)malloc(sizeof(unsigned) * ncells);
+            p->n_cell_end = p->h_cell_end ? ncells : 0;
+        }
+        if (p->h_cell_end) OPAL_HIP(hipMemcpy(p->h_cell_end, p->d_count, sizeof(unsigned) * ncells, hipMemcpyDeviceToHost));
+    } else {
+        p->n_cell_end = 0;  // the host's cell map is of the previous order
+    }
+    // the next interval: end it ahead of the misses if the last one met a wall of them (policy_step)
+    p->preempt_at = 0;
+    if (p->sort_interval < 0 && p->last_onset > 0 && (p->last_trigger - p->last_onset) * 3 <= p->last_trigger)
+        p->preempt_at = std::max(4, p->last_onset - 1);
+    p->miss_onset = 0;
+    p->last_onset = p->last_trigger = 0;
     p->steps_since_sort = 0;
     p->emit_list_valid = false;  // slots moved
     p->sorted_exact = true;
     p->dead_cost = 0.0;
     p->ctr_pending = false;  // (a publication still on its way carries an older sequence number and is never read)
     // the chunk table: slot ranges of the push workgroups, cut every BLOCK x pop_max_ppt slots and every CHUNK_CELLS cells
+    // (sized with the host's bound of the slot count; the kernel reads the true one: see k_chunk_table)
     {
         const unsigned N = (unsigned)p->n_upper, chunk = BLOCK * pop_max_ppt(p);
         const unsigned K1 = (N + chunk - 1) / chunk, K2 = (unsigned)((ncells + CHUNK_CELLS - 1) / CHUNK_CELLS);
@@ -1926,20 +1946,30 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g)
             p->h_tab_slot = (unsigned *)malloc(sizeof(unsigned) * p->tab_cap);
         }
         if (M) {
-            k_chunk_table<<<(M + 255) / 256, 256, 0, p->stream>>>(p->d_count, (int)ncells, chunk, N, K1, K2, p->d_tab_slot);
+            k_chunk_table<<<(M + 255) / 256, 256, 0, p->stream>>>(p->d_count, (int)ncells, chunk, p->d_ctr, K1, K2, p->d_tab_slot);
             OPAL_HIP(hipGetLastError());
-            if (p->h_tab_slot)
-                OPAL_HIP(hipMemcpyAsync(p->h_tab_slot, p->d_tab_slot, sizeof(unsigned) * (M + 1), hipMemcpyDeviceToHost, p->stream));
-            OPAL_HIP(hipStreamSynchronize(p->stream));
+            if (wait) {
+                if (p->h_tab_slot)
+                    OPAL_HIP(hipMemcpyAsync(p->h_tab_slot, p->d_tab_slot, sizeof(unsigned) * (M + 1), hipMemcpyDeviceToHost, p->stream));
+                OPAL_HIP(hipStreamSynchronize(p->stream));
+            }
         }
         p->n_tab = M;
-        p->n_sorted = N;
+        p->n_sorted = wait ? N : 0;  // (a lower bound until the count arrives)
     }
-    // uniform chunks (slots appended behind the table): at most about a quarter of the tile
-    unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
-    double per_cell = (double)p->h_ctr->n_live / ne;
-    int ppt = (int)((TILE / 4) * per_cell / BLOCK);
-    p->ppt = std::max(1, std::min(pop_max_ppt(p), ppt));
+    if (wait) {
+        // uniform chunks (slots appended behind the table): at most about a quarter of the tile
+        unsigned ne = std::max(1u, p->h_ctr->n_nonempty);
+        double per_cell = (double)p->h_ctr->n_live / ne;
+        int ppt = (int)((TILE / 4) * per_cell / BLOCK);
+        p->ppt = std::max(1, std::min(pop_max_ppt(p), ppt));
+    } else {
+        p->ppt = std::max(1, std::min(pop_max_ppt(p), p->ppt));
+        // the slot count the re-binning left, on its way to the host: it is both the new bound of the slots in use and
+        // the number of sorted slots
+        if (int rc = opal::pop_snapshot_upper(p, 0)) return rc;
+        p->sorted_count_pending = true;
+    }
     return OPAL_OK;
 }
 
@@ -2044,6 +2074,23 @@ int policy_step(opal_pop_t *p, bool &sort_now)
 #define OPAL_MISS_NS 100.0
 #endif
     constexpr double miss_ns = OPAL_MISS_NS, pass_ns = OPAL_PASS_NS;
+    // Ahead of the misses.  Where they come as a wall -- a relativistic bunch outrunning its tiles, a dense ion front:
+    // nothing for N steps, then thousands per step within three or four -- waiting for their cost to add up to a
+    // re-binning's means paying both, and the counters the host sees are two to four steps old besides (the ion front of
+    // the laser-plasma run took the push from 0.26 to 0.67 ms before the re-binning came).  If the previous interval
+    // showed such a wall (the misses cost a re-binning within a third of the interval after they began), this interval
+    // ends one step before the wall is due; an interval that ends without a miss seen moves the date two steps out.
+    if (p->preempt_at > 0 && p->steps_since_sort >= p->preempt_at) {
+        if (p->miss_onset == 0) {  // nothing seen yet: the wall may have moved further away -- probe later next time
+            p->last_onset = p->preempt_at + 3;
+            p->last_trigger = p->last_onset + 1;
+        } else {
+            p->last_onset = p->miss_onset;
+            p->last_trigger = p->steps_since_sort;
+        }
+        sort_now = true;
+        return OPAL_OK;
+    }
     if (p->steps_since_sort % check_every != 0) return OPAL_OK;
     // The counters are published to mapped host memory by a one-wave kernel and read at the NEXT check, check_every
     // steps later: waiting for that older publication keeps the host at most ~2 check intervals ahead of the device
@@ -2061,7 +2108,8 @@ int policy_step(opal_pop_t *p, bool &sort_now)
     if (int rc = ask_publication(p)) return rc;
     if (!fresh) return OPAL_OK;
     const PopCounters seen = p->h_ctr_seen;  // snapshot taken when the copy was found complete
-    double sort_ms = 0.06 * (double)seen.n_slots * 1e-6 + 0.05;  // ~100 B per particle at ~2 TB/s + launches
+    // (a re-binning: ~100 B per particle at 3.6 TB/s -- 0.277 ms per 1e7 measured -- plus its launches and the host's part)
+    double sort_ms = 0.028 * (double)seen.n_slots * 1e-6 + 0.05;
     if (p->species == OPAL_PHOTON && !p->extras) {
         // The field-free photon push has no tile to miss: order does not matter to it.  What a re-binning buys
         // is the slots that photons vacated at the open edges (or by migrating): each is still streamed, 36 B
@@ -2076,7 +2124,13 @@ int policy_step(opal_pop_t *p, bool &sort_now)
         return OPAL_OK;
     }
     double lost_ms = ((double)seen.n_slow_pass * pass_ns + (double)seen.n_slow * miss_ns) * 1e-6;
+    // (the counters seen were published a check ago, at steps_since_sort - check_every)
+    if (seen.n_slow && p->miss_onset == 0) p->miss_onset = std::max(1, p->steps_since_sort - check_every);
     sort_now = lost_ms > sort_ms;
+    if (sort_now) {
+        p->last_onset = p->miss_onset ? p->miss_onset : p->steps_since_sort;
+        p->last_trigger = p->steps_since_sort;
+    }
     return OPAL_OK;
 }
 
@@ -2084,7 +2138,7 @@ int maybe_sort(opal_pop_t *p, const opal_grid_t *g)
 {
     bool sort_now;
     if (int rc = policy_step(p, sort_now)) return rc;
-    return sort_now ? do_sort(p, g) : OPAL_OK;
+    return sort_now ? do_sort(p, g, false) : OPAL_OK;
 }
 
 }  // namespace
@@ -2195,6 +2249,9 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
         hipEventSynchronize(p->upper_event);
         p->upper_pending = false;
     }
+    p->sorted_count_pending = false;
+    p->count_cells = 0;
+    p->miss_onset = p->last_onset = p->last_trigger = p->preempt_at = 0;
     p->added_since_snapshot = 0;
     p->steps_since_sort = 0;
     p->emit_list_valid = false;
@@ -2630,6 +2687,31 @@ int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link,
     return run_push_pair(pe, pi, link, g, dt, edges ? PART_EDGES : PART_BULK, MODE_FUSED, on);
 }
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g) { return maybe_sort(p, g); }
+// The policy's step for a step's species, leaving the re-binnings it decides on to the caller (pops_sort_decided) and
+// the publication of the counters to a kernel the caller is about to launch anyway (grid_sync_advance): `pub` comes
+// back with n = 0 if nothing is due (or if the batch went out by a launch of its own: populations on other streams).
+int pops_policy(opal_pop_t *const *pops, int npops, PublishBatch *pub, bool *sort_now)
+{
+    memset(pub, 0, sizeof *pub);
+    PublishScope scope;
+    for (int i = 0; i < npops; i++) {
+        sort_now[i] = false;
+        if (pops[i])
+            if (int rc = policy_step(pops[i], sort_now[i])) return rc;
+    }
+    if (scope.b.n && pops[0] && scope.stream == pops[0]->stream) {
+        *pub = scope.b;
+        scope.b.n = 0;
+    }
+    return OPAL_OK;
+}
+int pops_sort_decided(opal_pop_t *const *pops, int npops, const bool *sort_now, const opal_grid_t *g)
+{
+    for (int i = 0; i < npops; i++)
+        if (pops[i] && sort_now[i])
+            if (int rc = do_sort(pops[i], g, false)) return rc;
+    return OPAL_OK;
+}
 // the re-binning bookkeeping of a step's species together (their counters are published in one launch)
 int pops_maybe_sort(opal_pop_t *const *pops, int npops, const opal_grid_t *g)
 {
@@ -2643,7 +2725,7 @@ int pops_maybe_sort(opal_pop_t *const *pops, int npops, const opal_grid_t *g)
 // p->d_count[c] = one past the last slot of cell c
 int pop_sort_exact(opal_pop_t *p, const opal_grid_t *g)
 {
-    if (p->sorted_exact && p->d_count && p->n_cell_end == g->size) return OPAL_OK;  // nothing has moved since
+    if (p->sorted_exact && p->d_count && p->count_cells == g->size) return OPAL_OK;  // nothing has moved since
     return do_sort(p, g);
 }
 // The host's bound on the slots in use (n_upper) when particles are appended by the device without the host
@@ -2658,6 +2740,10 @@ int pop_tighten_upper(opal_pop_t *p)
     p->upper_pending = false;
     size_t bound = (size_t)*p->h_upper + p->added_since_snapshot;
     if (bound < p->n_upper) p->n_upper = bound;
+    if (p->sorted_count_pending) {  // the count a re-binning left (do_sort, wait = false)
+        p->n_sorted = *p->h_upper;
+        p->sorted_count_pending = false;
+    }
     return OPAL_OK;
 }
 int pop_snapshot_upper(opal_pop_t *p, size_t just_added)
@@ -2711,7 +2797,7 @@ int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *
     if (int rc = unpack_arrivals(pops, npops, link, g, true, sync, adv, peer_exchange, &pub)) return rc;
     for (int i = 0; i < npops && i < 4; i++)
         if (pops[i] && sort_now[i])
-            if (int rc = do_sort(pops[i], g)) return rc;
+            if (int rc = do_sort(pops[i], g, false)) return rc;
     return OPAL_OK;
 }
 }

@@ -30,6 +30,8 @@ int pops_unpack(opal_pop_t *const *pops, int npops, opal_link_t *link, const opa
 int pops_push_fused_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt);
 int pop_maybe_sort(opal_pop_t *p, const opal_grid_t *g);
 int pops_maybe_sort(opal_pop_t *const *pops, int npops, const opal_grid_t *g);
+int pops_policy(opal_pop_t *const *pops, int npops, PublishBatch *pub, bool *sort_now);
+int pops_sort_decided(opal_pop_t *const *pops, int npops, const bool *sort_now, const opal_grid_t *g);
 int pops_advance_pair_noexchange(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt);
 int pops_deposit_pair(opal_pop_t *pe, opal_pop_t *pi, opal_grid_t *g, double dt);
 int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const double **recv_left, const double **recv_right,
@@ -742,6 +744,9 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             s->step_index++;
             continue;
         }
+        opal_pop_t *both[2] = {s->electrons, s->ions};
+        PublishBatch pub{};
+        bool sort_now[2] = {false, false}, deferred = false;
         // With photon emission on, the reference's order is advance -> emit -> deposit (main.rs:240-258) and
         // the deposit's transverse currents use the velocity after the recoil, so the fused push+deposit
         // pass does not apply: the separate operators run in the reference's order.
@@ -751,8 +756,9 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             if (s->electrons && s->ions && !linked) {
                 // both species in one launch, then the re-binning bookkeeping of each
                 if (int rc = pops_push_fused_pair_noexchange(s->electrons, s->ions, nullptr, s->grid, s->dt)) return rc;
-                opal_pop_t *both[2] = {s->electrons, s->ions};
-                if (int rc = pops_maybe_sort(both, 2, s->grid)) return rc;
+                // (the policy's counters are published by the field solve's launch below; re-binnings follow it)
+                if (int rc = pops_policy(both, 2, &pub, sort_now)) return rc;
+                deferred = true;
             } else {
                 if (s->electrons)
                     if (int rc = opal_pop_advance_deposit(s->electrons, s->link, s->grid, s->dt)) return rc;
@@ -764,7 +770,6 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             const bool pair = !linked && s->electrons && s->ions && !qed && s->current_deposition;
             if (pair) {
                 if (int rc = pops_advance_pair_noexchange(s->electrons, s->ions, s->grid, s->dt)) return rc;
-                opal_pop_t *both[2] = {s->electrons, s->ions};
                 if (int rc = pops_maybe_sort(both, 2, s->grid)) return rc;
             } else {
                 if (s->electrons) {
@@ -811,7 +816,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             // a lone subdomain: synchronize and the field solve in one launch
             double ly, lz;
             laser_now(ly, lz);
-            if (int rc = grid_sync_advance(s->grid, nullptr, nullptr, ly, lz, s->dt)) return rc;
+            if (int rc = grid_sync_advance(s->grid, nullptr, nullptr, ly, lz, s->dt, &pub)) return rc;
+            pub.n = 0;
         } else {
             if (s->has_laser) {
                 if (int rc = opal_grid_synchronize(s->grid, s->link, laser_y_cb, laser_z_cb, &lp, s->t, s->dt)) return rc;
@@ -820,6 +826,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
             if (int rc = opal_grid_advance(s->grid, s->dt)) return rc;
         }
+        if (deferred)
+            if (int rc = pops_sort_decided(both, 2, sort_now, s->grid)) return rc;
         s->t += s->dt;
     }
     return OPAL_OK;
@@ -992,6 +1000,10 @@ int opal_sim_set_overlap(opal_sim_t *s, int on)
 {
     if (!s) return OPAL_ERR_ARG;
     s->overlap = on != 0;
+    // the edge / bulk split of an overlapped step reads the host's copies of the cell map and the chunk table: the
+    // re-binnings of these populations then wait for the device (particles.hip: do_sort)
+    for (opal_pop_t *p : {s->electrons, s->ions})
+        if (p) p->want_host_maps = s->overlap;
     return OPAL_OK;
 }
 size_t opal_sim_overlapped_steps(const opal_sim_t *s) { return s ? s->n_overlapped : 0; }
