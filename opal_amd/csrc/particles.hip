@@ -879,39 +879,70 @@ __global__ __launch_bounds__(256) void k_sort_hist(const int *__restrict__ cell,
     if (threadIdx.x < SORT_W && s_cnt[threadIdx.x]) atomicAdd(&count[wbase + threadIdx.x], s_cnt[threadIdx.x]);
 }
 
-// exclusive scan of count[0..ncells) in place, one workgroup; also the live total and non-empty cell count
-__global__ void k_sort_scan(unsigned *count, int ncells, PopCounters *ctr)
+// exclusive scan of count[0..ncells) in place, one workgroup of 1024; also the live total and non-empty cell count.
+// Every thread owns a contiguous run of cells (values kept in registers when the run is short), the runs' sums are
+// scanned across the workgroup with wave shuffles and one round through LDS.
+__global__ __launch_bounds__(1024) void k_sort_scan(unsigned *count, int ncells, PopCounters *ctr)
 {
-    __shared__ unsigned s_sum[1024];
-    __shared__ unsigned s_ne[1024];
-    int t = threadIdx.x, nt = blockDim.x;
-    int per = (ncells + nt - 1) / nt;
-    int lo = t * per, hi = min(lo + per, ncells);
+    __shared__ unsigned s_wave[16], s_wave_ne[16];
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
+    const int per = (ncells + nt - 1) / nt;
+    const int lo = t * per, hi = min(lo + per, ncells);
+    constexpr int KEEP = 32;  // cells per thread held in registers (20 000 cells / 1024 threads = 20)
+    unsigned v[KEEP];
     unsigned sum = 0, ne = 0;
-    for (int i = lo; i < hi; i++) {
-        sum += count[i];
-        ne += count[i] != 0;
-    }
-    s_sum[t] = sum;
-    s_ne[t] = ne;
-    __syncthreads();
-    if (t == 0) {
-        unsigned run = 0, rne = 0;
-        for (int k = 0; k < nt; k++) {
-            unsigned v = s_sum[k];
-            s_sum[k] = run;
-            run += v;
-            rne += s_ne[k];
+    if (per <= KEEP) {
+#pragma unroll
+        for (int q = 0; q < KEEP; q++) {
+            v[q] = (q < per && lo + q < hi) ? count[lo + q] : 0u;
+            sum += v[q];
+            ne += v[q] != 0;
         }
-        ctr->n_live = run;
-        ctr->n_nonempty = rne;
+    } else {
+        for (int i = lo; i < hi; i++) {
+            sum += count[i];
+            ne += count[i] != 0;
+        }
+    }
+    // inclusive scan of (sum, ne) over the workgroup
+    unsigned inc = sum, inc_ne = ne;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned a = __shfl_up(inc, o), b = __shfl_up(inc_ne, o);
+        if (lane >= o) {
+            inc += a;
+            inc_ne += b;
+        }
+    }
+    if (lane == 63) {
+        s_wave[wave] = inc;
+        s_wave_ne[wave] = inc_ne;
     }
     __syncthreads();
-    unsigned run = s_sum[t];
-    for (int i = lo; i < hi; i++) {
-        unsigned v = count[i];
-        count[i] = run;
-        run += v;
+    unsigned before = 0, total = 0, total_ne = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) before += s_wave[w];
+        total += s_wave[w];
+        total_ne += s_wave_ne[w];
+    }
+    if (t == 0) {
+        ctr->n_live = total;
+        ctr->n_nonempty = total_ne;
+    }
+    unsigned run = before + inc - sum;  // exclusive prefix of this thread's run
+    if (per <= KEEP) {
+#pragma unroll
+        for (int q = 0; q < KEEP; q++) {
+            if (q < per && lo + q < hi) count[lo + q] = run;
+            run += v[q];
+        }
+    } else {
+        for (int i = lo; i < hi; i++) {
+            unsigned c = count[i];
+            count[i] = run;
+            run += c;
+        }
     }
 }
 
