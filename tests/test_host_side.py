@@ -235,17 +235,25 @@ def test_output_spec_file_names(oa):
 
 
 def test_committed_traffic_figures_point_at_committed_profiles():
-    """bench.py's roofline.traffic comes from profiles/traffic.json (a separate rocprofv3 --pmc run): every entry must
-    name a committed PMC summary that holds the same bytes-per-update figure."""
+    """bench.py's roofline.traffic comes from profiles/traffic.json (separate rocprofv3 --pmc passes of the bench
+    command, scripts/profile_bench.sh + summarise_profile.py): every entry is keyed by the workload and the kernel
+    instantiation it was measured on, names a committed PMC summary that holds the same bytes-per-update figure, and
+    carries the hash of the kernel sources it was taken with (bench.py reports an entry only while that hash is current)."""
     import json
+    import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
-    assert "two_stream" in t and "two_stream_no_elision" in t
+    head = "two_stream:32768x1526|"
+    assert head + "k_push_pair<1, true, false>" in t and head + "k_push_pair<1, false, true>" in t
     for key, entry in t.items():
+        workload, kernel = key.split("|")
+        assert re.fullmatch(r"k_push(_pair)?<[^>]*>", kernel), key
         src = os.path.join(root, entry["source"])
         assert os.path.exists(src), (key, entry["source"])
         pmc = json.load(open(src))
-        assert abs(pmc["hbm_bytes_per_particle_update"] - entry["hbm_bytes_per_particle_update"]) < 1e-9
+        assert pmc["workload_key"] == workload and pmc["kernel_src_sha"] == entry["src_sha"]
+        assert abs(pmc["kernels"][kernel]["hbm_bytes_per_particle_update"] - entry["hbm_bytes_per_particle_update"]) < 1e-9
         assert 8.0 < entry["hbm_bytes_per_particle_update"] < 90.0
     # the electrostatic launch moves less than the general kernel, which moves less than the survey's 80 B
-    assert t["two_stream"]["hbm_bytes_per_particle_update"] < t["two_stream_no_elision"]["hbm_bytes_per_particle_update"] < 80.0
+    assert t[head + "k_push_pair<1, false, true>"]["hbm_bytes_per_particle_update"] < \
+        t[head + "k_push_pair<1, true, false>"]["hbm_bytes_per_particle_update"] < 80.0
