@@ -421,59 +421,26 @@ def main():
         # up to npc = 2441 (an overflow is reported as an error, never silent)
         link_capacity = max(1024, npc // 2)
 
-    def make_link(r, w, device):
-        """Neighbour transport over RCCL: native (the library issues the send/recv itself on the simulation's
-        stream) unless OPAL_BENCH_LINK=torch asks for the torch.distributed callback."""
-        from opal_amd.exchange import PeerLink, RcclLink, TorchLink
-        nonlocal link_kind
-        if link_kind == "peer":
-            # mailboxes in the neighbours' device memory, written by the step's own kernels; checked once with a few
-            # halo exchanges on every subdomain -- if they do not all come through (no peer access between two GPUs),
-            # every subdomain falls back to RCCL together
-            lp_open = args.workload == "laser_plasma"
-            try:
-                lk = PeerLink(r, w, device, particle_capacity=link_capacity, stream=torch.cuda.current_stream().cuda_stream)
-                if lk.self_test(to_left=not (lp_open and r == 0), to_right=not (lp_open and r == w - 1)):
-                    return lk
-                print("[bench] peer link self-test failed; using RCCL", file=sys.stderr)
-            except Exception as e:
-                print(f"[bench] peer link unavailable ({e}); using RCCL", file=sys.stderr)
-            link_kind = "rccl"
-        if link_kind == "rccl":
-            try:
-                lk = RcclLink(r, w, device, particle_capacity=link_capacity)
-                if os.environ.get("OPAL_BENCH_FIXED"):  # diagnostic: ship all slots every step
-                    lk.set_bounded(False)
-                return lk
-            except Exception as e:  # e.g. no librccl to open: the torch.distributed transport does the same job
-                print(f"[bench] native RCCL link unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
-                link_kind = "torch"
-        return TorchLink(r, w, device, particle_capacity=link_capacity)
-
     dist = None
     link = None
     if world > 1 or args.self_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
+        lp_open = args.workload == "laser_plasma"
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-            link = make_link(rank, world, torch.device("cuda", dev_index))
+            link_device = torch.device("cuda", dev_index)
         else:
-            from opal_amd.exchange import PeerLink, TorchLink
             dist.init_process_group(backend, rank=rank, world_size=world)
-            if link_kind == "peer":
-                lp_open = args.workload == "laser_plasma"
-                try:
-                    link = PeerLink(rank, world, particle_capacity=link_capacity, stream=torch.cuda.current_stream().cuda_stream)
-                    if not link.self_test(to_left=not (lp_open and rank == 0), to_right=not (lp_open and rank == world - 1)):
-                        link = None
-                except Exception as e:
-                    print(f"[bench] peer link unavailable ({e}); using host-staged gloo messages", file=sys.stderr)
-                    link = None
-            if link is None:
-                link_kind = "gloo"
-                link = TorchLink(rank, world, torch.device("cpu"), particle_capacity=link_capacity)
+            link_device = torch.device("cpu")
+        from opal_amd.exchange import make_link
+        order = {"peer": ("peer", "rccl", "torch"), "rccl": ("rccl", "torch"), "torch": ("torch",), "gloo": ("torch",)}[link_kind]
+        link, link_kind = make_link(rank, world, link_device, link_capacity, stream=torch.cuda.current_stream().cuda_stream,
+                                    to_left=not (lp_open and rank == 0), to_right=not (lp_open and rank == world - 1),
+                                    prefer=order, log=lambda m: print(m.replace("[opal_amd]", "[bench]"), file=sys.stderr))
+        if link_kind == "rccl" and os.environ.get("OPAL_BENCH_FIXED"):  # diagnostic: ship all slots every step
+            link.set_bounded(False)
     red_dev = "cuda" if backend == "nccl" else "cpu"
     rccl_ranks = None
     if link is not None and hasattr(link, "rccl_ranks"):

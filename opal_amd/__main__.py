@@ -4,8 +4,9 @@
     python -m opal_amd input.yaml                                                   # one GPU
     python -m torch.distributed.run --nproc-per-node 8 -m opal_amd input.yaml       # one subdomain per GPU
 
-One process per GPU; neighbour exchange over RCCL (backend "nccl"); outputs are written next to the input
-file by rank 0, as the reference does (main.rs:60-61)."""
+One process per GPU; the subdomains exchange through peer-mapped mailboxes over xGMI (or RCCL where the GPUs cannot
+address each other; OPAL_LINK=peer|rccl|torch forces one); outputs are written next to the input file by rank 0, as the
+reference does (main.rs:60-61)."""
 import os
 import sys
 
@@ -13,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 import opal_amd as oa
-from opal_amd.exchange import RcclLink, TorchLink
+from opal_amd.exchange import make_link
 
 
 def main(argv):
@@ -36,12 +37,14 @@ def main(argv):
         # error); what travels each step is sized to the particles within 3 cells of each cut, not to this
         cap = int(os.environ.get("OPAL_LINK_CAPACITY", "65536"))
         stream = torch.cuda.current_stream().cuda_stream
-        if backend == "nccl" and os.environ.get("OPAL_LINK", "rccl") == "rccl":
-            link = RcclLink(rank, world, device, cap, photon_emission=emission, photon_absorption=absorption,
-                            stream=stream)  # native RCCL send/recv
-        else:
-            link = TorchLink(rank, world, device if backend == "nccl" else torch.device("cpu"), cap,
-                             photon_emission=emission, photon_absorption=absorption, stream=stream)
+        open_ends = cfg.contains("laser")  # laser + absorbing boundaries: the first and last subdomain have one neighbour
+        want = os.environ.get("OPAL_LINK")
+        link, kind = make_link(rank, world, device if backend == "nccl" else torch.device("cpu"), cap, stream=stream,
+                               photon_emission=emission, photon_absorption=absorption,
+                               to_left=not (open_ends and rank == 0), to_right=not (open_ends and rank == world - 1),
+                               prefer=(want,) if want else ("peer", "rccl", "torch"))
+        if rank == 0:
+            print(f"Neighbour exchange: {kind}")
     try:
         sim = oa.Simulation(yaml_path=argv[1], rank=rank, numtasks=world, link=link,
                             stream=torch.cuda.current_stream().cuda_stream)

@@ -207,36 +207,41 @@ class PeerLink:
     def __init__(self, rank, world, device=None, particle_capacity=4096, group=None, stream=None, photon_emission=False,
                  photon_absorption=False):
         self._lib = _lib.load()
+        # (what Simulation builds its output-time collectives from: the device the reductions run on and the group)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.transport = NeighbourTransport(rank, world, group)
         slots, fields = (3, 15) if photon_absorption else (3, 12) if photon_emission else (2, 6)
+        # Every step below that can fail locally is followed by an exchange in which all subdomains take part whatever
+        # happened to them: a subdomain that cannot set its mailboxes up must not leave the others waiting for it.
         h = C.c_void_p()
-        rc = self._lib.opal_link_create_peer(C.byref(h), rank, world, particle_capacity, slots, fields, stream)
-        if rc:
-            raise RuntimeError(self._lib.opal_last_error().decode())
-        self.h = h
-        self.nbytes = self._lib.opal_link_message_bytes(h)
+        err = None
         mine = C.create_string_buffer(64)
-        if self._lib.opal_link_peer_export(h, mine):
-            raise RuntimeError(self._lib.opal_last_error().decode())
+        if self._lib.opal_link_create_peer(C.byref(h), rank, world, particle_capacity, slots, fields, stream):
+            err, h = self._lib.opal_last_error().decode(), None
+        elif self._lib.opal_link_peer_export(h, mine):
+            err = self._lib.opal_last_error().decode()
+        self.h = h
         left = right = None
         if world > 1:
             handles = [None] * world
-            dist.all_gather_object(handles, mine.raw, group=group)
-            left = C.create_string_buffer(handles[(rank - 1 + world) % world], 64)
-            right = C.create_string_buffer(handles[(rank + 1) % world], 64)
-        err = None
-        if self._lib.opal_link_peer_connect(h, left, right):
+            dist.all_gather_object(handles, (mine.raw, err), group=group)
+            err = next((f"subdomain {r}: {e}" for r, (_, e) in enumerate(handles) if e), None)
+            left = C.create_string_buffer(handles[(rank - 1 + world) % world][0], 64)
+            right = C.create_string_buffer(handles[(rank + 1) % world][0], 64)
+        if not err and self._lib.opal_link_peer_connect(h, left, right):
             err = self._lib.opal_last_error().decode()
         if world > 1:
             # every mailbox is mapped before anybody's first step writes into one -- and if mapping failed anywhere
-            # (no peer access between two GPUs, say) every subdomain learns it here instead of waiting for a
-            # neighbour that has already given up
+            # (no peer access between two GPUs, say) every subdomain learns it here
             errs = [None] * world
             dist.all_gather_object(errs, err, group=group)
-            err = next((f"subdomain {r}: {e}" for r, e in enumerate(errs) if e), None)
+            err = next((e if e.startswith("subdomain") else f"subdomain {r}: {e}" for r, e in enumerate(errs) if e), None)
         if err:
-            self._lib.opal_link_free(h)
+            if h:
+                self._lib.opal_link_free(h)
             self.h = None
             raise RuntimeError("peer link: " + err)
+        self.nbytes = self._lib.opal_link_message_bytes(h)
         self.world, self.group = world, group
 
     def self_test(self, to_left=True, to_right=True, n=4):
@@ -267,6 +272,57 @@ class PeerLink:
 
     def set_bounded(self, on=True):
         pass  # nothing to plan: a message is as long as the leavers it carries
+
+
+def make_link(rank, world, device, particle_capacity, stream=None, photon_emission=False, photon_absorption=False,
+              to_left=True, to_right=True, prefer=("peer", "rccl", "torch"), log=None):
+    """The neighbour transport of a decomposed run on one node, best first: peer-mapped mailboxes written by the step's
+    own kernels; the library's own RCCL send/recv; torch.distributed P2P.  Collective: every subdomain calls it, and all
+    of them end up with the same kind (a kind is kept only if it came up on EVERY subdomain: the mailboxes are tried
+    with a few halo exchanges first).  Returns (link, kind).  With a CPU `device` (ranks sharing a card in a rehearsal)
+    the fallback is the host-staged torch.distributed link.
+
+    The handles and the yes/no votes travel over a gloo group of their own when the default group is RCCL's."""
+    device = torch.device(device)
+    log = log or (lambda m: print(m, file=sys.stderr))
+    ctl = None
+    if world > 1:
+        ctl = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    kw = dict(particle_capacity=particle_capacity, stream=stream, photon_emission=photon_emission,
+              photon_absorption=photon_absorption)
+
+    def all_ok(ok):
+        if world == 1:
+            return ok
+        votes = [None] * world
+        dist.all_gather_object(votes, bool(ok), group=ctl)
+        return all(votes)
+
+    for kind in prefer:
+        link, err = None, None
+        try:
+            if kind == "peer":
+                link = PeerLink(rank, world, device, group=ctl, **kw)
+                if not link.self_test(to_left=to_left, to_right=to_right):
+                    err, link = "the mailboxes' self-test failed on some subdomain", None
+                else:
+                    link.transport.group = None  # the output-time collectives run on the default group
+            elif kind == "rccl" and device.type == "cuda":
+                link = RcclLink(rank, world, device, **kw)
+            elif kind == "torch" or device.type != "cuda":
+                link = TorchLink(rank, world, device, **kw)
+                kind = "torch" if device.type == "cuda" else "gloo"
+        except Exception as e:  # noqa: BLE001
+            err, link = str(e), None
+        if kind == "peer":
+            pass  # PeerLink's constructor and self_test have already agreed among the subdomains
+        elif not all_ok(link is not None):
+            link = None
+        if link is not None:
+            return link, kind
+        if err and rank == 0:
+            log(f"[opal_amd] {kind} link unavailable ({err}); trying the next transport")
+    raise RuntimeError("no neighbour transport could be set up")
 
 
 class TorchCollectives:
