@@ -17,6 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $
 echo "kernel-trace done"
 SHORT="--steps 5 --warmup 2"
 case " $* " in *" --steps "*) SHORT="";; esac
+echo "$ARGS $SHORT" > $O/args_pmc.txt
 rocprofv3 --kernel-include-regex "k_push" --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py $ARGS $SHORT > /dev/null 2> $O/pmc_f.log
 rocprofv3 --kernel-include-regex "k_push" --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py $ARGS $SHORT > /dev/null 2> $O/pmc_w.log
 echo "hbm done"
