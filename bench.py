@@ -7,25 +7,34 @@ boundary synchronisation, field solve) on synthetic input already resident in HB
 Default workload = north_star's target configuration, BASELINE.json configs[2]: two-stream, 32 768 cells,
 1526 electrons + 1526 positrons per cell (100 007 936 macro-particles), periodic, current deposition on,
 no QED.  N = 1 holds it on one GPU (4.4 GB); N > 1 splits the SAME domain into N subdomains, one per GPU,
-with RCCL neighbour exchange (strong scaling: `value` at N GPUs over `value` at 1 GPU is the speed-up
-north_star asks for).  `--weak` gives every GPU its own `--cells-per-gpu` x `--npc` block instead
-(default configs[1]: 4096 cells, 2441 + 2441 per cell).  At N = 1 the line also carries configs[1] as
-`secondary`, measured the same way in the same process.
+exchanging with their neighbours through peer-mapped mailboxes over xGMI (RCCL where the GPUs cannot address each
+other) -- strong scaling: `value` at N GPUs over `value` at 1 GPU is the speed-up north_star asks for.  `--weak`
+gives every GPU its own `--cells-per-gpu` x `--npc` block instead (default configs[1]: 4096 cells, 2441 + 2441 per
+cell).
+
+What the line's top level measures: the CONTRACT RUN -- the general kernel with every attribute of every particle
+streamed (SURVEY.md 8d's 80 B per update: read cell,x,ux,uy,uz,w; write cell,x,ux,uy,uz) and rho deposited on every
+step, whatever the data would allow to skip.  The library's default path (which, for this electrostatic input, neither
+streams uy/uz nor the uniform weight, and gives the same bits) is measured beside it on the same population as
+`default_path`.  Every `roofline` block is priced with the algorithmic bytes of the kernel FORM that ran in its timed
+region (`bytes_model`; the library reports the form of each launch, opal_prof_forms), so `frac` <= 1 by construction and
+`algorithmic_GBps_over_whole_step` <= 8000.  The kernel's mean duration is measured with HIP events on the
+simulation's stream around a 1-in-5 sample of its launches in the timed region; `traffic` is the PMC-measured HBM bytes
+per launch from profiles/traffic.json, used only if that entry was taken for this workload, this kernel instantiation
+and these kernel sources.  At N = 1 the line also carries configs[1] (`secondary`) and configs[3]'s physics inside the
+laser-plasma interaction (`laser_plasma_interaction`), measured the same way in the same process.
 
 `python bench.py --gpus N` needs no launcher: with WORLD_SIZE unset the parent -- which never touches a
 GPU -- starts N ranks of itself as child processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on
 127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank failed.  Under torch.distributed.run
-the same file is simply one rank.  With fewer GPUs than ranks (a 1-GPU box) the ranks share the card and
-exchange through host buffers (gloo): a rehearsal of the decomposed step, labelled as such in `config`.
+the same file is simply one rank.  With fewer GPUs than ranks (a 1-GPU box) the ranks share the card: a rehearsal of
+the decomposed step, labelled as such in `config`.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused push+deposit pass; one
-launch covers both species): algorithmic bytes = 80 B per particle-update x particles per
-launch, divided by the kernel's mean duration measured with HIP events on the simulation's stream around a
-1-in-5 sample of its launches in the timed region.  `cpu_baseline` times the CPU oracle in its
-reference-algorithm mode (AoS structs, comparison sort every step, per-thread private current arrays +
-serial reduce, serial field solve; a port of the reference's algorithm, not the opal binary) on a bounded
-sample of the workload on this box's host cores, S subdomains x T threads = all physical cores (the
-reference's MPI x Rayon layout), plus the 1 x 1 point for BASELINE configs[0].
+`cpu_baseline` times the CPU oracle in its reference-algorithm mode (AoS structs, the population sorted by cell every
+step with a restatement of rayon's par_sort_unstable_by_key, per-thread private current arrays + serial reduce, serial
+field solve; a port of the reference's algorithm, not the opal binary) on a bounded sample of the workload on this
+box's host cores: S subdomains x T threads = the cores this process may use (affinity AND cgroup quota), the
+reference's MPI x Rayon layout, with the per-phase breakdown; plus the 1 x 1 point for BASELINE configs[0].
 """
 import argparse
 import json
@@ -518,9 +527,6 @@ def main():
     def measure(sim, steps, warmup, preheat=True, workload_key="two_stream"):
         """Pre-heat (untimed, >= PREHEAT_SECONDS of steps so that clocks and caches are those of a running job),
         W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
-        n_e = len(sim.electrons) if sim.electrons is not None else 0
-        n_i = len(sim.ions) if sim.ions is not None else 0
-        n_local = n_e + n_i
         barrier()
         done = 0
         if preheat:
@@ -536,6 +542,10 @@ def main():
                 done += more
         sim.step(warmup)
         sim.sync()
+        # the particles this rank holds NOW (open boundaries delete leavers, subdomains trade them): counted after the
+        # warm-up, and again after the timed steps -- the smaller number is the one the rate is quoted for
+        n_e = len(sim.electrons) if sim.electrons is not None else 0
+        n_i = len(sim.ions) if sim.ions is not None else 0
         oa.prof_reset()
         # HIP events around every 5th launch of each tracked kernel (an odd stride samples both species);
         # timing every launch costs ~10 % of the step because each event record breaks back-to-back dispatch
@@ -547,7 +557,12 @@ def main():
         barrier()
         elapsed = all_max(time.perf_counter() - t0)
         oa.prof_enable(0)
-        n_total = int(all_sum(n_local))
+        n_e_after = len(sim.electrons) if sim.electrons is not None else 0
+        n_i_after = len(sim.ions) if sim.ions is not None else 0
+        n_total = int(min(all_sum(n_e + n_i), all_sum(n_e_after + n_i_after)))
+        if world == 1:
+            n_e, n_i = min(n_e, n_e_after), min(n_i, n_i_after)
+        n_local = n_e + n_i
         kname = "fused" if not args.unfused else "advance"
         launches, total_ms = oa.prof_get(kname)
         sort_launches, sort_ms = oa.prof_get("sort")
@@ -649,6 +664,20 @@ def main():
     half = max(20, args.steps // 2)
     if args.elision == "on":
         m = measure(sim, args.steps, args.warmup, workload_key=wkey)
+        t_end = sim.t
+    elif args.workload == "laser_plasma":
+        # the physics has phases (the warm-up brings the pulse onto the slab): each form gets a simulation of its own,
+        # warmed up to the same time -- the contract run first
+        oa.set_elision(False)
+        m = measure(sim, args.steps, args.warmup, preheat=args.warmup < 1000, workload_key=wkey)
+        t_end = sim.t
+        oa.set_elision(True)
+        if not args.unfused and not args.no_default_path:
+            del sim
+            sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
+            sim.set_fused(True)
+            m_default = measure(sim, args.steps, args.warmup, preheat=args.warmup < 1000, workload_key=wkey)
+            half = args.steps
     else:
         if not args.unfused and not args.no_default_path:
             m_default = measure(sim, half, args.warmup, workload_key=wkey)
@@ -656,7 +685,7 @@ def main():
         if m_default is not None or os.environ.get("OPAL_BENCH_REGROUP"):  # (the latter: a diagnostic)
             regroup(sim)
         m = measure(sim, args.steps, args.warmup, workload_key=wkey)  # (pre-heated again: another kernel, another power state)
-    t_end = sim.t
+        t_end = sim.t
 
     if rank == 0:
         if args.workload == "two_stream":
