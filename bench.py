@@ -485,11 +485,16 @@ def main():
         return float(t.item())
 
     def src_sha():
-        """Hash of the kernel sources the PMC traffic figures were taken with (profiles/traffic.json records it)."""
+        """Hash of the kernel sources the PMC traffic figures were taken with (profiles/traffic.json records it):
+        the code of the push and field kernels with comments and white space taken out."""
         import hashlib
+        import re
         h = hashlib.sha256()
         for f in ("particles.hip", "pic_device.hpp", "grid.hip", "grid_device.hpp"):
-            h.update(open(os.path.join(ROOT, "opal_amd", "csrc", f), "rb").read())
+            text = open(os.path.join(ROOT, "opal_amd", "csrc", f)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+            h.update(re.sub(r"\s+", "", text).encode())
         return h.hexdigest()[:16]
 
     def bytes_model(forms, n_e, n_i, unfused):

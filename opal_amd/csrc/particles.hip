@@ -1157,9 +1157,9 @@ struct UnpackArgs {
     int *es_flag;         // an arrival with transverse momentum ends the electrostatic launches (ctr->hot_yz, grid flag)
 };
 
-// The tail of a linked step, one launch: up to three species' arrivals (blocks 2 s and 2 s + 1 belong to species s), and,
-// in one more workgroup, YeeGrid::synchronize (has_sync) followed by the whole field solve of a small subdomain
-// (has_adv).  With a peer link (peer.enabled) the launch IS the exchange: workgroup 0 first writes this subdomain's two
+// The tail of a linked step, one launch: up to three species' arrivals (blocks 2 s and 2 s + 1 belong to species s), in
+// one more workgroup YeeGrid::synchronize (has_sync) followed by the edge tiles of the field solve (has_adv), and one
+// workgroup per interior tile of the field solve behind them.  With a peer link (peer.enabled) the launch IS the exchange: workgroup 0 first writes this subdomain's two
 // messages -- header, the halo packed straight from the grid rows, the row blocks the leavers occupy -- into the
 // neighbours' mailboxes, and every workgroup waits for the neighbours' messages before it reads them (peer_device.hpp).
 // The first workgroup also files this exchange's zone counts -- mine from the send headers, the neighbours' from the
@@ -1171,7 +1171,7 @@ struct UnpackBatch {
     int n;
     int has_sync;   // one more workgroup runs YeeGrid::synchronize's kernel (the fused linked step: independent work)
     SyncArgs sync;
-    int has_adv;    // ... and then YeeGrid::advance, tile after tile (small grids: grid_is_small)
+    int has_adv;    // ... and then the edge tiles of YeeGrid::advance; further workgroups take the interior tiles (grid_device.hpp)
     AdvArgs adv;
     PeerArgs peer;
     PublishBatch pub;
