@@ -167,6 +167,52 @@ constants:
 """
 
 
+def src_sha():
+    """Hash of the kernel sources the PMC traffic figures were taken with (profiles/traffic.json records it):
+    the code of the push and field kernels with comments and white space taken out."""
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    for f in ("particles.hip", "pic_device.hpp", "grid.hip", "grid_device.hpp"):
+        text = open(os.path.join(ROOT, "opal_amd", "csrc", f)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
+    return h.hexdigest()[:16]
+
+def bytes_model(forms, n_e, n_i, unfused):
+    """Algorithmic bytes per particle-update of the kernel FORM(S) that ran in the timed region:
+    cell, x, ux are read and written by every form (40 B); uy, uz are read and written (32 B) by every form but the
+    electrostatic launch; the weight is read (8 B) unless the launch takes it from its arguments.  The general
+    form with streamed weights is SURVEY.md 8d's 80 B.  Write-back elision and skipped rho are not byte-model
+    changes (rho lives in LDS; an attribute no lane changed is still part of what the form has to handle)."""
+    tot = sum(forms.values())
+    if not tot:
+        return None
+    n = max(n_e + n_i, 1)
+    acc, parts = 0.0, []
+    for f, cnt in sorted(forms.items()):
+        es, single = bool(f & 1), bool(f & 16)
+        base = 40.0 + (0.0 if es else 32.0) + (8.0 if unfused else 0.0)   # unfused advance also writes prev_x
+        if single:
+            w = 0.0 if f & 12 else 8.0
+        else:
+            w = ((0.0 if f & 4 else 8.0) * n_e + (0.0 if f & 8 else 8.0) * n_i) / n
+        acc += cnt * (base + w)
+        parts.append({"form": ("electrostatic" if es else "general") + (", rho deposited" if f & 2 else ", rho skipped")
+                              + ("" if w == 8.0 else ", weight from the launch arguments" if w == 0.0 else ", one species' weight from the launch arguments")
+                              + (", single species" if single else ""),
+                      "launches": cnt, "bytes_per_update": base + w})
+    dom = max(forms.items(), key=lambda kv: kv[1])[0]
+    mode = "0" if unfused else "1"
+    name = (f"k_push<{'0' if n_e else '1'}, {mode}, true, 0, false>" if dom & 16 else
+            f"k_push_pair<{mode}, {'true' if dom & 2 else 'false'}, {'true' if dom & 1 else 'false'}>")
+    return {"bytes_per_update": acc / tot, "forms": parts, "kernel": name,
+            "what": "read cell,x,ux + write cell,x,ux = 40 B; + uy,uz read and written = 32 B unless the launch is "
+                    "electrostatic; + w read = 8 B unless it comes from the launch arguments (general form, streamed "
+                    "weights: SURVEY.md 8d's 44 + 36 = 80 B)"}
+
+
 def cpu_quota():
     """CPUs' worth of time the cgroup this process runs in may use (None: unlimited)."""
     try:
@@ -483,51 +529,6 @@ def main():
         t = torch.tensor([v], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
-
-    def src_sha():
-        """Hash of the kernel sources the PMC traffic figures were taken with (profiles/traffic.json records it):
-        the code of the push and field kernels with comments and white space taken out."""
-        import hashlib
-        import re
-        h = hashlib.sha256()
-        for f in ("particles.hip", "pic_device.hpp", "grid.hip", "grid_device.hpp"):
-            text = open(os.path.join(ROOT, "opal_amd", "csrc", f)).read()
-            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-            text = re.sub(r"//[^\n]*", "", text)
-            h.update(re.sub(r"\s+", "", text).encode())
-        return h.hexdigest()[:16]
-
-    def bytes_model(forms, n_e, n_i, unfused):
-        """Algorithmic bytes per particle-update of the kernel FORM(S) that ran in the timed region:
-        cell, x, ux are read and written by every form (40 B); uy, uz are read and written (32 B) by every form but the
-        electrostatic launch; the weight is read (8 B) unless the launch takes it from its arguments.  The general
-        form with streamed weights is SURVEY.md 8d's 80 B.  Write-back elision and skipped rho are not byte-model
-        changes (rho lives in LDS; an attribute no lane changed is still part of what the form has to handle)."""
-        tot = sum(forms.values())
-        if not tot:
-            return None
-        n = max(n_e + n_i, 1)
-        acc, parts = 0.0, []
-        for f, cnt in sorted(forms.items()):
-            es, single = bool(f & 1), bool(f & 16)
-            base = 40.0 + (0.0 if es else 32.0) + (8.0 if unfused else 0.0)   # unfused advance also writes prev_x
-            if single:
-                w = 0.0 if f & 12 else 8.0
-            else:
-                w = ((0.0 if f & 4 else 8.0) * n_e + (0.0 if f & 8 else 8.0) * n_i) / n
-            acc += cnt * (base + w)
-            parts.append({"form": ("electrostatic" if es else "general") + (", rho deposited" if f & 2 else ", rho skipped")
-                                  + ("" if w == 8.0 else ", weight from the launch arguments" if w == 0.0 else ", one species' weight from the launch arguments")
-                                  + (", single species" if single else ""),
-                          "launches": cnt, "bytes_per_update": base + w})
-        dom = max(forms.items(), key=lambda kv: kv[1])[0]
-        mode = "0" if unfused else "1"
-        name = (f"k_push<{'0' if n_e else '1'}, {mode}, true, 0, false>" if dom & 16 else
-                f"k_push_pair<{mode}, {'true' if dom & 2 else 'false'}, {'true' if dom & 1 else 'false'}>")
-        return {"bytes_per_update": acc / tot, "forms": parts, "kernel": name,
-                "what": "read cell,x,ux + write cell,x,ux = 40 B; + uy,uz read and written = 32 B unless the launch is "
-                        "electrostatic; + w read = 8 B unless it comes from the launch arguments (general form, streamed "
-                        "weights: SURVEY.md 8d's 44 + 36 = 80 B)"}
 
     def measure(sim, steps, warmup, preheat=True, workload_key="two_stream"):
         """Pre-heat (untimed, >= PREHEAT_SECONDS of steps so that clocks and caches are those of a running job),

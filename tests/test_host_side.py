@@ -4,6 +4,7 @@ the oracle bit for bit, and the compute entry points fail loudly when there is n
 import ctypes as C
 import math
 import os
+import sys
 import re
 
 import numpy as np
@@ -257,3 +258,23 @@ def test_committed_traffic_figures_point_at_committed_profiles():
     # the electrostatic launch moves less than the general kernel, which moves less than the survey's 80 B
     assert t[head + "k_push_pair<1, false, true>"]["hbm_bytes_per_particle_update"] < \
         t[head + "k_push_pair<1, true, false>"]["hbm_bytes_per_particle_update"] < 80.0
+
+
+def test_bench_prices_each_kernel_form_with_its_own_bytes():
+    """bench.py's roofline: the algorithmic bytes per particle-update follow the FORM of the fused push that ran
+    (opal_prof_forms: bit 0 electrostatic, 1 rho, 2 / 3 the electrons' / ions' weight from the launch arguments, 4 a
+    single-species launch) -- 80 B only for the general form with streamed weights."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    general = bench.bytes_model({2: 200}, 5, 5, False)
+    assert general["bytes_per_update"] == 80.0 and general["kernel"] == "k_push_pair<1, true, false>"
+    es = bench.bytes_model({1 | 4 | 8: 19, 1 | 2 | 4 | 8: 1}, 5, 5, False)   # 19 steps without rho, the last with
+    assert es["bytes_per_update"] == 40.0 and es["kernel"] == "k_push_pair<1, false, true>"
+    assert bench.bytes_model({2 | 4 | 8: 3}, 5, 5, False)["bytes_per_update"] == 72.0      # general, uniform weights
+    assert bench.bytes_model({1 | 2: 3}, 5, 5, False)["bytes_per_update"] == 48.0          # electrostatic, weights streamed
+    assert bench.bytes_model({2 | 4: 3}, 6, 2, False)["bytes_per_update"] == 80.0 - 8.0 * 6 / 8   # one species' weight only
+    assert bench.bytes_model({2: 5}, 5, 5, True)["bytes_per_update"] == 88.0                # unfused advance also writes prev_x
+    assert bench.bytes_model({}, 5, 5, False) is None
+    # the hash that guards profiles/traffic.json does not move with comments or white space
+    assert len(bench.src_sha()) == 16
