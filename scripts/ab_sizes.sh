@@ -1,3 +1,7 @@
+#!/bin/bash
+# Same-box A/B of two builds (scripts/ab_build.sh: libvar_base = HEAD; libopal_amd = the working tree) at the sizes that
+# matter: one GPU's share of configs[2] at N = 8 through the peer self-exchange, configs[1], configs[2], the laser-plasma
+# interaction.  Through gpurun from the repo root: bash scripts/ab_sizes.sh
 cd $GRAFT_REPO_ROOT
 run() { OPAL_AMD_LIB=$PWD/opal_amd/lib/$1.so python bench.py --steps ${STEPS:-150} --warmup 15 --no-cpu-baseline --no-secondary $2 2>/dev/null | python -c "
 import json,sys

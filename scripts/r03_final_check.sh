@@ -1,3 +1,5 @@
+#!/bin/bash
+# End-of-round check on one MI355X: smoke, the whole -m gpu suite, the two default bench lines.
 set -e
 R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out/r03; mkdir -p $O
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel timeline of a few steps from a rocprofv3 --kernel-trace run of bench.py (scripts/trace_self_exchange.sh):
+"""Kernel timeline of a few steps from a rocprofv3 --kernel-trace run of bench.py (scripts/trace_linked.sh):
 what runs between two pushes, in microseconds from the start of each push.
 usage: step_timeline.py <dir with kt_kernel_trace.csv> [steps to print] [steps to skip from the end]"""
 import csv
