@@ -134,7 +134,7 @@ def test_decomposed_thin_plasma_is_ballistic(tmp_path, world, link_kind):
         assert np.max(np.minimum(d, nx - d)) < 1e-6, name
 
 
-def test_receiving_subdomain_grows_its_storage(oracle, tmp_path):
+def test_receiving_subdomain_grows_its_storage(oracle, tmp_path, link_kind):
     """All particles start on rank 0 and stream into rank 1, which starts with the minimum capacity."""
     o = oracle
     world, nx, npc, steps = 2, 48, 60, 70
@@ -234,7 +234,7 @@ def test_photon_emission_across_subdomains(oracle, tmp_path, world, deposit, lin
             assert abs(got[r]["ke_ph"] - phs[r].total_kinetic_energy()) / phs[r].total_kinetic_energy() < 5e-4
 
 
-def test_decomposed_run_writes_the_reference_outputs(oracle, tmp_path):
+def test_decomposed_run_writes_the_reference_outputs(oracle, tmp_path, link_kind):
     """opal_sim_run on 2 subdomains: {i}_grid.dat gathered in rank order (yee.rs:749-779), {i}_energy.dat
     reduced (main.rs:23-42), {i}_{species}_x-px.fits all-reduced (hgram.rs:190-260) -- against the oracle run
     with the same decomposition from the driver's own initial particles."""
