@@ -210,9 +210,41 @@ int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n)
         set_error("opal_link_self_test: null link");
         return OPAL_ERR_ARG;
     }
-    for (int k = 0; k < n; k++)
+    if (!l->device_buffers) {  // (host-staged transports: completion is all there is to see)
+        for (int k = 0; k < n; k++)
+            if (int rc = link_exchange_halo(l, to_left != 0, to_right != 0, l->stream)) return rc;
+        OPAL_HIP(hipStreamSynchronize(l->stream));
+        return OPAL_OK;
+    }
+    // Every round ships a halo whose 80 doubles name their sender, the side they left through and the round, and checks
+    // that what arrived is what the neighbour on that side must have sent in THIS round: a message that arrives late,
+    // stale (the mailbox of two rounds ago) or torn fails here, before a simulation depends on it.
+    constexpr int ND = (int)(LINK_HALO_BYTES / sizeof(double));
+    auto pattern = [](int rank, int side, int round, int i) { return 1.0e6 * (rank + 1) + 1.0e4 * (side + 1) + 1.0e2 * round + i; };
+    const int left = (l->rank - 1 + l->size) % l->size, right = (l->rank + 1) % l->size;
+    double buf[ND];
+    for (int k = 0; k < n; k++) {
+        for (int side = 0; side < 2; side++) {
+            for (int i = 0; i < ND; i++) buf[i] = pattern(l->rank, side, k, i);
+            OPAL_HIP(hipMemcpyAsync(link_send(l, side) + LINK_HEADER_BYTES, buf, sizeof buf, hipMemcpyHostToDevice, l->stream));
+        }
+        OPAL_HIP(hipStreamSynchronize(l->stream));
         if (int rc = link_exchange_halo(l, to_left != 0, to_right != 0, l->stream)) return rc;
-    OPAL_HIP(hipStreamSynchronize(l->stream));
+        for (int side = 0; side < 2; side++) {
+            if (!(side == 0 ? to_left : to_right)) continue;
+            OPAL_HIP(hipMemcpyAsync(buf, link_recv(l, side) + LINK_HEADER_BYTES, sizeof buf, hipMemcpyDeviceToHost, l->stream));
+            OPAL_HIP(hipStreamSynchronize(l->stream));
+            // from the left neighbour comes what it sent to the RIGHT, and the other way round
+            const int from = side == 0 ? left : right, their_side = side == 0 ? 1 : 0;
+            for (int i = 0; i < ND; i++)
+                if (buf[i] != pattern(from, their_side, k, i)) {
+                    set_error("link self-test: round %d, halo word %d from subdomain %d reads %.17g, not %.17g (a late, stale or "
+                              "torn message)", k, i, from, buf[i], pattern(from, their_side, k, i));
+                    return OPAL_ERR_LINK;
+                }
+        }
+    }
+    // (the send buffers' halo regions are rewritten by every step's pack; nothing to restore)
     return l->peer ? opal_link_peer_status(l, nullptr, nullptr, nullptr) : OPAL_OK;
 }
 
