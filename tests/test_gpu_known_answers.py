@@ -149,3 +149,135 @@ def test_ion_in_a_static_electric_field(oa):
     assert abs(p.total_kinetic_energy() - ke) <= 1e-11 * ke
     # gamma(t) = sqrt(1 + (q E t / M c)^2), the form of electron.rs:423-436
     assert abs(np.sqrt(1.0 + s["ux"][0] ** 2) - np.sqrt(1.0 + (q * e0 * steps * dt / (M * C)) ** 2)) < 1e-12
+
+
+# ------------------------------------------------------------------ the whole loop against textbook physics
+EPS0 = 8.854188e-12       # constants.rs:8
+
+LANGMUIR = """---
+control:
+ dx: 1.0e-8
+ nx: {nx}
+ xmin: 0.0
+ start: 0.0
+ end: 1.0e-12
+ current_deposition: true
+ n_outputs: 2
+ balance: false
+qed:
+ photon_emission: false
+ photon_absorption: false
+electrons:
+ npc: 64
+ ne: {ne}
+ ux: {u0} * sin(2.0 * pi * x / ({nx} * 1.0e-8))
+ uy: 0.0
+ uz: 0.0
+ output: x:px
+ions:
+ name: ballast
+ npc: 4
+ Z: 1.0
+ A: 1.0e9
+ ni: {ne}
+ ux: 0.0
+ uy: 0.0
+ uz: 0.0
+ output: x:px
+"""
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_cold_plasma_oscillates_at_the_plasma_frequency(oa, fused):
+    """gather -> push -> deposit -> synchronize -> advance, closed on itself: a cold electron fluid given the velocity
+    u0 sin(kx) over ions too heavy to move (A = 1e9; Ex = 0 at t = 0, and Ampere's law alone evolves it -- which is what
+    a charge-conserving deposit is for) rings at omega_p = sqrt(n e^2 / eps0 m), whatever k.  The leapfrog correction
+    sin(omega dt / 2) = omega_p dt / 2 is 1e-4 here and the spline's form factor (k dx)^2 ~ 6e-4: the measured frequency
+    must agree with the textbook one to 0.2 %.  Nothing of the oracle enters."""
+    nx, ne, u0 = 256, 1.0e27, 1.0e-3
+    sim = oa.Simulation(yaml_text=LANGMUIR.format(nx=nx, ne=ne, u0=u0))
+    sim.set_fused(fused)
+    g = sim.grid
+    L = g.left_bdy_size
+    dt = sim.dt
+    wp = np.sqrt(ne * E_CHARGE ** 2 / (EPS0 * M_E))
+    assert 0.04 < wp * dt < 0.07
+    kx = 2.0 * np.pi * (np.arange(nx) + 0.5) / nx  # Ex lives at cell centres (yee.rs:70-82)
+    steps = int(3.6 * 2.0 * np.pi / (wp * dt))
+    a = np.empty(steps + 1)
+    b = np.empty(steps + 1)
+    for i in range(steps + 1):
+        ex = g.raw("Ex")[L:L + nx]
+        a[i] = 2.0 / nx * np.sum(ex * np.sin(kx))
+        b[i] = 2.0 / nx * np.sum(ex * np.cos(kx))
+        if i < steps:
+            sim.step(1)
+    sim.sync()
+    # E(x, t) = +(m c omega_p u0 / e) sin(kx) sin(omega_p t): amplitude, phase and shape
+    amp = M_E * C * wp * u0 / E_CHARGE
+    assert abs(np.max(np.abs(a)) / amp - 1.0) < 5e-3
+    assert np.max(np.abs(b)) < 2e-3 * amp           # the mode stays a sine: nothing drifts
+    assert a[1] > 0.0                                # electrons moving to +x carry j < 0: dEx/dt = -j / eps0 > 0 there
+    # frequency from the zero crossings of the mode amplitude (linear interpolation between the bracketing steps)
+    s = np.sign(a[1:])
+    idx = np.nonzero(s[1:] * s[:-1] < 0)[0] + 1
+    tz = (idx + a[idx] / (a[idx] - a[idx + 1])) * dt
+    assert len(tz) >= 6
+    half_period = (tz[-1] - tz[0]) / (len(tz) - 1)
+    assert abs(np.pi / half_period / wp - 1.0) < 2e-3
+    # energy sloshes between the field and the electrons and the sum stays put
+    fe, ke = sim.energies()[0], sim.energies()[1]
+    n_macro = nx * 64
+    ke0 = 0.25 * u0 ** 2 * M_E * C ** 2 * ne * nx * 1.0e-8  # <sin^2> = 1/2, per unit area
+    # (momenta and fields are not known at the same instant, so the sum read at one instant wobbles by
+    # O(omega_p dt) = 5 %; the amplitude check above is the sharp statement that all of ke0 reaches the field)
+    assert abs((fe + ke) / ke0 - 1.0) < 0.04, (fe, ke, ke0, n_macro)
+
+
+def test_light_wave_on_the_yee_mesh(oa):
+    """synchronize (periodic wrap) + advance alone, against the dispersion relation of the scheme the reference states
+    (yee.rs:839-867: B half step, E step, B half step -- Yee 1966 with B also known at the integer times):
+    sin(omega dt / 2) = (c dt / dx) sin(k dx / 2).  The right-going eigenmode of that scheme,
+        Ey_j^n = E0 sin(k x_j - omega t_n),   Bz_{j+1/2}^n = E0 dx sin(omega dt) / (2 c^2 dt sin(k dx / 2)) sin(k x_{j+1/2} - omega t_n),
+    must come back after N steps with its amplitude, shifted by omega N dt -- measurably less than c k N dt -- and with
+    nothing in Ez / By.  No oracle.  (The c of the field solve is sqrt(SPEED_OF_LIGHT_SQD) = 299 792 458 m/s,
+    constants.rs:6, not the rounded SPEED_OF_LIGHT of constants.rs:4 the pushes use: 800 steps tell the two apart.)"""
+    nx, dx, m = 240, 1.0e-8, 12
+    dt = 0.9 * dx / C
+    c2 = 89875517873681764.0
+    cf = np.sqrt(c2)
+    g = oa.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    k = 2.0 * np.pi * m / (nx * dx)
+    w = 2.0 / dt * np.arcsin(cf * dt / dx * np.sin(0.5 * k * dx))
+    j = np.arange(g.len) - L
+    e0 = 3.0e10
+    b0 = e0 * dx * np.sin(w * dt) / (2.0 * c2 * dt * np.sin(0.5 * k * dx))
+    assert 0.99 < b0 * C / e0 < 1.0
+    g.set_raw("Ey", e0 * np.sin(k * dx * j))            # Ey at the left-hand edge of cell j (yee.rs:70-82)
+    g.set_raw("Bz", b0 * np.sin(k * dx * (j + 0.5)))    # Bz at its centre
+    g.synchronize()
+    e_before = g.em_field_energy()
+    steps = 800
+    for _ in range(steps):
+        g.advance(dt)
+        g.synchronize()
+    got = g.raw("Ey")[L:L + nx]
+    jj = np.arange(nx)
+    c_, s_ = 2.0 / nx * np.sum(got * np.cos(k * dx * jj)), 2.0 / nx * np.sum(got * np.sin(k * dx * jj))
+    # Ey = e0 sin(k x - w t) = e0 [sin kx cos wt - cos kx sin wt]
+    phase = np.arctan2(-c_, s_)
+    want = (w * steps * dt) % (2.0 * np.pi)
+    d = (phase - want + np.pi) % (2.0 * np.pi) - np.pi
+    assert abs(d) < 1e-8, (phase, want)
+    w_rounded_c = 2.0 / dt * np.arcsin(C * dt / dx * np.sin(0.5 * k * dx))
+    assert abs((w_rounded_c - w) * steps * dt) > 1e-5
+    assert abs(np.hypot(c_, s_) / e0 - 1.0) < 1e-9
+    assert abs((cf * k - w) * steps * dt) > 0.1          # a wave at c would sit 0.17 rad further on
+    assert abs(g.em_field_energy() / e_before - 1.0) < 1e-9
+    assert np.max(np.abs(g.raw("Ez"))) == 0.0 and np.max(np.abs(g.raw("By"))) == 0.0
+    resid = got - (s_ * np.sin(k * dx * jj) + c_ * np.cos(k * dx * jj))
+    assert np.max(np.abs(resid)) < 1e-9 * e0            # still the one harmonic
+    bz = g.raw("Bz")[L:L + nx]
+    want_bz = b0 * np.sin(k * dx * (jj + 0.5) - w * steps * dt)
+    assert np.max(np.abs(bz - want_bz)) < 1e-8 * b0

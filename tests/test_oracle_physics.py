@@ -1,0 +1,85 @@
+"""The CPU oracle against textbook physics, where the reference holds no test of its own (gather,
+deposit and the closed loop have none): the same two statements tests/test_gpu_known_answers.py makes of the HIP
+path, made of oracle/opal_oracle.c.  A mis-reading of the reference that oracle and kernels share would have to
+reproduce the Yee dispersion relation to 1e-8 and the plasma frequency to 0.2 % to get past both."""
+import numpy as np
+
+C = 2.997925e8            # constants.rs:4
+C2_FIELD = 89875517873681764.0  # constants.rs:6: the c^2 of the field solve is the exact one
+EPS0 = 8.854188e-12
+E_CHARGE = 1.602177e-19
+M_E = 9.109383e-31
+
+
+def test_light_wave_on_the_yee_mesh(oracle):
+    """yee.rs:839-867 (B half step, E step, B half step) has the dispersion relation
+    sin(omega dt / 2) = (c dt / dx) sin(k dx / 2); its right-going eigenmode returns after N steps shifted by
+    omega N dt, amplitude and energy intact."""
+    o = oracle
+    nx, dx, m = 240, 1.0e-8, 12
+    dt = 0.9 * dx / C
+    cf = np.sqrt(C2_FIELD)
+    g = o.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    k = 2.0 * np.pi * m / (nx * dx)
+    w = 2.0 / dt * np.arcsin(cf * dt / dx * np.sin(0.5 * k * dx))
+    j = np.arange(g.len) - L
+    e0 = 3.0e10
+    b0 = e0 * dx * np.sin(w * dt) / (2.0 * C2_FIELD * dt * np.sin(0.5 * k * dx))
+    g.set_raw("Ey", e0 * np.sin(k * dx * j))
+    g.set_raw("Bz", b0 * np.sin(k * dx * (j + 0.5)))
+    g.synchronize()
+    e_before = g.em_field_energy()
+    steps = 800
+    for _ in range(steps):
+        g.advance(dt)
+        g.synchronize()
+    jj = np.arange(nx)
+    got = g.raw("Ey")[L:L + nx]
+    c_, s_ = 2.0 / nx * np.sum(got * np.cos(k * dx * jj)), 2.0 / nx * np.sum(got * np.sin(k * dx * jj))
+    phase = np.arctan2(-c_, s_)
+    d = (phase - (w * steps * dt) % (2.0 * np.pi) + np.pi) % (2.0 * np.pi) - np.pi
+    assert abs(d) < 1e-8
+    assert abs(np.hypot(c_, s_) / e0 - 1.0) < 1e-9
+    assert abs((cf * k - w) * steps * dt) > 0.1  # not the continuum's c k
+    assert abs(g.em_field_energy() / e_before - 1.0) < 1e-9
+    want_bz = b0 * np.sin(k * dx * (jj + 0.5) - w * steps * dt)
+    assert np.max(np.abs(g.raw("Bz")[L:L + nx] - want_bz)) < 1e-8 * b0
+    assert np.max(np.abs(g.raw("Ez"))) == 0.0 and np.max(np.abs(g.raw("By"))) == 0.0
+
+
+def test_cold_plasma_oscillates_at_the_plasma_frequency(oracle):
+    """fields_at -> Electron::push -> deposit -> synchronize -> advance closed on itself: omega_p = sqrt(n e^2 / eps0 m)."""
+    o = oracle
+    nx, dx, npc, ne, u0 = 256, 1.0e-8, 16, 1.0e27, 1.0e-3
+    dt = 0.95 * dx / C
+    g = o.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    cell = np.repeat(np.arange(nx), npc).astype(np.int64)
+    x = np.tile((np.arange(npc) + 0.5) / npc, nx)
+    X = (cell + x) * dx
+    ux = u0 * np.sin(2.0 * np.pi * X / (nx * dx))
+    z = np.zeros_like(x)
+    wgt = np.full_like(x, ne * dx / npc)
+    pe = o.Population.from_soa(o.ELECTRON, cell, x, ux, z, z, wgt, dx, dt)
+    pi = o.Population.from_soa(o.ION, cell, x, z, z, z, wgt, dx, dt)
+    pi.set_charge_state(1.0, 1.0, 1.0e9)  # ballast: too heavy to move
+    wp = np.sqrt(ne * E_CHARGE ** 2 / (EPS0 * M_E))
+    steps = int(3.6 * 2.0 * np.pi / (wp * dt))
+    kx = 2.0 * np.pi * (np.arange(nx) + 0.5) / nx
+    a = np.empty(steps + 1)
+    t = 0.0
+    for i in range(steps + 1):
+        a[i] = 2.0 / nx * np.sum(g.raw("Ex")[L:L + nx] * np.sin(kx))
+        if i < steps:
+            assert o.world_step([g], [pe], [pi], True, t, dt) == 0
+            t += dt
+    amp = M_E * C * wp * u0 / E_CHARGE
+    assert abs(np.max(np.abs(a)) / amp - 1.0) < 5e-3
+    assert a[1] > 0.0
+    s = np.sign(a[1:])
+    idx = np.nonzero(s[1:] * s[:-1] < 0)[0] + 1
+    tz = (idx + a[idx] / (a[idx] - a[idx + 1])) * dt
+    assert len(tz) >= 6
+    half_period = (tz[-1] - tz[0]) / (len(tz) - 1)
+    assert abs(np.pi / half_period / wp - 1.0) < 2e-3
