@@ -83,3 +83,49 @@ def test_cold_plasma_oscillates_at_the_plasma_frequency(oracle):
     assert len(tz) >= 6
     half_period = (tz[-1] - tz[0]) / (len(tz) - 1)
     assert abs(np.pi / half_period / wp - 1.0) < 2e-3
+
+
+def test_light_in_a_cold_plasma(oracle):
+    """The transverse half of the loop.  Omega^2 = c^2 K^2 + omega_p^2 Wg Wd with Omega = (2/dt) sin(omega dt/2),
+    K = (2/dx) sin(k dx/2), Wg = sinc^3(k dx/2) and Wd = (1 - 1/48) sinc^3(k dx/2): the reference's transverse taps
+    end in weight(2.0 + x) = 0 (yee.rs:597, 602), so 1/48 of j_y is not deposited; the amplitude of the wave,
+    u0 m c omega_p^2 Wd / (e Omega cos(omega dt/2)), resolves that."""
+    o = oracle
+    nx, dx, npc, ne, u0, m = 256, 1.0e-8, 32, 1.0e27, 1.0e-3, 4
+    dt = 0.95 * dx / C
+    g = o.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    cell = np.repeat(np.arange(nx), npc).astype(np.int64)
+    x = np.tile((np.arange(npc) + 0.5) / npc, nx)
+    uy = u0 * np.sin(2.0 * np.pi * m * (cell + x) / nx)
+    z = np.zeros_like(x)
+    wgt = np.full_like(x, ne * dx / npc)
+    pe = o.Population.from_soa(o.ELECTRON, cell, x, z, uy, z, wgt, dx, dt)
+    pi = o.Population.from_soa(o.ION, cell, x, z, z, z, wgt, dx, dt)
+    pi.set_charge_state(1.0, 1.0, 1.0e9)
+    wp = np.sqrt(ne * E_CHARGE ** 2 / (EPS0 * M_E))
+    cf = np.sqrt(C2_FIELD)
+    kdx = 2.0 * np.pi * m / nx
+    sinc3 = (np.sin(0.5 * kdx) / (0.5 * kdx)) ** 3
+    Wg, Wd = sinc3, (1.0 - 1.0 / 48.0) * sinc3
+    w = 2.0 / dt * np.arcsin(np.sqrt((cf * dt / dx * np.sin(0.5 * kdx)) ** 2 + 0.25 * (wp * dt) ** 2 * Wg * Wd))
+    w_vac = 2.0 / dt * np.arcsin(cf * dt / dx * np.sin(0.5 * kdx))
+    kj = kdx * np.arange(nx)
+    steps = int(4.6 * 2.0 * np.pi / (w * dt))
+    a = np.empty(steps + 1)
+    t = 0.0
+    for i in range(steps + 1):
+        a[i] = 2.0 / nx * np.sum(g.raw("Ey")[L:L + nx] * np.sin(kj))
+        if i < steps:
+            assert o.world_step([g], [pe], [pi], True, t, dt) == 0
+            t += dt
+    assert a[1] > 0.0
+    s = np.sign(a[1:])
+    idx = np.nonzero(s[1:] * s[:-1] < 0)[0] + 1
+    tz = (idx + a[idx] / (a[idx] - a[idx + 1])) * dt
+    assert len(tz) >= 8
+    got = np.pi / ((tz[-1] - tz[0]) / (len(tz) - 1))
+    assert abs(got / w - 1.0) < 3e-3 and abs(got / w_vac - 1.0) > 0.1
+    big_omega = 2.0 / dt * np.sin(0.5 * w * dt)
+    amp = u0 * M_E * C * wp * wp * Wd / (E_CHARGE * big_omega * np.cos(0.5 * w * dt))
+    assert abs(np.max(np.abs(a)) / amp - 1.0) < 4e-3, np.max(np.abs(a)) / amp
