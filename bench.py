@@ -22,7 +22,9 @@ region (`bytes_model`; the library reports the form of each launch, opal_prof_fo
 simulation's stream around a 1-in-5 sample of its launches in the timed region; `traffic` is the PMC-measured HBM bytes
 per launch from profiles/traffic.json, used only if that entry was taken for this workload, this kernel instantiation
 and these kernel sources.  At N = 1 the line also carries configs[1] (`secondary`) and configs[3]'s physics inside the
-laser-plasma interaction (`laser_plasma_interaction`), measured the same way in the same process.
+laser-plasma interaction (`laser_plasma_interaction`), measured the same way in the same process.  At N > 1 the line
+carries `laser_plasma_interaction` for configs[3] as named (1e8 particles, `balance: true`) on the same N GPUs, run after
+the two-stream measurement is complete and under a deadline, so that nothing in it can cost the line.
 
 `python bench.py --gpus N` needs no launcher: with WORLD_SIZE unset the parent -- which never touches a
 GPU -- starts N ranks of itself as child processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on
@@ -165,6 +167,15 @@ constants:
  A: 12.0
  kT: 500 * eV
 """
+
+
+def lp_link_capacity(npc):
+    """Room in a laser-plasma link for the leavers of one step through one cut, per species: what sits within c dt = 0.95
+    cells of the cut and moves towards it.  The hole-boring front piles the electrons up to tens of times the slab's
+    density before it reaches a cut, so 2 npc (a front at the initial density) overflows -- reported as an error, as it
+    was at 4 and 6 subdomains with 1e8 particles; 32 npc is room for a 30-fold pile-up (what travels is still only the
+    actual leavers: capacity costs mailbox memory, 2 x 17 MB per cut at npc = 10 000)."""
+    return max(4096, 32 * npc)
 
 
 def src_sha():
@@ -462,8 +473,7 @@ def main():
     if args.workload == "laser_plasma":
         npc = args.npc if args.npc is not None else 2000
         nx = 20000
-        # a relativistic front carries ~0.95 npc particles per step and species through a cut
-        link_capacity = max(1024, 2 * npc)
+        link_capacity = lp_link_capacity(npc)
     else:
         if weak:
             cells_per_gpu = args.cells_per_gpu or C2_CELLS
@@ -744,7 +754,67 @@ def main():
         }
         if m_default is not None:
             out["default_path"] = block(m_default, DEFAULT, half)
-        del sim
+    del sim
+
+    def write_line():
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    if world > 1 and args.workload == "two_stream" and not weak and not args.self_exchange and not args.unfused \
+            and not args.no_laser_plasma and (nx, npc) == (C3_CELLS, C3_NPC) and args.elision == "off":
+        # BASELINE configs[3] on the same N GPUs: hole_boring.yaml's physics with 1e8 particles, `balance: true`
+        # (subdomains of different sizes, GridDesign::balanced), laser and absorbing ends, timed inside the interaction.
+        # A second set of mailboxes (open ends, room for a relativistic front) is set up for it.  The two-stream line
+        # above is complete at this point: whatever happens here -- an error on some subdomain, a transport that never
+        # returns -- the line is written, with the failure in it, and every rank leaves with status 0 once the
+        # deadline passes.
+        import threading
+        lp_npc, lp_warm, lp_steps = 10000, 21000, 2000
+        deadline = float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "480"))  # (below torch.distributed's own 600 s collective timeout)
+        once = threading.Lock()
+
+        def give_up(why):
+            if not once.acquire(blocking=False):
+                return
+            if rank == 0:
+                out["laser_plasma_interaction"] = {"error": why}
+                write_line()
+            print(f"[bench] rank {rank}: laser-plasma block abandoned: {why}", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(deadline, give_up, args=(f"did not finish within {deadline:.0f} s",))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            link = None
+            link3, kind3 = make_link(rank, world, link_device, lp_link_capacity(lp_npc), stream=stream, to_left=rank != 0,
+                                     to_right=rank != world - 1, prefer=order,
+                                     log=lambda m_: print(m_.replace("[opal_amd]", "[bench]"), file=sys.stderr))
+            oa.set_elision(False)
+            sim3 = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=lp_npc), rank=rank, numtasks=world, link=link3, stream=stream)
+            sizes = [None] * world
+            dist.all_gather_object(sizes, int(sim3.grid.size))
+            m3 = measure(sim3, lp_steps, lp_warm, preheat=False, workload_key=f"laser_plasma:{lp_npc}")
+            t3 = sim3.t
+            del sim3, link3
+            oa.set_elision(True)
+            if rank == 0:
+                out["laser_plasma_interaction"] = block(
+                    m3, f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]) on "
+                        + (f"{world} GPUs" if backend == "nccl" else f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)")
+                        + f", {lp_npc} e- + {lp_npc} "
+                        f"C6+ per cell in 5000 of 20000 cells, balanced decomposition (subdomain sizes {sizes}), {lp_warm} "
+                        f"untimed steps to bring the pulse onto the slab, then {lp_steps} timed steps ending at "
+                        f"t = {t3:.3e} s; " + CONTRACT, lp_steps, {"link": kind3, "n_gpus": world})
+        except BaseException as e:  # noqa: BLE001
+            # the other subdomains may be waiting in a collective of the block: no further collective from here
+            give_up(f"{type(e).__name__}: {e}")
+        watchdog.cancel()
+        if not once.acquire(blocking=False):  # the watchdog fired while the block was finishing: it ends the process
+            time.sleep(3600)
+
+    if rank == 0:
         if world == 1 and args.workload == "two_stream" and not weak and not args.no_secondary and not args.self_exchange \
                 and (nx, npc) == (C3_CELLS, C3_NPC) and args.elision == "off":
             # BASELINE configs[1], measured the same way in the same process (default path first, then the contract run)
@@ -777,10 +847,7 @@ def main():
             oa.set_elision(True)
         if not args.no_cpu_baseline and world == 1 and args.workload == "two_stream":
             out["cpu_baseline"] = cpu_baseline(oa, nx, npc)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    else:
-        del sim
+        write_line()
     if dist is not None:
         # success path only: a rank that failed above has already left with a non-zero status, and its peers
         # are torn down by the launcher instead of waiting in a collective that can never match

@@ -22,6 +22,9 @@ void set_error(const char *fmt, ...)
 int hip_fail(hipError_t e, const char *what)
 {
     set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    // the runtime also keeps the error as the thread's "last error": taken here, or the next launch check
+    // (hipGetLastError after a <<<>>>) of a caller that carried on -- with another transport, say -- would report it
+    (void)hipGetLastError();
     return OPAL_ERR_HIP;
 }
 

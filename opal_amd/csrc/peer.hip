@@ -2,6 +2,7 @@
 // existing exchange point (opal_grid_synchronize's halo-only exchange, the separate-operator step's whole
 // messages) run over them unchanged; the fused linked step does the same inside its own tail kernel
 // (particles.hip: k_link_tail).
+#include <unistd.h>
 #include "peer_device.hpp"
 
 #include <cstring>
@@ -12,6 +13,7 @@ struct opal_peer {
     char *box_mem = nullptr;   // my four mailboxes: [from left | from right] x [parity 0 | 1], each `stride` bytes
     size_t stride = 0;         // flag line + message, rounded up to 256
     char *peer_base[2] = {nullptr, nullptr};  // where my messages go: the left neighbour's from-right pair, the right neighbour's from-left pair
+    size_t total = 0;                         // bytes of box_mem
     void *mapped[2] = {nullptr, nullptr};     // hipIpcOpenMemHandle mappings to close (null: the neighbour is in this process)
     unsigned *d_err = nullptr;
     unsigned seq = 0;          // exchanges made so far
@@ -108,6 +110,27 @@ void link_peer_free(opal_link_t *l)
 
 }  // namespace opal
 
+// memory both ends see coherently: uncached, else fine-grained; OPAL_PEER_ALLOC=plain|fine|uncached overrides
+static hipError_t peer_alloc(opal_peer *p, char **mem)
+{
+    const char *want = getenv("OPAL_PEER_ALLOC");
+    hipError_t e = hipErrorUnknown;
+    if (!want || !strcmp(want, "uncached")) {
+        e = hipExtMallocWithFlags((void **)mem, p->total, hipDeviceMallocUncached);
+        p->alloc_kind = 0;
+    }
+    if (e != hipSuccess && (!want || !strcmp(want, "fine"))) {
+        e = hipExtMallocWithFlags((void **)mem, p->total, hipDeviceMallocFinegrained);
+        p->alloc_kind = 1;
+    }
+    if (e != hipSuccess && want && !strcmp(want, "plain")) {
+        e = hipMalloc((void **)mem, p->total);
+        p->alloc_kind = 2;
+    }
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
+
 extern "C" {
 
 int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges);
@@ -130,23 +153,9 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
     l->peer = p;
     p->stride = (PEER_FLAG_BYTES + l->nbytes + 255) / 256 * 256;
     const size_t total = 4 * p->stride;
-    // memory both ends see coherently: uncached, else fine-grained; OPAL_PEER_ALLOC=plain|fine|uncached overrides
-    const char *want = getenv("OPAL_PEER_ALLOC");
-    hipError_t e = hipErrorUnknown;
-    if (!want || !strcmp(want, "uncached")) {
-        e = hipExtMallocWithFlags((void **)&p->box_mem, total, hipDeviceMallocUncached);
-        p->alloc_kind = 0;
-    }
-    if (e != hipSuccess && (!want || !strcmp(want, "fine"))) {
-        e = hipExtMallocWithFlags((void **)&p->box_mem, total, hipDeviceMallocFinegrained);
-        p->alloc_kind = 1;
-    }
-    if (e != hipSuccess && want && !strcmp(want, "plain")) {
-        e = hipMalloc((void **)&p->box_mem, total);
-        p->alloc_kind = 2;
-    }
+    p->total = total;
+    hipError_t e = peer_alloc(p, &p->box_mem);
     if (e != hipSuccess) {
-        (void)hipGetLastError();
         p->box_mem = nullptr;
         opal_link_free(l);
         *out = nullptr;
@@ -167,7 +176,27 @@ int opal_link_peer_export(opal_link_t *l, void *handle64)
     }
     static_assert(sizeof(hipIpcMemHandle_t) == OPAL_PEER_HANDLE_BYTES, "IPC handle size");
     hipIpcMemHandle_t h;
-    OPAL_HIP(hipIpcGetMemHandle(&h, l->peer->box_mem));
+    opal_peer *p = l->peer;
+    // The export of a fresh allocation has been seen to fail once ("invalid argument", one of four processes sharing a
+    // card, right after each had freed an exported allocation): tried again, then with another allocation, before the
+    // caller is told to use another transport.
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        e = hipIpcGetMemHandle(&h, p->box_mem);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        usleep(20000u << attempt);
+        if (attempt >= 1) {
+            char *fresh = nullptr;
+            if (peer_alloc(p, &fresh) == hipSuccess) {  // (while the old one is still held: another address)
+                hipFree(p->box_mem);
+                p->box_mem = fresh;
+                OPAL_HIP(hipMemset(p->box_mem, 0, p->total));
+                OPAL_HIP(hipDeviceSynchronize());
+            }
+        }
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipIpcGetMemHandle(mailboxes), 4 attempts");
     memcpy(handle64, &h, sizeof h);
     return OPAL_OK;
 }
