@@ -286,8 +286,12 @@ def make_link(rank, world, device, particle_capacity, stream=None, photon_emissi
     device = torch.device(device)
     log = log or (lambda m: print(m, file=sys.stderr))
     ctl = None
-    if world > 1:
-        ctl = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
+    if world > 1 and dist.get_backend() != "gloo":
+        try:
+            ctl = dist.new_group(backend="gloo")
+        except Exception as e:  # noqa: BLE001  (no usable host interface for gloo: the default group carries the votes)
+            log(f"[opal_amd] no gloo control group ({e}); using the default process group")
+            ctl = None
     kw = dict(particle_capacity=particle_capacity, stream=stream, photon_emission=photon_emission,
               photon_absorption=photon_absorption)
 
