@@ -331,3 +331,40 @@ def test_light_wave_on_the_yee_mesh(oa):
     bz = g.raw("Bz")[L:L + nx]
     want_bz = b0 * np.sin(k * dx * (jj + 0.5) - w * steps * dt)
     assert np.max(np.abs(bz - want_bz)) < 1e-8 * b0
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_stream_instability_grows_at_half_the_beam_plasma_frequency(oa, fused):
+    """The headline workload as a known answer (no oracle): two equal cold beams,
+    1 = omega_b^2 [1/(omega - k v0)^2 + 1/(omega + k v0)^2], fastest-growing root Im omega = omega_b / 2 at
+    k v0 = (sqrt 3 / 2) omega_b with omega_b^2 = n_b e^2 / (eps0 m gamma^3).  The seeded mode's Ex amplitude is followed
+    through seven e-foldings and the fitted rate must be the textbook one to 1 % (the CPU oracle measures 0.9995 of it:
+    tests/test_oracle_physics.py)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_physics import _two_cold_beams, growth_rate
+    nx, dx, m = 256, 4.0e-9, 3
+    dt = 0.95 * dx / C
+    st, wb = _two_cold_beams(nx, dx, m, 32, 0.2, 1e-7)
+    g = oa.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    pe = oa.Population.from_soa(oa.ELECTRON, st[0].astype(np.int32), *st[1:], dx, dt)
+    kx = 2.0 * np.pi * m * (np.arange(nx) + 0.5) / nx
+    steps = 2200
+    a = np.empty(steps)
+    for i in range(steps):
+        if fused:
+            g.clear()
+            pe.advance_deposit(g, dt)
+        else:
+            pe.advance(g, dt)
+            g.clear()
+            g.deposit(pe, dt)
+        g.synchronize(None, None, 0.0, dt)
+        g.advance(dt)
+        ex = g.raw("Ex")[L:L + nx]
+        a[i] = np.hypot(np.sum(ex * np.sin(kx)), np.sum(ex * np.cos(kx))) * 2.0 / nx
+    assert np.max(a) > 1e6 * a[0]
+    assert abs(growth_rate(a, dt) / (0.5 * wb) - 1.0) < 1e-2
+    assert pe.counters()["tile_misses"] >= 0 and len(pe) == 2 * 32 * nx

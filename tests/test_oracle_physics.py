@@ -129,3 +129,57 @@ def test_light_in_a_cold_plasma(oracle):
     big_omega = 2.0 / dt * np.sin(0.5 * w * dt)
     amp = u0 * M_E * C * wp * wp * Wd / (E_CHARGE * big_omega * np.cos(0.5 * w * dt))
     assert abs(np.max(np.abs(a)) / amp - 1.0) < 4e-3, np.max(np.abs(a)) / amp
+
+
+def _two_cold_beams(nx, dx, m, npc, u0, eps):
+    """Two cold counter-streaming electron beams, quiet start, a velocity ripple of relative size eps in mode m; the beam
+    density is chosen so that mode m is the fastest-growing one: k v0 = (sqrt 3 / 2) omega_b."""
+    gam = np.sqrt(1.0 + u0 * u0)
+    v0 = u0 / gam * C
+    k = 2.0 * np.pi * m / (nx * dx)
+    wb = k * v0 / (0.5 * np.sqrt(3.0))
+    nb = wb ** 2 * EPS0 * M_E * gam ** 3 / E_CHARGE ** 2   # omega_b^2 = n_b e^2 / (eps0 m gamma^3): longitudinal mass
+    cell = np.repeat(np.arange(nx), npc).astype(np.int64)
+    x = np.tile((np.arange(npc) + 0.5) / npc, nx)
+    ripple = 1.0 + eps * np.sin(2.0 * np.pi * m * (cell + x) / nx)
+    cell2, x2 = np.concatenate([cell, cell]), np.concatenate([x, x])
+    ux2 = np.concatenate([u0 * ripple, -u0 * ripple])
+    order = np.argsort(cell2, kind="stable")
+    z = np.zeros(len(x2))
+    w = np.full(len(x2), nb * dx / npc)
+    return (cell2[order], x2[order], ux2[order], z, z.copy(), w), wb
+
+
+def growth_rate(a, dt):
+    """Slope of ln a over the stretch in which the growing mode has outrun the seed's other components (50 x the first
+    steps' amplitude) and is still linear (3 % of the saturated one)."""
+    lo, hi = 50.0 * np.max(a[:60]), 0.03 * np.max(a)
+    i0, i1 = int(np.argmax(a > lo)), int(np.argmax(a > hi))
+    assert i1 - i0 > 400, (i0, i1)
+    return np.polyfit(np.arange(i0, i1) * dt, np.log(a[i0:i1]), 1)[0]
+
+
+def test_two_stream_instability_grows_at_half_the_beam_plasma_frequency(oracle):
+    """The workload of the headline benchmark as a known answer: for two equal cold beams
+    1 = omega_b^2 [1/(omega - k v0)^2 + 1/(omega + k v0)^2] has its fastest-growing root Im omega = omega_b / 2 at
+    k v0 = (sqrt 3 / 2) omega_b.  Seven e-foldings of the seeded mode's Ex amplitude, fitted: 1 %."""
+    o = oracle
+    nx, dx, m = 256, 4.0e-9, 3
+    dt = 0.95 * dx / C
+    st, wb = _two_cold_beams(nx, dx, m, 32, 0.2, 1e-7)
+    g = o.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    pe = o.Population.from_soa(o.ELECTRON, *st, dx, dt)
+    kx = 2.0 * np.pi * m * (np.arange(nx) + 0.5) / nx
+    steps = 2200
+    a = np.empty(steps)
+    for i in range(steps):
+        pe.advance(g, dt, 4)
+        g.clear()
+        g.deposit(pe, dt, 4)
+        g.synchronize(None, None, 0.0, dt)
+        g.advance(dt)
+        ex = g.raw("Ex")[L:L + nx]
+        a[i] = np.hypot(np.sum(ex * np.sin(kx)), np.sum(ex * np.cos(kx))) * 2.0 / nx
+    assert np.max(a) > 1e6 * a[0]
+    assert abs(growth_rate(a, dt) / (0.5 * wb) - 1.0) < 1e-2
