@@ -368,3 +368,76 @@ def test_two_stream_instability_grows_at_half_the_beam_plasma_frequency(oa, fuse
     assert np.max(a) > 1e6 * a[0]
     assert abs(growth_rate(a, dt) / (0.5 * wb) - 1.0) < 1e-2
     assert pe.counters()["tile_misses"] >= 0 and len(pe) == 2 * 32 * nx
+
+
+# ------------------------------------------------------------------ photon emission against synchrotron theory
+ALPHA_FINE = 7.29735257e-3     # constants.rs:24
+COMPTON_TIME = 1.28808867e-21  # constants.rs:26
+CRITICAL_FIELD = 1.323285e18   # constants.rs:22
+
+
+def _quantum_power_factor(chi):
+    """g(chi) = radiated power / classical power of quantum synchrotron emission (Baier & Katkov; e.g. Ridgers et al.,
+    J. Comput. Phys. 260 (2014) eq. 6), by quadrature: g -> 1 for chi -> 0."""
+    from scipy import integrate, special
+    f = lambda y: (2.0 * y * y * special.kv(5.0 / 3.0, y) / (2.0 + 3.0 * chi * y) ** 2
+                   + 36.0 * chi * chi * y ** 3 * special.kv(2.0 / 3.0, y) / (2.0 + 3.0 * chi * y) ** 4)
+    return 9.0 * np.sqrt(3.0) / (8.0 * np.pi) * integrate.quad(f, 0.0, np.inf, limit=400)[0]
+
+
+@pytest.mark.parametrize("chi0,dt,tol", [(0.005, 1.0e-16, 0.01), (0.1, 1.0e-17, 0.015), (1.0, 2.5e-18, 0.015)])
+def test_radiated_power_is_the_synchrotron_power(oa, chi0, dt, tol):
+    """The emission chain closed on physics (no oracle): 1e5 electrons of gamma = 1000 gyrating in a static B with quantum
+    parameter chi0 -- push (chi from the fields, electron.rs:282-288; optical depth run down), emit_radiation (rate,
+    spectrum, recoil, new optical depth), three emissions each.  What must come out:
+    * chi on the first step is gamma |v x B| / E_crit;
+    * the photons carry what the electrons lost (B does no work), to 1 / gamma^2;
+    * the number of photons is the time integral of the rate over the electrons' actual chi and gamma (Poisson: 0.2 %),
+      less the second emissions a step cannot hold (W dt / 2 <= 0.8 %);
+    * the radiated energy is the time integral of the synchrotron power (2/3) alpha chi^2 m c^2 / tau_C times g(chi):
+      g by quadrature of the quantum spectrum for chi >= 0.01; below that the reference pairs the first-order rate
+      1 - 8 chi / (5 sqrt 3) (photon_emission.rs:61-62) with the classical spectrum mapped u -> u / (1 + u)
+      (photon_emission.rs:139-142, 264-292), which takes <u^2> / <u> = (55 sqrt 3 / 48) chi off the mean photon energy
+      (4 sqrt 3 / 15) chi gamma m c^2: its g is (1 - 0.924 chi)(1 - 1.985 chi), not the exact 1 - 5.95 chi, and that is what
+      is asked for (measured: 0.9864 of the classical power at chi = 0.005, model 0.9855)."""
+    n, gamma0, per_electron = 100_000, 1000.0, 3.0
+    nx = 64
+    dx = 2.0 * C * dt
+    g = oa.Grid.single(nx, 0.0, dx)
+    g.set_raw("Bz", np.full(g.len, chi0 * CRITICAL_FIELD / (gamma0 * C)))
+    rng = np.random.default_rng(1)
+    cell = np.sort(rng.integers(0, nx, n)).astype(np.int32)
+    z = np.zeros(n)
+    p = oa.Population(oa.ELECTRON, n)
+    p.track_extras(2)
+    p.upload(cell, rng.random(n), np.full(n, -np.sqrt(gamma0 ** 2 - 1.0)), z, z, np.ones(n), dx, dt)
+    p.set_emission_state(rng.exponential(size=n), np.arange(n, dtype=np.uint64))
+    ph = oa.Population(oa.PHOTON, 1024)
+    ph.track_extras(1)
+    ke0 = p.total_kinetic_energy()
+    if chi0 < 0.01:
+        factor = lambda chi: (1.0 - 8.0 * chi / (5.0 * np.sqrt(3.0))) * (1.0 - 55.0 * np.sqrt(3.0) / 48.0 * chi)
+    else:
+        lc = np.linspace(np.log(chi0 / 100.0), np.log(chi0 * 1.01), 48)
+        gg = np.array([_quantum_power_factor(np.exp(v)) for v in lc])
+        factor = lambda chi: np.interp(np.log(np.maximum(chi, 1e-300)), lc, gg)
+    mc2 = M_E_MEV * 1.0e6 * E_CHARGE
+    w0 = float(oa.qed_rate(np.array([chi0]), np.array([gamma0]))[0])
+    assert w0 * dt < 0.016
+    steps = int(per_electron / (w0 * dt))
+    energy = count = 0.0
+    for s in range(steps):
+        p.advance(g, dt)
+        chi = p.extras()["chi"]
+        if s == 0:
+            assert abs(chi.mean() / chi0 - 1.0) < 2e-5 and chi.std() < 1e-6 * chi0
+        u = p.soa()
+        gam = np.sqrt(1.0 + u["ux"] ** 2 + u["uy"] ** 2 + u["uz"] ** 2)
+        energy += np.sum((2.0 / 3.0) * ALPHA_FINE * chi ** 2 * mc2 / COMPTON_TIME * factor(chi)) * dt
+        count += np.sum(oa.qed_rate(chi, gam)) * dt
+        oa.emit_radiation(p, ph, seed=5, step=s, t=s * dt, count=False)
+    lost, radiated = ke0 - p.total_kinetic_energy(), ph.total_kinetic_energy()
+    assert abs(radiated / lost - 1.0) < 1e-5
+    assert len(ph) > 2.5 * n
+    assert -0.012 < len(ph) / count - 1.0 < 0.004, len(ph) / count
+    assert abs(radiated / energy - 1.0) < tol, radiated / energy
