@@ -150,3 +150,72 @@ def test_photon_r_and_chi_histograms(oracle):
             assert abs(h["min"][d] - ref["min"][d]) <= 1e-9 * max(abs(ref["max"][d]), 1e-300), (spec, d)
         scale = np.max(ref["cts"])
         assert np.sum(np.abs(h["cts"] - ref["cts"]) > 1e-9 * scale) <= 6, spec
+
+
+# ----------------------------------------------------------------------------- known answers without the oracle
+# The reference's own histogram tests are #[ignore]d (they need an MPI launch); what they assert -- one point gives a
+# histogram, no points give none (hgram.rs:437-505) -- and what hgram.rs:131-143, 168-262 state is checked here
+# against numpy on values placed by hand.
+def _px_population(oa, ux, w, nx=16, dx=1.0e-8):
+    dt = 0.95 * dx / C
+    n = len(ux)
+    cell = np.sort(np.arange(n) % nx).astype(np.int32)
+    z = np.zeros(n)
+    return oa.Grid.single(nx, 0.0, dx), oa.Population.from_soa(0, cell, np.full(n, 0.5), ux, z, z, w, dx, dt)
+
+
+def test_one_point_gives_a_histogram_and_no_points_give_none():
+    """hgram.rs:437-461 (single_2d), :489-505 (empty_2d); min == max: one bin of volume 1 (hgram.rs:131-134, 202-204)."""
+    import opal_amd as oa
+    g, p = _px_population(oa, np.array([0.3]), np.array([7.0]))
+    for spec, nb in (("px", [1, 1]), ("x:px", [1, 1]), ("energy:(log;energy)", [1, 1])):
+        h = p.histogram(g, spec)
+        assert h is not None and h["nbins"] == nb and len(h["cts"]) == 1
+        assert np.all(h["bin_sz"][:h["dim"]] == 0.0)       # hgram.rs:253: a single bin reports size 0
+        assert h["cts"][0] > 0.0
+    h = p.histogram(g, "px")
+    assert h["total"] == 7.0 and h["cts"][0] == 7.0        # density with bin volume 1
+    e = np.zeros(0)
+    g, p = _px_population(oa, e, e)
+    for spec in ("px", "x:px", "energy:(log;energy)"):
+        assert p.histogram(g, spec) is None
+
+
+def test_fixed_and_automatic_bins_against_numpy():
+    """BinSpec::FixedSize / FixedNumber / Automatic (hgram.rs:131-143), the bin of a value (:215), HeightSpec::Density
+    (:247), the weight summed whether binned or not (:222), the maximum -- on the last edge -- dropped by `fbin < len`
+    (:236) when the bins divide the range exactly.  px is in MeV/c (mod.rs: px = u * 0.510999)."""
+    import opal_amd as oa
+    MEV = 0.510999
+    rng = np.random.default_rng(3)
+    n = 5000
+    lo, hi, size = -2.4, 2.45, 0.25                       # range 4.85: ceil(19.4) = 20 bins of the fixed size
+    k = rng.integers(0, 19, n)
+    v = lo + (k + rng.uniform(0.05, 0.95, n)) * size      # well inside their bins
+    v[0], v[1] = lo, hi
+    ux = v / MEV
+    v = ux * MEV                                          # what the accessor will compute
+    w = 1.0 + rng.random(n)
+    g, p = _px_population(oa, ux, w)
+    h = p.histogram(g, "px:(0.25;weight)")
+    assert h["nbins"][0] == 20 and h["bin_sz"][0] == size
+    assert abs(h["min"][0] - v.min()) < 1e-15 and abs(h["max"][0] - v.max()) < 1e-15
+    want = np.bincount(np.floor((v - v.min()) / size).astype(int), weights=w, minlength=20) / size
+    assert np.max(np.abs(h["cts"] - want)) <= 1e-12 * np.max(want)
+    assert abs(h["total"] - np.sum(w)) <= 1e-12 * np.sum(w)
+    # fixed number 17 and automatic ceil(2 n^(1/3)) = 35: the range divided exactly, so the maximum sits on the last
+    # edge and is not binned -- but is counted in the total
+    for spec, nb in (("px:(17;weight)", 17), ("px", int(np.ceil(2.0 * n ** (1.0 / 3.0))))):
+        h = p.histogram(g, spec)
+        assert h["nbins"][0] == nb
+        bs = (v.max() - v.min()) / nb
+        assert abs(h["bin_sz"][0] / bs - 1.0) < 1e-14
+        idx = np.floor((v - v.min()) / bs).astype(int)
+        safe = np.abs((v - v.min()) / bs - np.round((v - v.min()) / bs)) > 1e-9   # not within rounding of an edge
+        safe[1] = False
+        want = np.bincount(idx[safe], weights=w[safe], minlength=nb + 1)[:nb] / bs
+        slack = np.bincount(np.clip(idx[~safe], 0, nb - 1), weights=w[~safe], minlength=nb)[:nb] / bs
+        slack = slack + np.roll(slack, 1) + np.roll(slack, -1)
+        assert np.all(np.abs(h["cts"] - want) <= slack + 1e-12 * np.max(want))
+        assert abs(np.sum(h["cts"]) * bs - (np.sum(w) - w[1])) <= 1e-9 * np.sum(w)
+        assert abs(h["total"] - np.sum(w)) <= 1e-12 * np.sum(w)
