@@ -118,10 +118,23 @@ def main():
     oa.set_device(0)
     # OPAL_TEST_LINK=peer: peer-mapped mailboxes between the processes (hipIpc handles travel over gloo once; the
     # kernels of the step then exchange by themselves) instead of host-staged gloo messages
-    peer = os.environ.get("OPAL_TEST_LINK", "gloo") == "peer"
-    Link = PeerLink if peer else TorchLink
-    link = Link(rank, world, torch.device("cpu"), particle_capacity=128 if mode != "qed" else 1024,
-                photon_emission=mode == "qed") if world > 1 else None
+    kind = os.environ.get("OPAL_TEST_LINK", "gloo")
+    cap = 128 if mode != "qed" else 1024
+    if world == 1:
+        link = None
+    elif kind == "auto":
+        # what bench.py and the launcher do: the best transport that comes up on EVERY subdomain (with
+        # OPAL_PEER_ALLOC=none the mailboxes cannot be allocated anywhere, with OPAL_TEST_BREAK_RANK=r only there)
+        from opal_amd.exchange import make_link
+        if os.environ.get("OPAL_TEST_BREAK_RANK") == str(rank):
+            os.environ["OPAL_PEER_ALLOC"] = "none"
+        notes = []
+        link, got = make_link(rank, world, torch.device("cpu"), cap, photon_emission=mode == "qed", log=notes.append)
+        with open(os.path.join(outdir, f"link_kind_{rank}.txt"), "w") as f:
+            f.write(got + "\n" + "\n".join(notes))
+    else:
+        Link = PeerLink if kind == "peer" else TorchLink
+        link = Link(rank, world, torch.device("cpu"), particle_capacity=cap, photon_emission=mode == "qed")
     dx = 1.0e-8
     dt = 0.95 * dx / C
     if mode == "grow":

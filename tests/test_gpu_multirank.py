@@ -72,6 +72,44 @@ def test_ops_with_link_match_oracle_decomposition(oracle, tmp_path, world, fused
     assert total == nx * npc
 
 
+@pytest.mark.parametrize("broken", ["nowhere", "everywhere", "rank1"])
+def test_make_link_keeps_a_transport_only_if_it_came_up_everywhere(oracle, tmp_path, monkeypatch, broken):
+    """exchange.make_link, what bench.py and the launcher call: the mailboxes where they work; where they cannot be set
+    up -- on every subdomain, or on ONE of three while the others could -- all subdomains agree on the next transport
+    together (nobody is left waiting in a mailbox for a neighbour that went another way) and the run gives the
+    oracle's numbers either way."""
+    o = oracle
+    world, fused = 3, 1
+    nx, npc, steps = 48, 12, 12
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    monkeypatch.setenv("OPAL_TEST_LINK", "auto")
+    if broken == "everywhere":
+        monkeypatch.setenv("OPAL_PEER_ALLOC", "none")
+    elif broken == "rank1":
+        monkeypatch.setenv("OPAL_TEST_BREAK_RANK", "1")
+    _launch("_gloo_hip_worker.py", world, ["ops", tmp_path, nx, npc, steps, fused])
+    kinds = [open(os.path.join(tmp_path, f"link_kind_{r}.txt")).read().split("\n") for r in range(world)]
+    assert len({k[0] for k in kinds}) == 1, kinds           # the same transport on every subdomain
+    assert kinds[0][0] == ("peer" if broken == "nowhere" else "gloo"), kinds
+    if broken != "nowhere":
+        assert "trying the next transport" in "\n".join(kinds[0]) and ("subdomain 1" in kinds[0][1] or broken == "everywhere")
+    nxs, _ = o.design_unbalanced(world, nx, dx)
+    se, si = global_state(nx, npc, dx, 5), global_state(nx, npc, dx, 6)
+    grids, pes, pis = _oracle_world(o, world, nx, dx, dt, [split(se, nxs, r) for r in range(world)],
+                                    [split(si, nxs, r) for r in range(world)], steps)
+    for r in range(world):
+        got = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        for k in COMPS:
+            ref = grids[r].raw(k)
+            assert np.max(np.abs(got[k] - ref)) / max(np.max(np.abs(ref)), 1e-300) < 1e-9, (r, k)
+        for name, p in (("e", pes[r]), ("i", pis[r])):
+            ref = p.soa()
+            order = np.argsort(ref["w"], kind="stable")
+            a = _by_w(got, name)
+            assert np.array_equal(a["w"], ref["w"][order]) and np.array_equal(a["cell"], ref["cell"][order].astype(np.int32))
+
+
 @pytest.mark.parametrize("world,fused,nx,mode", [(2, 1, 64, "sim"), (2, 0, 64, "sim"), (2, 1, 512, "sim"), (3, 1, 768, "sim"),
                                                  (2, 1, 64, "sim_es"), (3, 1, 768, "sim_es"), (2, 1, 512, "sim_half")])
 def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx, mode, link_kind):
