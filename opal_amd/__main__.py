@@ -58,6 +58,11 @@ def main(argv):
                             stream=torch.cuda.current_stream().cuda_stream)
         if rank == 0:
             print(f"Running {world} task{'s' if world > 1 else ''} on {world} GPU{'s' if world > 1 else ''}...")
+        if world > 1:
+            # the waits of the step's exchange are bounded (20 s): start together, however long each subdomain's
+            # loader took
+            torch.cuda.synchronize()
+            dist.barrier()
         sim.run()
     except oa.OpalError as e:
         # No barrier here: the peers are still inside opal_sim_run issuing send/recv and all-reduces to this

@@ -119,6 +119,7 @@ def main():
     # OPAL_TEST_LINK=peer: peer-mapped mailboxes between the processes (hipIpc handles travel over gloo once; the
     # kernels of the step then exchange by themselves) instead of host-staged gloo messages
     kind = os.environ.get("OPAL_TEST_LINK", "gloo")
+    peer = kind == "peer"
     cap = 128 if mode != "qed" else 1024
     if world == 1:
         link = None
@@ -130,6 +131,7 @@ def main():
             os.environ["OPAL_PEER_ALLOC"] = "none"
         notes = []
         link, got = make_link(rank, world, torch.device("cpu"), cap, photon_emission=mode == "qed", log=notes.append)
+        peer = got == "peer"
         with open(os.path.join(outdir, f"link_kind_{rank}.txt"), "w") as f:
             f.write(got + "\n" + "\n".join(notes))
     else:
