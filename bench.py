@@ -173,12 +173,13 @@ REHEAT_STEPS = int(os.environ.get("OPAL_BENCH_REHEAT", "40"))
 
 
 def lp_link_capacity(npc):
-    """Room in a laser-plasma link for the leavers of one step through one cut, per species: what sits within c dt = 0.95
-    cells of the cut and moves towards it.  The hole-boring front piles the electrons up to tens of times the slab's
-    density before it reaches a cut, so 2 npc (a front at the initial density) overflows -- reported as an error, as it
-    was at 4 and 6 subdomains with 1e8 particles; 32 npc is room for a 30-fold pile-up (what travels is still only the
-    actual leavers: capacity costs mailbox memory, 2 x 17 MB per cut at npc = 10 000)."""
-    return max(4096, 32 * npc)
+    """Room in a laser-plasma link for the leavers of one step through one cut, per species: at most the occupants of
+    the cell next to the cut (nobody moves a whole cell per step).  The hole-boring front piles the particles up:
+    scripts/lp_pileup_probe.py finds up to 41 (electrons) / 56 (ions) times the initial particles per cell in one cell
+    during the interaction, so 2 npc (a front at the initial density) and then 32 npc overflowed -- reported as the
+    error it is -- at 4, 5 and 6 subdomains with 1e8 particles.  128 npc; what travels is still only the actual
+    leavers: capacity costs mailbox memory (0.5 GB per subdomain at npc = 10 000)."""
+    return int(os.environ.get("OPAL_BENCH_LP_CAPACITY") or max(4096, 128 * npc))
 
 
 def src_sha():

@@ -35,15 +35,15 @@ def main(argv):
         emission, absorption = cfg.read_bool("qed", "photon_emission"), cfg.read_bool("qed", "photon_absorption")
         # room in the buffers for the leavers of one step through one cut, per species (an overflow is reported as an
         # error); what travels each step is sized to the particles within 3 cells of each cut, not to this
-        # (a relativistic front piles the particles up to tens of times the initial density before it meets a cut: room
-        # for 32 cells' worth of the densest species, at least 65536)
+        # (a hole-boring front piles the particles up to ~50 times the initial density before it meets a cut --
+        # scripts/lp_pileup_probe.py --: room for 128 cells' worth of the densest species, at least 65536)
         npc = 0
         for sec in ("electrons", "ions"):
             try:
                 npc = max(npc, cfg.read_usize(sec, "npc")) if cfg.contains(sec) else npc
             except oa.OpalError:
                 pass  # (the run itself will report a malformed section)
-        cap = int(os.environ.get("OPAL_LINK_CAPACITY", str(max(65536, 32 * npc))))
+        cap = int(os.environ.get("OPAL_LINK_CAPACITY", str(max(65536, 128 * npc))))
         stream = torch.cuda.current_stream().cuda_stream
         open_ends = cfg.contains("laser")  # laser + absorbing boundaries: the first and last subdomain have one neighbour
         want = os.environ.get("OPAL_LINK")

@@ -25,8 +25,9 @@
 // sizes each edge to the SUM of the two ends' counts plus LINK_SLACK (link_plan has the argument).  Both ends of an
 // edge hold the same numbers, so they agree on the size without talking; a front that reaches a cut is seen LINK_ZONE
 // cells before it arrives.  Transports that cannot take a size per edge (opal_exchange_fn) keep shipping all
-// `particle_capacity` slots; so do links that carry stimulated emission, and peer links need none of it (the sending
-// kernel reads the leaver counts itself).
+// `particle_capacity` slots; so do links that carry stimulated emission.  A peer link's messages need no sizing (the
+// sending kernel reads the leaver counts itself), but the same bound is kept for it as plan_cap: it is the room the
+// populations reserve for a step's arrivals.
 // A halo-only exchange (opal_grid_synchronize) moves the first 704 bytes.
 // What a subdomain sends left arrives as its left neighbour's "recv_right".
 #include <hip/hip_runtime_api.h>
@@ -78,9 +79,15 @@ int link_plan(opal_link_t *l, unsigned species_mask)
 {
     const unsigned full = (unsigned)l->cap;
     l->send_cap[0] = l->send_cap[1] = full;
+    l->plan_cap[0] = l->plan_cap[1] = full;
     const unsigned X = l->xseq;
     l->ring_mask[X % LINK_RING] = species_mask;
-    if (!l->bounded || !l->exchange2 || !l->h_bounds || l->nfields >= 15) return OPAL_OK;
+    // A transport that is told a size per edge ships the bound; a peer link ships what leaves (its kernels read the
+    // counts), but the populations still need the bound -- it is what they reserve room for before each step's arrivals,
+    // and reserving the link's whole capacity every step would have a link sized for a pile-up (128 cells' worth of
+    // particles) blow the host's bound on the slots in use up by millions per step.
+    const bool sizes_messages = l->bounded && l->exchange2 && !link_is_peer(l);
+    if ((!sizes_messages && !link_is_peer(l)) || !l->h_bounds || l->nfields >= 15) return OPAL_OK;
     if (X < (unsigned)LINK_ZONE) return OPAL_OK;
     unsigned need[2] = {0, 0};
     auto entry_of = [&](int sp, const LinkBounds **out) -> int {  // most recent usable entry that counted species sp
@@ -126,7 +133,8 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     }
     for (int side = 0; side < 2; side++) {
         unsigned slots = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
-        l->send_cap[side] = slots < full ? slots : full;
+        l->plan_cap[side] = slots < full ? slots : full;
+        if (sizes_messages) l->send_cap[side] = l->plan_cap[side];
     }
     return OPAL_OK;
 }
@@ -227,6 +235,7 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
     l->layout.blk = LINK_ROWS * (unsigned)(sizeof(int32_t) + (size_t)fields_per_particle * sizeof(double));
     l->nbytes = link_prefix_bytes(l, (unsigned)particle_capacity);
     l->send_cap[0] = l->send_cap[1] = (unsigned)particle_capacity;
+    l->plan_cap[0] = l->plan_cap[1] = (unsigned)particle_capacity;
     l->bounded = true;  // takes effect once a per-edge transport is set (opal_link_set_exchange2, native links)
     OPAL_HIP(hipHostMalloc((void **)&l->h_bounds, sizeof(LinkBounds) * LINK_RING, hipHostMallocMapped | hipHostMallocCoherent));
     memset((void *)l->h_bounds, 0, sizeof(LinkBounds) * LINK_RING);

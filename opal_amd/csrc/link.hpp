@@ -75,6 +75,8 @@ struct opal_link {
     unsigned xseq;           // whole-message exchanges so far
     unsigned ring_mask[opal::LINK_RING];  // which species' pushes counted into exchange e's headers, at e % LINK_RING (link_plan)
     unsigned send_cap[2];    // slots (a multiple of 64) the next exchange ships per species: left / right edge
+    unsigned plan_cap[2];    // bound on the particles per species that can cross each edge in the next exchange (<= send_cap):
+                             // what the populations reserve room for (a peer link ships whatever leaves, up to `cap`)
     bool bounded;            // sizes follow the bounds (needs exchange2); else every exchange ships all `cap` slots
     size_t last_bytes[2];    // what the last whole-message exchange moved per edge (diagnostic)
     // peer-mapped mailboxes (peer.hip, peer_device.hpp): the kernels of the step move the messages themselves
@@ -99,6 +101,7 @@ bool link_can_use_stream(const opal_link_t *l, hipStream_t st);
 struct PeerArgs;
 struct HaloSrc;
 bool link_is_peer(const opal_link_t *l);
+void link_peer_zone(opal_link_t *l, unsigned done, unsigned **cur, const unsigned **prev, unsigned *prev_seq);
 // the arguments with which a kernel of the step makes the NEXT exchange itself (advances the link's sequence); halo
 // = where the halo is packed from, or null when the send messages already hold it
 int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, const HaloSrc *halo, PeerArgs &a);

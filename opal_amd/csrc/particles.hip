@@ -1179,6 +1179,12 @@ struct UnpackBatch {
     const unsigned *send_head[2], *recv_head[2];  // null where there is no neighbour
     LinkBounds *bounds;                            // ring entry of this exchange (mapped host memory), or null
     unsigned seq;
+    // peer links: this exchange's zone counts are parked in device memory (zone_cur: 6 mine, 6 theirs) and the PREVIOUS
+    // exchange's go to its ring entry from the first workgroup, off the launch's longest chain (peer.hip: link_peer_zone)
+    unsigned *zone_cur;
+    const unsigned *zone_prev;
+    LinkBounds *prev_bounds;
+    unsigned prev_seq;
 };
 
 __device__ void unpack_one(const UnpackArgs &a, int side);
@@ -1203,13 +1209,20 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
         peer_wait(b.peer);
     }
     if (boss) {
-        if (b.bounds && threadIdx.x < 6) {
+        if (threadIdx.x < 6 && (b.bounds || b.zone_cur)) {
             const int side = threadIdx.x / 3, sp = threadIdx.x % 3;
-            b.bounds->mine[side][sp] = b.send_head[side] ? b.send_head[side][LINK_H_ZONE + sp] : 0u;
-            b.bounds->theirs[side][sp] = b.recv_head[side] ? b.recv_head[side][LINK_H_ZONE + sp] : 0u;
+            const unsigned mine = b.send_head[side] ? b.send_head[side][LINK_H_ZONE + sp] : 0u;
+            const unsigned theirs = b.recv_head[side] ? b.recv_head[side][LINK_H_ZONE + sp] : 0u;
+            if (b.zone_cur) {
+                b.zone_cur[threadIdx.x] = mine;
+                b.zone_cur[6 + threadIdx.x] = theirs;
+            } else {
+                b.bounds->mine[side][sp] = mine;
+                b.bounds->theirs[side][sp] = theirs;
+            }
         }
         __syncthreads();
-        if (b.bounds && threadIdx.x == 0) {
+        if (b.bounds && !b.zone_cur && threadIdx.x == 0) {
             __threadfence_system();
             b.bounds->seq = b.seq;
         }
@@ -1221,6 +1234,18 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
     // (the policy's counters go out from workgroup 0: where another workgroup runs synchronize and the field solve's
     // edges -- the longest chain of the launch -- the ~2 us of the write to host memory are off it)
     if (blockIdx.x == 0 && b.pub.n) publish_counters(b.pub);
+    if (blockIdx.x == 0 && b.prev_bounds) {  // the previous exchange's zone counts (written by the launch before this one)
+        if (threadIdx.x < 6) {
+            const int side = threadIdx.x / 3, sp = threadIdx.x % 3;
+            b.prev_bounds->mine[side][sp] = b.zone_prev[threadIdx.x];
+            b.prev_bounds->theirs[side][sp] = b.zone_prev[6 + threadIdx.x];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            b.prev_bounds->seq = b.prev_seq;
+        }
+    }
     if (blockIdx.x >= n_unpack) {  // (only launched when has_sync)
         synchronize_body(b.sync);
         if (ADV && b.has_adv) advance_edges(b.adv, s_adv);  // the cells synchronize wrote, and their stencil neighbours
@@ -1540,8 +1565,9 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
         a.send_layout = link->layout;
         a.send_slot = slot;
         a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
-        // the particles next to a linked edge are counted for transports whose message sizes the host plans (link_plan)
-        a.zone = (link->bounded && link->exchange2 && !link_is_peer(link)) ? LINK_ZONE : 0;
+        // the particles next to a linked edge are counted for transports whose message sizes the host plans, and for
+        // peer links, where the same bound sizes the room the populations reserve for arrivals (link_plan)
+        a.zone = ((link->bounded && link->exchange2) || link_is_peer(link)) ? LINK_ZONE : 0;
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
     a.w_uniform = g_elision && p->w_uniform && p->species != OPAL_PHOTON;
@@ -1715,9 +1741,9 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g, bool wait = true);
 int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, UnpackArgs &u)
 {
     bool from_left = g->left_bdy == OPAL_BDY_INTERNAL, from_right = g->right_bdy == OPAL_BDY_INTERNAL;
-    // at most what this step's messages ship per species (link_plan): the host's bound on the slots in use grows by
-    // that much, not by the link's full capacity
-    size_t incoming = (from_left ? (size_t)link->send_cap[0] : 0) + (from_right ? (size_t)link->send_cap[1] : 0);
+    // at most what can cross each edge in this step per species (link_plan): the host's bound on the slots in use grows
+    // by that much, not by the link's full capacity
+    size_t incoming = (from_left ? (size_t)link->plan_cap[0] : 0) + (from_right ? (size_t)link->plan_cap[1] : 0);
     // the host only knows that at most `incoming` particles arrive per step; counter snapshots that land a
     // step or two later pull its bound on the slots in use back down to the true count
     if (int rc = opal::pop_tighten_upper(p)) return rc;
@@ -1814,13 +1840,19 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.zero[0] = reinterpret_cast<unsigned *>(link_send(link, 0));
         b.zero[1] = reinterpret_cast<unsigned *>(link_send(link, 1));
     }
-    if (link->d_bounds && link->xseq && !link_is_peer(link)) {  // the exchange just made is number xseq - 1
+    if (link->d_bounds && link->xseq) {  // the exchange just made is number xseq - 1
         for (int side = 0; side < 2; side++) {
             b.send_head[side] = nb[side] ? reinterpret_cast<const unsigned *>(link_send(link, side)) : nullptr;
-            b.recv_head[side] = nb[side] ? reinterpret_cast<const unsigned *>(link_recv(link, side)) : nullptr;
+            // (a peer exchange made by this very launch leaves the neighbour's message in the mailbox)
+            const char *got = peer_exchange ? (b.peer.box[side] ? b.peer.box[side] + PEER_FLAG_BYTES : nullptr) : link_recv(link, side);
+            b.recv_head[side] = nb[side] && got ? reinterpret_cast<const unsigned *>(got) : nullptr;
         }
         b.bounds = &link->d_bounds[(link->xseq - 1) % LINK_RING];
         b.seq = link->xseq;
+        if (link_is_peer(link)) {
+            link_peer_zone(link, link->xseq - 1, &b.zone_cur, &b.zone_prev, &b.prev_seq);
+            if (b.prev_seq) b.prev_bounds = &link->d_bounds[(b.prev_seq - 1) % LINK_RING];
+        }
     }
     const unsigned nblk = (b.n ? 2 * b.n : 1) + b.has_sync;
     if (b.has_adv) k_link_tail<ADV_TILE, true><<<nblk + grid_interior_tiles(b.adv), ADV_TILE, 0, st>>>(b);
