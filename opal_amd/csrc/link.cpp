@@ -75,6 +75,10 @@ int link_begin(opal_link_t *l, hipStream_t st, unsigned species_mask)
 // per electron and step at most: need(photons) += LINK_ZONE x need(electrons).  Stimulated emission (15 fields) has
 // no such bound (several photons may copy themselves off one electron): those links ship every slot.  No usable entry
 // in the ring (start-up; more than LINK_RING - LINK_ZONE exchanges since the species was last counted): every slot.
+// A peer link (whose messages need no sizing: plan_cap only, the room populations reserve) counts LINK_PEER_ZONE cells
+// and files every LINK_PEER_EVERY-th exchange: the same argument with an entry up to LINK_PEER_ZONE exchanges old (a
+// caller that exchanges species by species over such a link finds entries for the species of those exchanges only; the
+// others reserve the link's capacity).
 int link_plan(opal_link_t *l, unsigned species_mask)
 {
     const unsigned full = (unsigned)l->cap;
@@ -90,10 +94,15 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     if ((!sizes_messages && !link_is_peer(l)) || !l->h_bounds || l->nfields >= 15) return OPAL_OK;
     if (X < (unsigned)LINK_ZONE) return OPAL_OK;
     unsigned need[2] = {0, 0};
+    // (a peer link files every LINK_PEER_EVERY-th exchange only and counts LINK_PEER_ZONE cells: see link.hpp)
+    const bool peer = link_is_peer(l);
+    const unsigned zone_cells = peer ? (unsigned)LINK_PEER_ZONE : (unsigned)LINK_ZONE;
     auto entry_of = [&](int sp, const LinkBounds **out) -> int {  // most recent usable entry that counted species sp
         *out = nullptr;
-        for (unsigned e = X - LINK_ZONE;; e--) {
-            if (X - e >= (unsigned)LINK_RING) break;  // overwritten since (or about to be)
+        unsigned e = X - LINK_ZONE;
+        if (peer) e -= e % LINK_PEER_EVERY;
+        for (;; e -= peer ? LINK_PEER_EVERY : 1) {
+            if (X - e >= (unsigned)LINK_RING || X - e > zone_cells) break;  // overwritten since (or about to be), or too old
             if (l->ring_mask[e % LINK_RING] & (1u << sp)) {
                 const LinkBounds *b = &l->h_bounds[e % LINK_RING];
                 // Written by the unpack kernel of exchange e, at least LINK_ZONE exchanges ago: normally there already.
@@ -112,7 +121,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
                 *out = b;
                 return OPAL_OK;
             }
-            if (e == 0) break;
+            if (e < (peer ? (unsigned)LINK_PEER_EVERY : 1u)) break;
         }
         return OPAL_OK;
     };
@@ -127,7 +136,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
         if (!b || (sp == 2 && qed && !be)) return OPAL_OK;  // no history to go by: every slot
         for (int side = 0; side < 2; side++) {
             unsigned n = b->mine[side][sp] + b->theirs[side][sp];
-            if (sp == 2 && qed) n += (unsigned)LINK_ZONE * (be->mine[side][0] + be->theirs[side][0]);
+            if (sp == 2 && qed) n += zone_cells * (be->mine[side][0] + be->theirs[side][0]);
             need[side] = need[side] > n ? need[side] : n;
         }
     }

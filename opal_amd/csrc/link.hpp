@@ -6,9 +6,16 @@ namespace opal {
 constexpr size_t LINK_HEADER_BYTES = 64;
 constexpr size_t LINK_HALO_BYTES = 80 * sizeof(double);
 constexpr size_t LINK_HEAD_BYTES = LINK_HEADER_BYTES + LINK_HALO_BYTES;  // 704
-// header words (uint32): [0, 3) leavers per species slot, [4, 7) particles per species within LINK_ZONE cells of the
-// edge the message crosses after this step's push (an upper bound on the leavers LINK_ZONE steps from now)
+// header words (uint32): [0, 3) leavers per species slot; [4, 7) and [8, 11) particles per species within LINK_ZONE cells
+// of the edge the message crosses after this step's push (an upper bound on the leavers LINK_ZONE steps from now) -- two
+// sets, used by exchange number parity: the push before exchange X counts into set X & 1, the tail of exchange X reads
+// that set (any of its workgroups, at any time: nobody writes it then) and zeroes the other one for the next push
 constexpr int LINK_H_COUNT = 0, LINK_H_ZONE = 4;
+constexpr int link_h_zone(unsigned exchange) { return LINK_H_ZONE + 4 * (int)(exchange & 1u); }
+// peer links (peer.hip) use the bound only for the room the populations reserve, and pay for every write to host memory
+// at the end of the tail kernel (~1 us): they count a wider zone and file it with the host every LINK_PEER_EVERY-th
+// exchange only -- an entry is then at most LINK_ZONE + LINK_PEER_EVERY - 1 <= LINK_PEER_ZONE exchanges old when it is used
+constexpr int LINK_PEER_ZONE = 8, LINK_PEER_EVERY = 4;
 constexpr int LINK_ZONE = 3;        // cells; also the lag (in exchanges) with which message sizes follow the bound
 constexpr unsigned LINK_ROWS = 64;  // particles per row block
 constexpr unsigned LINK_SLACK = 64; // slots beyond the bound (nothing relies on it: the bound itself is rigorous, link_plan)
@@ -101,7 +108,6 @@ bool link_can_use_stream(const opal_link_t *l, hipStream_t st);
 struct PeerArgs;
 struct HaloSrc;
 bool link_is_peer(const opal_link_t *l);
-void link_peer_zone(opal_link_t *l, unsigned done, unsigned **cur, const unsigned **prev, unsigned *prev_seq);
 // the arguments with which a kernel of the step makes the NEXT exchange itself (advances the link's sequence); halo
 // = where the halo is packed from, or null when the send messages already hold it
 int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, const HaloSrc *halo, PeerArgs &a);

@@ -99,6 +99,7 @@ struct PushArgs {
     double dt, dt_over_dx, inv_dt, inv_dx, alpha, charge;
     int left_mode, right_mode;
     int zone;  // cells from a linked edge within which particles are counted into the message header (link_plan); 0: nobody asks
+    int zone_word;  // ... into this word of the header: this exchange's set (link_h_zone) + the species slot
     PopCounters *ctr;
     // leavers (EDGE_SEND) go into the link's send messages (layout: link.hpp): header words + row blocks
     char *send_msg[2];
@@ -333,9 +334,9 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             // (a.zone = 0 where there is no linked edge, or its transport does not plan message sizes: no lane passes)
             if (__ballot(newc < a.zone || newc >= a.size - a.zone)) {
                 if (a.left_mode == EDGE_SEND && newc < a.zone)
-                    atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + LINK_H_ZONE + a.send_slot, 1u);
+                    atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + a.zone_word, 1u);
                 if (a.right_mode == EDGE_SEND && newc >= a.size - a.zone)
-                    atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + LINK_H_ZONE + a.send_slot, 1u);
+                    atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + a.zone_word, 1u);
             }
             if (__ballot(newc != c_mem)) stk(cp.cell, kc, newc);
             stk(cp.x, kc, xn);
@@ -801,9 +802,9 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
         }
         if (!deleted && send_side < 0) {
             if (a.left_mode == EDGE_SEND && newc < a.zone)
-                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + LINK_H_ZONE + a.send_slot, 1u);
+                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + a.zone_word, 1u);
             if (a.right_mode == EDGE_SEND && newc >= a.size - a.zone)
-                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + LINK_H_ZONE + a.send_slot, 1u);
+                atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + a.zone_word, 1u);
             if (__ballot(newc != c)) stk(cellp, kc, newc);
             stk(xp, kc, xn);
         } else if (deleted) {
@@ -1179,12 +1180,7 @@ struct UnpackBatch {
     const unsigned *send_head[2], *recv_head[2];  // null where there is no neighbour
     LinkBounds *bounds;                            // ring entry of this exchange (mapped host memory), or null
     unsigned seq;
-    // peer links: this exchange's zone counts are parked in device memory (zone_cur: 6 mine, 6 theirs) and the PREVIOUS
-    // exchange's go to its ring entry from the first workgroup, off the launch's longest chain (peer.hip: link_peer_zone)
-    unsigned *zone_cur;
-    const unsigned *zone_prev;
-    LinkBounds *prev_bounds;
-    unsigned prev_seq;
+    int zone_at;                                   // header word of this exchange's zone counts (link_h_zone)
 };
 
 __device__ void unpack_one(const UnpackArgs &a, int side);
@@ -1208,42 +1204,28 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
         if (boss) peer_send(b.peer);  // (ends behind a barrier: the send messages have been read)
         peer_wait(b.peer);
     }
-    if (boss) {
-        if (threadIdx.x < 6 && (b.bounds || b.zone_cur)) {
-            const int side = threadIdx.x / 3, sp = threadIdx.x % 3;
-            const unsigned mine = b.send_head[side] ? b.send_head[side][LINK_H_ZONE + sp] : 0u;
-            const unsigned theirs = b.recv_head[side] ? b.recv_head[side][LINK_H_ZONE + sp] : 0u;
-            if (b.zone_cur) {
-                b.zone_cur[threadIdx.x] = mine;
-                b.zone_cur[6 + threadIdx.x] = theirs;
-            } else {
-                b.bounds->mine[side][sp] = mine;
-                b.bounds->theirs[side][sp] = theirs;
-            }
-        }
-        __syncthreads();
-        if (b.bounds && !b.zone_cur && threadIdx.x == 0) {
-            __threadfence_system();
-            b.bounds->seq = b.seq;
-        }
-        if (threadIdx.x < 16) {
-            if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
-            if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
-        }
+    if (boss && threadIdx.x < 16 && (threadIdx.x < b.zone_at || threadIdx.x >= b.zone_at + 4)) {
+        // the leaver counts have been shipped, and the OTHER set of zone counts is the next push's; this exchange's set
+        // stays as it is until the next tail (the first workgroup is reading it)
+        if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
+        if (b.zero[1]) b.zero[1][threadIdx.x] = 0u;
     }
     // (the policy's counters go out from workgroup 0: where another workgroup runs synchronize and the field solve's
     // edges -- the longest chain of the launch -- the ~2 us of the write to host memory are off it)
     if (blockIdx.x == 0 && b.pub.n) publish_counters(b.pub);
-    if (blockIdx.x == 0 && b.prev_bounds) {  // the previous exchange's zone counts (written by the launch before this one)
+    if (blockIdx.x == 0 && b.bounds) {
+        // this exchange's zone counts -- mine from the send headers, the neighbours' from the received ones -- go to the
+        // link's ring in mapped host memory (link.cpp: link_plan) from the first workgroup: the write and its
+        // system-scope fence cost about a microsecond, which the workgroup that runs synchronize does not have
         if (threadIdx.x < 6) {
             const int side = threadIdx.x / 3, sp = threadIdx.x % 3;
-            b.prev_bounds->mine[side][sp] = b.zone_prev[threadIdx.x];
-            b.prev_bounds->theirs[side][sp] = b.zone_prev[6 + threadIdx.x];
+            b.bounds->mine[side][sp] = b.send_head[side] ? b.send_head[side][b.zone_at + sp] : 0u;
+            b.bounds->theirs[side][sp] = b.recv_head[side] ? b.recv_head[side][b.zone_at + sp] : 0u;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence_system();
-            b.prev_bounds->seq = b.prev_seq;
+            b.bounds->seq = b.seq;
         }
     }
     if (blockIdx.x >= n_unpack) {  // (only launched when has_sync)
@@ -1567,7 +1549,8 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
         a.send_nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
         // the particles next to a linked edge are counted for transports whose message sizes the host plans, and for
         // peer links, where the same bound sizes the room the populations reserve for arrivals (link_plan)
-        a.zone = ((link->bounded && link->exchange2) || link_is_peer(link)) ? LINK_ZONE : 0;
+        a.zone = link_is_peer(link) ? LINK_PEER_ZONE : (link->bounded && link->exchange2) ? LINK_ZONE : 0;
+        a.zone_word = link_h_zone(link->xseq) + slot;  // (the exchange this push packs for is number xseq)
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
     a.w_uniform = g_elision && p->w_uniform && p->species != OPAL_PHOTON;
@@ -1840,7 +1823,8 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.zero[0] = reinterpret_cast<unsigned *>(link_send(link, 0));
         b.zero[1] = reinterpret_cast<unsigned *>(link_send(link, 1));
     }
-    if (link->d_bounds && link->xseq) {  // the exchange just made is number xseq - 1
+    // the exchange just made is number xseq - 1; a peer link files every LINK_PEER_EVERY-th one only (link.hpp)
+    if (link->d_bounds && link->xseq && !(link_is_peer(link) && (link->xseq - 1) % LINK_PEER_EVERY)) {
         for (int side = 0; side < 2; side++) {
             b.send_head[side] = nb[side] ? reinterpret_cast<const unsigned *>(link_send(link, side)) : nullptr;
             // (a peer exchange made by this very launch leaves the neighbour's message in the mailbox)
@@ -1849,11 +1833,8 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         }
         b.bounds = &link->d_bounds[(link->xseq - 1) % LINK_RING];
         b.seq = link->xseq;
-        if (link_is_peer(link)) {
-            link_peer_zone(link, link->xseq - 1, &b.zone_cur, &b.zone_prev, &b.prev_seq);
-            if (b.prev_seq) b.prev_bounds = &link->d_bounds[(b.prev_seq - 1) % LINK_RING];
-        }
     }
+    b.zone_at = link_h_zone(link->xseq ? link->xseq - 1 : 0u);
     const unsigned nblk = (b.n ? 2 * b.n : 1) + b.has_sync;
     if (b.has_adv) k_link_tail<ADV_TILE, true><<<nblk + grid_interior_tiles(b.adv), ADV_TILE, 0, st>>>(b);
     else k_link_tail<256, false><<<nblk, 256, 0, st>>>(b);

@@ -16,8 +16,6 @@ struct opal_peer {
     size_t total = 0;                         // bytes of box_mem
     void *mapped[2] = {nullptr, nullptr};     // hipIpcOpenMemHandle mappings to close (null: the neighbour is in this process)
     unsigned *d_err = nullptr;
-    unsigned *d_zone = nullptr;  // 2 x 12 words: the zone counts of the last two exchanges (link_peer_zone)
-    unsigned zone_seq = 0;       // exchange number + 1 whose counts wait in d_zone to be filed with the host; 0: none
     unsigned seq = 0;          // exchanges made so far
     bool connected = false;
     int alloc_kind = 0;        // 0 uncached, 1 fine-grained, 2 plain device memory
@@ -98,26 +96,6 @@ int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, 
     return OPAL_OK;
 }
 
-// The zone counts of a peer link's exchanges reach the host ring one exchange late and from a workgroup that has
-// time for it: the workgroup that runs the exchange, synchronize and the field solve's edges (the longest chain of the
-// tail launch) only copies the twelve words of exchange e into device memory (*cur); the first workgroup of the NEXT
-// tail launch files them -- the write to host memory and its system-scope fence cost about a microsecond.
-// `done`: the number of the exchange this launch makes.  prev / prev_seq: what is waiting to be filed (null / 0: nothing).
-void link_peer_zone(opal_link_t *l, unsigned done, unsigned **cur, const unsigned **prev, unsigned *prev_seq)
-{
-    opal_peer *p = l->peer;
-    *cur = nullptr;
-    *prev = nullptr;
-    *prev_seq = 0;
-    if (!p || !p->d_zone) return;
-    if (p->zone_seq) {
-        *prev = p->d_zone + 12 * ((p->zone_seq - 1) & 1u);
-        *prev_seq = p->zone_seq;
-    }
-    *cur = p->d_zone + 12 * (done & 1u);
-    p->zone_seq = done + 1;
-}
-
 void link_peer_free(opal_link_t *l)
 {
     opal_peer *p = l->peer;
@@ -126,7 +104,6 @@ void link_peer_free(opal_link_t *l)
         if (p->mapped[s] && (s == 0 || p->mapped[1] != p->mapped[0])) hipIpcCloseMemHandle(p->mapped[s]);
     if (p->box_mem) hipFree(p->box_mem);
     if (p->d_err) hipFree(p->d_err);
-    if (p->d_zone) hipFree(p->d_zone);
     delete p;
     l->peer = nullptr;
 }
@@ -187,8 +164,6 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
     OPAL_HIP(hipMemset(p->box_mem, 0, total));
     OPAL_HIP(hipMalloc((void **)&p->d_err, sizeof(unsigned)));
     OPAL_HIP(hipMemset(p->d_err, 0, sizeof(unsigned)));
-    OPAL_HIP(hipMalloc((void **)&p->d_zone, 24 * sizeof(unsigned)));
-    OPAL_HIP(hipMemset(p->d_zone, 0, 24 * sizeof(unsigned)));
     OPAL_HIP(hipDeviceSynchronize());
     return OPAL_OK;
 }
