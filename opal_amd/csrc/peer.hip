@@ -148,7 +148,8 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
     opal_link_t *l = *out;
     l->user = l;
     l->exchange2 = peer_exchange2;
-    l->bounded = false;  // nothing to plan: the sending kernel ships what the leavers occupy
+    l->bounded = false;  // no message size to plan: the sending kernel ships what the leavers occupy (link_plan still
+                         // keeps plan_cap, the room the populations reserve for arrivals)
     opal_peer *p = new opal_peer();
     l->peer = p;
     p->stride = (PEER_FLAG_BYTES + l->nbytes + 255) / 256 * 256;
