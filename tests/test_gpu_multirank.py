@@ -361,10 +361,12 @@ dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 stream = torch.cuda.current_stream().cuda_stream
 out = {}
-for mode in ("wrap", "self", "native", "fixed", "peer"):
+for mode in ("wrap", "self", "native", "fixed", "peer", "peer_big"):
     link = None
     if mode == "peer":                                          # mailboxes written by the step's own kernels
         link = PeerLink(0, 1, dev, particle_capacity=512, stream=stream)
+    if mode == "peer_big":                                      # ... with room for a 64-fold pile-up in every message
+        link = PeerLink(0, 1, dev, particle_capacity=1 << 20, stream=stream)
     if mode == "self":
         link = TorchLink(0, 1, dev, particle_capacity=512)      # torch.distributed P2P callback
     if mode == "native":
@@ -391,8 +393,13 @@ for mode in ("wrap", "self", "native", "fixed", "peer"):
         s = p.soa(); o = np.lexsort((s["x"], s["ux"], s["w"]))
         out[mode][name] = {k: v[o] for k, v in s.items()}
     out[mode]["calls"] = getattr(link, "calls", 0)
-    if mode == "peer":
+    if mode in ("peer", "peer_big"):
         assert link.status()[1] == 25, link.status()           # one exchange per step, none timed out
+        # what a population reserves for a step's arrivals follows the particles near the cuts (link_plan's plan_cap:
+        # 16 per cell within 8 cells, both sides, both ends), not the link's capacity: with a million slots per message
+        # the host's bound on the slots in use would otherwise have run away by 2e6 a step
+        for p in (sim.electrons, sim.ions):
+            assert p.counters()["slots_upper"] - len(p) < 8192, (mode, p.counters(), len(p))
     elif link is not None:
         full = oa._lib.load().opal_link_message_bytes(link.h)
         moved = link.last_exchange_bytes()
@@ -400,10 +407,10 @@ for mode in ("wrap", "self", "native", "fixed", "peer"):
         # slack, in blocks of 64 -> 192 slots of the 512 (self, native); the fixed link ships all 16384
         assert moved[0] == moved[1] and ((moved[0] == full) if mode == "fixed" else (704 < moved[0] < full // 2)), (mode, moved, full)
     # the native link (and it alone here: TorchLink's RCCL ops are tied to torch's stream) takes the overlapped step
-    assert mode in ("fixed", "peer") or (sim.overlapped_steps >= 20) == (mode == "native"), (mode, sim.overlapped_steps)
+    assert mode in ("fixed", "peer", "peer_big") or (sim.overlapped_steps >= 20) == (mode == "native"), (mode, sim.overlapped_steps)
     del sim, link
 assert out["self"]["calls"] == 25, out["self"]["calls"]            # one exchange per step
-for mode in ("self", "native", "fixed", "peer"):
+for mode in ("self", "native", "fixed", "peer", "peer_big"):
     for k in ("Ex", "Ey", "Ez", "By", "Bz"):
         a, b = out[mode][k], out["wrap"][k]
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), (mode, k)
