@@ -776,31 +776,63 @@ def main():
         # (subdomains of different sizes, GridDesign::balanced), laser and absorbing ends, timed inside the interaction.
         # A second set of mailboxes (open ends, room for a relativistic front) is set up for it.  The two-stream line
         # above is complete at this point: whatever happens here -- an error on some subdomain, a transport that never
-        # returns -- the line is written, with the failure in it, and every rank leaves with status 0 once the
-        # deadline passes.
+        # returns -- the line is written, with the failure in it, and every rank leaves with status 0: at once
+        # where the failure is seen, within seconds elsewhere (the rendezvous store carries the news), at the deadline at the latest.
         import threading
         lp_npc, lp_warm, lp_steps = 10000, 21000, 2000
-        deadline = float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "480"))  # (below torch.distributed's own 600 s collective timeout)
+        deadline = float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300"))  # (well below torch.distributed's 600 s collective timeout)
         once = threading.Lock()
+        finished = threading.Event()
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:  # noqa: BLE001
+            store = None
+        ABORT = "opal_bench_lp_abort"
 
-        def give_up(why):
+        def give_up(why, tell=True):
             if not once.acquire(blocking=False):
                 return
+            if tell and store is not None:
+                # the other subdomains may sit in a collective that can no longer complete (RCCL does not notice a peer
+                # that left): tell them through the rendezvous store, which their watchdogs poll
+                try:
+                    store.set(ABORT, f"rank {rank}: {why}")
+                except Exception:  # noqa: BLE001
+                    pass
             if rank == 0:
                 out["laser_plasma_interaction"] = {"error": why}
                 write_line()
             print(f"[bench] rank {rank}: laser-plasma block abandoned: {why}", file=sys.stderr)
             sys.stderr.flush()
+            if rank == 0 and tell:
+                time.sleep(6.0)  # the store lives in this process: the others poll it every 2 s
             os._exit(0)
 
-        watchdog = threading.Timer(deadline, give_up, args=(f"did not finish within {deadline:.0f} s",))
-        watchdog.daemon = True
+        def watch():
+            t_end = time.monotonic() + deadline
+            unreachable = 0
+            while not finished.wait(2.0):
+                if time.monotonic() > t_end:
+                    give_up(f"did not finish within {deadline:.0f} s")
+                if store is not None:
+                    try:
+                        if store.check([ABORT]):
+                            give_up(store.get(ABORT).decode(), tell=False)
+                        unreachable = 0
+                    except Exception:  # noqa: BLE001
+                        unreachable += 1
+                        if unreachable >= 3 and rank != 0:
+                            give_up("the rendezvous store is gone: rank 0 has left", tell=False)
+
+        watchdog = threading.Thread(target=watch, daemon=True)
         watchdog.start()
         try:
             link = None
             link3, kind3 = make_link(rank, world, link_device, lp_link_capacity(lp_npc), stream=stream, to_left=rank != 0,
                                      to_right=rank != world - 1, prefer=order,
                                      log=lambda m_: print(m_.replace("[opal_amd]", "[bench]"), file=sys.stderr))
+            if os.environ.get("OPAL_BENCH_LP_FAIL_RANK") == str(rank):  # (rehearsing the failure path)
+                raise RuntimeError("failure requested through OPAL_BENCH_LP_FAIL_RANK")
             oa.set_elision(False)
             sim3 = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=lp_npc), rank=rank, numtasks=world, link=link3, stream=stream)
             sizes = [None] * world
@@ -820,7 +852,7 @@ def main():
         except BaseException as e:  # noqa: BLE001
             # the other subdomains may be waiting in a collective of the block: no further collective from here
             give_up(f"{type(e).__name__}: {e}")
-        watchdog.cancel()
+        finished.set()
         if not once.acquire(blocking=False):  # the watchdog fired while the block was finishing: it ends the process
             time.sleep(3600)
 
