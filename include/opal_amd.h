@@ -316,7 +316,8 @@ int opal_link_peer_connect(opal_link_t *l, const void *left_handle64, const void
 int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges);
 /* n halo-only exchanges with the neighbours on the link's stream: 0 if they completed and -- links with device buffers
  * -- every halo word that arrived is the one the neighbour on that side sent in that round (each round's halo names its
- * sender, side and round: a late, stale or torn message fails).  Collective in the sense that the neighbours must make
+ * sender, side and round: a late, stale or torn message fails); links with device buffers then make 4 n exchanges back
+ * to back (the cadence of a run) and one more checked round.  Collective in the sense that the neighbours must make
  * the same calls. */
 int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n);
 /* Ranks of the RCCL communicator behind a link made by opal_link_create_rccl (ncclCommCount): lets a caller

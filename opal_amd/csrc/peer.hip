@@ -253,7 +253,12 @@ int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n)
     auto pattern = [](int rank, int side, int round, int i) { return 1.0e6 * (rank + 1) + 1.0e4 * (side + 1) + 1.0e2 * round + i; };
     const int left = (l->rank - 1 + l->size) % l->size, right = (l->rank + 1) % l->size;
     double buf[ND];
-    for (int k = 0; k < n; k++) {
+    // ... n rounds one at a time, then 4 n exchanges back to back with nothing between them (the cadence of a run: the
+    // two mailboxes of a direction are reused without acknowledgement, peer_device.hpp), then one more checked round
+    for (int k = 0; k <= n; k++) {
+        if (k == n)
+            for (int q = 0; q < 4 * n; q++)
+                if (int rc = link_exchange_halo(l, to_left != 0, to_right != 0, l->stream)) return rc;
         for (int side = 0; side < 2; side++) {
             for (int i = 0; i < ND; i++) buf[i] = pattern(l->rank, side, k, i);
             OPAL_HIP(hipMemcpyAsync(link_send(l, side) + LINK_HEADER_BYTES, buf, sizeof buf, hipMemcpyHostToDevice, l->stream));

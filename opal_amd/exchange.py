@@ -244,8 +244,9 @@ class PeerLink:
         self.nbytes = self._lib.opal_link_message_bytes(h)
         self.world, self.group = world, group
 
-    def self_test(self, to_left=True, to_right=True, n=4):
-        """n halo-only exchanges with the neighbours; True only if they completed on EVERY subdomain (collective)."""
+    def self_test(self, to_left=True, to_right=True, n=8):
+        """n checked halo-only exchanges with the neighbours, 4 n back to back, one more checked; True only if all of
+        that went well on EVERY subdomain (collective)."""
         ok = self._lib.opal_link_self_test(self.h, 1 if to_left else 0, 1 if to_right else 0, n) == 0
         if self.world > 1:
             oks = [None] * self.world
