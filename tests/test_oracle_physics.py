@@ -183,3 +183,64 @@ def test_two_stream_instability_grows_at_half_the_beam_plasma_frequency(oracle):
         a[i] = np.hypot(np.sum(ex * np.sin(kx)), np.sum(ex * np.cos(kx))) * 2.0 / nx
     assert np.max(a) > 1e6 * a[0]
     assert abs(growth_rate(a, dt) / (0.5 * wb) - 1.0) < 1e-2
+
+
+# ------------------------------------------------------------------ photon emission against synchrotron theory
+ALPHA_FINE = 7.29735257e-3     # constants.rs:24
+COMPTON_TIME = 1.28808867e-21  # constants.rs:26
+CRITICAL_FIELD = 1.323285e18   # constants.rs:22
+M_E_MEV = 0.510999             # constants.rs:20
+
+
+def quantum_power_factor(chi):
+    """g(chi) = radiated power / classical power of quantum synchrotron emission, by quadrature (g -> 1 for chi -> 0)."""
+    from scipy import integrate, special
+    f = lambda y: (2.0 * y * y * special.kv(5.0 / 3.0, y) / (2.0 + 3.0 * chi * y) ** 2
+                   + 36.0 * chi * chi * y ** 3 * special.kv(2.0 / 3.0, y) / (2.0 + 3.0 * chi * y) ** 4)
+    return 9.0 * np.sqrt(3.0) / (8.0 * np.pi) * integrate.quad(f, 0.0, np.inf, limit=400)[0]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("chi0,dt,tol", [(0.005, 2.0e-16, 0.03), (0.3, 5.0e-18, 0.03)])
+def test_radiated_power_is_the_synchrotron_power(oracle, chi0, dt, tol):
+    """The oracle's emission chain (Electron::push's optical depth, emit_radiation: rate, spectrum, recoil) closed on
+    physics: electrons of gamma = 1000 gyrating in a static B at quantum parameter chi0 radiate
+    (2/3) alpha chi^2 m c^2 / tau_C times g(chi) -- g by quadrature of the quantum spectrum above chi = 0.01; below it
+    the reference's own low-chi model, (1 - 8 chi / (5 sqrt 3)) (1 - (55 sqrt 3 / 48) chi) (photon_emission.rs:61-62,
+    139-142) -- and the photons carry what the electrons lost.  20 000 electrons, two emissions each: 1 % statistics."""
+    o = oracle
+    n, gamma0, per_electron, nx = 20_000, 1000.0, 2.0, 32
+    dx = 2.0 * C * dt
+    g = o.Grid.single(nx, 0.0, dx)
+    g.set_raw("Bz", np.full(g.len, chi0 * CRITICAL_FIELD / (gamma0 * C)))
+    rng = np.random.default_rng(2)
+    cell = np.sort(rng.integers(0, nx, n)).astype(np.int64)
+    z = np.zeros(n)
+    p = o.Population.from_soa(o.ELECTRON, cell, rng.random(n), np.full(n, -np.sqrt(gamma0 ** 2 - 1.0)), z, z, np.ones(n), dx, dt)
+    p.set_electron_state(tau=rng.exponential(size=n), ids=np.arange(n, dtype=np.uint64))
+    ph = o.Population.empty(o.PHOTON)
+    ke0 = p.total_kinetic_energy()
+    if chi0 < 0.01:
+        factor = lambda chi: (1.0 - 8.0 * chi / (5.0 * np.sqrt(3.0))) * (1.0 - 55.0 * np.sqrt(3.0) / 48.0 * chi)
+    else:
+        lc = np.linspace(np.log(chi0 / 100.0), np.log(chi0 * 1.01), 32)
+        gg = np.array([quantum_power_factor(np.exp(v)) for v in lc])
+        factor = lambda chi: np.interp(np.log(np.maximum(chi, 1e-300)), lc, gg)
+    mc2 = M_E_MEV * 1.0e6 * E_CHARGE
+    w0 = o.rate(chi0, gamma0)
+    assert w0 * dt < 0.02
+    steps = int(per_electron / (w0 * dt))
+    energy = 0.0
+    for s in range(steps):
+        p.advance(g, dt, 4)
+        chi = p.electron_extras()["chi"]
+        if s == 0:
+            assert abs(chi.mean() / chi0 - 1.0) < 2e-5
+        energy += np.sum((2.0 / 3.0) * ALPHA_FINE * chi ** 2 * mc2 / COMPTON_TIME * factor(chi)) * dt
+        o.emit_radiation(p, ph, seed=5, step=s, t=s * dt)
+    lost, radiated = ke0 - p.total_kinetic_energy(), ph.total_kinetic_energy()
+    assert abs(radiated / lost - 1.0) < 1e-5
+    assert len(ph) > 1.6 * n
+    assert abs(radiated / energy - 1.0) < tol, radiated / energy
