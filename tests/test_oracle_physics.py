@@ -244,3 +244,51 @@ def test_radiated_power_is_the_synchrotron_power(oracle, chi0, dt, tol):
     assert abs(radiated / lost - 1.0) < 1e-5
     assert len(ph) > 1.6 * n
     assert abs(radiated / energy - 1.0) < tol, radiated / energy
+
+
+@pytest.mark.parametrize("umax", [0.3, 20.0])
+def test_the_oracles_deposit_satisfies_the_continuity_equation(oracle, umax):
+    """Cell::flux / deposit (yee.rs:185-204, 551-641) have no test in the reference, so the oracle's reading of them is
+    checked against something that does not depend on any reading: with the charge of a macro-particle spread as a
+    triangle of half-width one cell, (rho_i(X_new) - rho_i(X_old)) / dt + (jx[i] - jx[i-1]) / dx = 0 cell by cell, rho
+    computed in numpy straight from the cumulative triangle (the statement tests/test_gpu_fullsize.py makes of the HIP
+    deposit).  Relativistic electrons and C6+ in random fields, periodic, every tap of the stencil live."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_fullsize import QE, continuity_residual, node_charge
+    o = oracle
+    nx, npc, dx = 96, 100, 1.0e-8
+    dt = 0.95 * dx / C
+    rng = np.random.default_rng(5)
+    g = o.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    for comp, amp in (("Ex", 2e12), ("Ey", 2e12), ("Ez", 2e12), ("Bx", 5e3), ("By", 5e3), ("Bz", 5e3)):
+        g.set_raw(comp, amp * rng.standard_normal(g.len))
+    g.synchronize(None, None, 0.0, 0.0)
+    pops = []
+    for species, zstar, amass, seed in ((o.ELECTRON, 1.0, 1.0, 1), (o.ION, 6.0, 12.0, 2)):
+        r = np.random.default_rng(seed)
+        n = nx * npc
+        cell = np.repeat(np.arange(nx, dtype=np.int64), npc)
+        u = umax * r.standard_normal((3, n))
+        p = o.Population.from_soa(species, cell, r.random(n), u[0], u[1], u[2], 1.0e3 * (0.5 + r.random(n)), dx, dt)
+        if species == o.ION:
+            p.set_charge_state(zstar, zstar, amass)
+        pops.append((p, QE if species == o.ELECTRON else -QE * zstar))
+    for step in range(3):
+        before = [(p.soa(), q) for p, q in pops]
+        for p, _ in pops:
+            p.advance(g, dt, 2)
+        g.clear()
+        for p, _ in pops:
+            g.deposit(p, dt, 2)
+        g.synchronize(None, None, 0.0, dt)
+        jx = g.raw("jx")[L:L + nx]
+        rho_old = sum(node_charge(s["cell"], s["x"], q * s["w"], nx) for s, q in before)
+        rho_new = sum(node_charge(s["cell"], s["x"], q * s["w"], nx) for s, q in [(p.soa(), q) for p, q in pops])
+        res = continuity_residual(rho_old, rho_new, jx, dt, dx)
+        scale = abs(QE) * 1.0e3 * npc * 7 / (dt * dx)
+        assert np.max(np.abs(res)) < 1e-12 * scale, (step, np.max(np.abs(res)) / scale)
+        assert np.max(np.abs(jx)) > 1e-3 * scale * dx
+        g.advance(dt)
