@@ -292,3 +292,72 @@ def test_the_oracles_deposit_satisfies_the_continuity_equation(oracle, umax):
         assert np.max(np.abs(res)) < 1e-12 * scale, (step, np.max(np.abs(res)) / scale)
         assert np.max(np.abs(jx)) > 1e-3 * scale * dx
         g.advance(dt)
+
+
+# ------------------------------------------------------------------ the operators the reference holds no test for
+M_P = 1.672622e-27        # constants.rs:18
+
+
+def test_the_oracles_gather_is_a_quadratic_spline_at_the_documented_stagger(oracle):
+    """fields_at (yee.rs:499-529): a linear field comes back exactly and x^2 as x_p^2 + 1/4 when the values are placed
+    where yee.rs:70-82 says each component lives (Ex, By, Bz at cell centres; Ey, Ez at left-hand edges; Bx un-interpolated)."""
+    o = oracle
+    nx, dx = 64, 1.0
+    g = o.Grid.single(nx, 0.0, dx)
+    L = g.left_bdy_size
+    j = np.arange(g.len, dtype=np.float64)
+    rng = np.random.default_rng(11)
+    coef = {k: (rng.normal(), rng.normal()) for k in ("Ex", "Ey", "Ez", "By", "Bz")}
+    centred = {"Ex": True, "By": True, "Bz": True, "Ey": False, "Ez": False}
+    for k, (a, b) in coef.items():
+        g.set_raw(k, a + b * (j + (0.5 if centred[k] else 0.0)))
+    bx = rng.normal(size=g.len)
+    g.set_raw("Bx", bx)
+    for c, xi in zip(rng.integers(0, nx, 300), np.concatenate([[0.0, 0.5, 0.499999999, 0.999999999], rng.random(296)])):
+        E, B = g.fields_at(int(c), float(xi))
+        pos = c + L + xi
+        got = {"Ex": E[0], "Ey": E[1], "Ez": E[2], "By": B[1], "Bz": B[2]}
+        for k, (a, b) in coef.items():
+            assert abs(got[k] - (a + b * pos)) <= 2e-13 * max(abs(a + b * pos), 1.0), (k, c, xi)
+        assert B[0] == bx[c + L]
+    g.set_raw("Ex", (j + 0.5) ** 2)
+    g.set_raw("Ey", j ** 2)
+    for c, xi in zip(rng.integers(0, nx, 100), rng.random(100)):
+        E, _ = g.fields_at(int(c), float(xi))
+        pos = c + L + xi
+        assert abs(E[0] - (pos ** 2 + 0.25)) <= 1e-12 * pos ** 2 and abs(E[1] - (pos ** 2 + 0.25)) <= 1e-12 * pos ** 2
+
+
+@pytest.mark.parametrize("axis,z_star,a_mass", [("z", 1.0, 1.0), ("z", 6.0, 12.0), ("x", 1.0, 1.0)])
+def test_the_oracles_ion_push_is_the_boris_rotation(oracle, axis, z_star, a_mass):
+    """Ion::push (ion.rs:168-214): |u| conserved, u turned by 2 atan(alpha c |B| / gamma) per step about B in the sense
+    of a positive charge -- the analogue, for ions, of the reference's electron.rs:401-421."""
+    o = oracle
+    nx, steps = 64, 100
+    q, M = z_star * E_CHARGE, a_mass * M_P
+    u0 = np.array([0.8, 0.3, 0.0]) if axis == "z" else np.array([0.1, 0.7, -0.4])
+    gamma = np.sqrt(1.0 + u0 @ u0)
+    b0 = 2.0
+    dt = (2.0 * np.pi / 60.0) * gamma * M / (q * b0)
+    dx = 3.0 * C * dt
+    g = o.Grid.single(nx, 0.0, dx)
+    g.set_raw("Bz" if axis == "z" else "Bx", np.full(g.len, b0))
+    n = 64
+    rng = np.random.default_rng(13)
+    cell = np.sort(rng.integers(0, nx, n)).astype(np.int64)
+    p = o.Population.from_soa(o.ION, cell, rng.random(n), np.full(n, u0[0]), np.full(n, u0[1]), np.full(n, u0[2]), np.ones(n), dx, dt)
+    p.set_charge_state(z_star, z_star, a_mass)
+    for _ in range(steps):
+        p.advance(g, dt)
+    s = p.soa()
+    alpha = q * dt / (2.0 * M * C)
+    theta = 2.0 * np.arctan(alpha * C * b0 / gamma)
+    u = np.stack([s["ux"], s["uy"], s["uz"]], axis=1)
+    assert np.max(np.abs(np.sqrt(np.sum(u * u, axis=1)) - np.sqrt(u0 @ u0))) < 1e-12
+    if axis == "z":
+        phi = np.arctan2(u0[1], u0[0]) - steps * theta
+        want = np.array([np.hypot(u0[0], u0[1]) * np.cos(phi), np.hypot(u0[0], u0[1]) * np.sin(phi), 0.0])
+    else:
+        phi = np.arctan2(u0[2], u0[1]) - steps * theta
+        want = np.array([u0[0], np.hypot(u0[1], u0[2]) * np.cos(phi), np.hypot(u0[1], u0[2]) * np.sin(phi)])
+    assert np.max(np.abs(u - want)) < 1e-10
