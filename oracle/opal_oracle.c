@@ -13,9 +13,17 @@
  *   - yee.rs:903-1079   laser_bc / conducting_bc / periodic_bc
  *   - electron.rs:401-436 static_magnetic_field / static_electric_field
  *   - photon_emission.rs:299-336 rate_* (five values)
- * (see tests/test_oracle_kat.py).  Nothing in the reference pins weight/flux/
- * deposit/fields_at values, Ion::push, migration or the loader: for those this
- * file is "source-following, parity unpinned by reference tests".
+ *   - airy.rs:77-112 airy_* (1e-12), pwmci.rs:235-283, vec3.rs:152-170, and the
+ *     reference's own sampling tables and Airy constants (transcribed data)
+ * (see tests/test_oracle_kat.py, test_qed_oracle.py, test_absorption_oracle.py).
+ * Nothing in the reference pins weight/flux/deposit/fields_at values, Ion::push,
+ * migration or the loader: for those this file is "source-following, parity
+ * unpinned by reference tests" -- and is held instead by answers that come from
+ * no reading of the reference at all (tests/test_oracle_physics.py,
+ * test_oracle_histogram.py): the gather's stagger and spline order, the Boris
+ * rotation angle, the continuity equation on the deposit cell by cell, the Yee
+ * dispersion relation, the plasma frequency, light in a cold plasma, the
+ * two-stream growth rate, the radiated synchrotron power, the binning rules.
  * The initial particle state is NOT bit-compatible with the reference: rand /
  * rand_xoshiro / rand_distr (Cargo.lock:540-586) are not vendored; the RNG here
  * is xoshiro256** + SplitMix64 seeding + 53-bit floats, with Box-Muller normals
