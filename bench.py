@@ -170,6 +170,7 @@ constants:
 
 
 REHEAT_STEPS = int(os.environ.get("OPAL_BENCH_REHEAT", "40"))
+REHEAT_SECONDS = 0.05
 
 
 def lp_link_capacity(npc):
@@ -549,6 +550,7 @@ def main():
         W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
         barrier()
         done = 0
+        per_step = None
         if preheat:
             t0 = time.perf_counter()
             sim.step(10)
@@ -560,8 +562,11 @@ def main():
                 sim.step(more)
                 sim.sync()
                 done += more
+        tw0 = time.perf_counter()
         sim.step(warmup)
         sim.sync()
+        if warmup >= 5:
+            per_step = all_max((time.perf_counter() - tw0) / warmup)  # (same on every rank: it sizes the burst below)
         # the particles this rank holds NOW (open boundaries delete leavers, subdomains trade them): counted after the
         # warm-up, and again after the timed steps -- the smaller number is the one the rate is quoted for
         n_e = len(sim.electrons) if sim.electrons is not None else 0
@@ -570,9 +575,11 @@ def main():
         if REHEAT_STEPS:
             # the counting above left the GPU idle for a few hundred microseconds, and its clocks take tens of
             # milliseconds to come back (a 20-step timed region measured 8 % slower per step than a 200-step one):
-            # a last untimed burst, so that all that separates the timed steps from running ones is the barrier itself
-            sim.step(REHEAT_STEPS)
-            done += REHEAT_STEPS
+            # a last untimed burst of >= 50 ms, so that all that separates the timed steps from running ones is the
+            # barrier itself
+            burst = REHEAT_STEPS if per_step is None else min(2000, max(REHEAT_STEPS, int(REHEAT_SECONDS / max(per_step, 1e-7))))
+            sim.step(burst)
+            done += burst
         barrier()
         # HIP events around every 5th launch of each tracked kernel (an odd stride samples both species);
         # timing every launch costs ~10 % of the step because each event record breaks back-to-back dispatch
