@@ -102,7 +102,10 @@ int link_plan(opal_link_t *l, unsigned species_mask)
         unsigned e = X - LINK_ZONE;
         if (peer) e -= e % LINK_PEER_EVERY;
         for (;; e -= peer ? LINK_PEER_EVERY : 1) {
-            if (X - e >= (unsigned)LINK_RING || X - e > zone_cells) break;  // overwritten since (or about to be), or too old
+            // overwritten since (or about to be).  (An old entry is as good as a recent one for a called transport: the
+            // exchanges after it that did not count the species did not push it either, so at most LINK_ZONE pushes of
+            // it lie between the entry and X.  A peer link skips entries whatever they counted, so age itself bounds.)
+            if (X - e >= (unsigned)LINK_RING || (peer && X - e > zone_cells)) break;
             if (l->ring_mask[e % LINK_RING] & (1u << sp)) {
                 const LinkBounds *b = &l->h_bounds[e % LINK_RING];
                 // Written by the unpack kernel of exchange e, at least LINK_ZONE exchanges ago: normally there already.
