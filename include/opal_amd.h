@@ -320,6 +320,10 @@ int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32
  * to back (the cadence of a run) and one more checked round.  Collective in the sense that the neighbours must make
  * the same calls. */
 int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n);
+/* The planning of message sizes and of the room populations reserve (link.cpp: link_plan) checked against its specification
+ * on a link that exists in host memory only: 0, or an error naming the first exchange that was planned differently.  Touches
+ * no device (the CPU-side tests call it). */
+int opal_link_plan_selftest(void);
 /* Ranks of the RCCL communicator behind a link made by opal_link_create_rccl (ncclCommCount): lets a caller
  * report that the subdomains really are joined by one RCCL communicator. */
 int opal_link_rccl_ranks(const opal_link_t *l, int *out);

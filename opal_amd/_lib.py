@@ -108,6 +108,7 @@ SIGNATURES = {
     "opal_link_rccl_ranks": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "opal_link_create_peer": (C.c_int, [pp, C.c_int, C.c_int, sz, C.c_int, C.c_int, vp]),
     "opal_link_self_test": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "opal_link_plan_selftest": (C.c_int, []),
     "opal_link_peer_export": (C.c_int, [vp, vp]),
     "opal_link_peer_connect": (C.c_int, [vp, vp, vp]),
     "opal_link_peer_status": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),

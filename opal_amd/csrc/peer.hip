@@ -283,6 +283,87 @@ int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n)
     return l->peer ? opal_link_peer_status(l, nullptr, nullptr, nullptr) : OPAL_OK;
 }
 
+// link_plan against its specification, on a link that exists in host memory only (no device is touched: callable, and
+// called by the CPU-side tests, without a GPU).  Three exchange patterns are played: every exchange counts every species
+// (the driver's steps); exchanges alternate between electrons and ions (the separate operators called species by species);
+// and a peer link, which files every LINK_PEER_EVERY-th exchange only.  After each plan the "device" files the exchange's
+// zone counts the way the tail kernel would.  Expected, from the argument in link.cpp: the entry of the most recent
+// exchange <= X - LINK_ZONE that counted the species (peer: the most recent filed one, at most LINK_PEER_ZONE old),
+// mine + theirs, maximum over the species of the exchange, plus LINK_SLACK, in whole row blocks, capped at the capacity.
+int opal_link_plan_selftest(void)
+{
+    auto fail = [](const char *what, int pattern, unsigned X, unsigned got, unsigned want) {
+        set_error("link_plan self-test, pattern %d, exchange %u: %s is %u, expected %u", pattern, X, what, got, want);
+        return OPAL_ERR_LINK;
+    };
+    for (int pattern = 0; pattern < 3; pattern++) {
+        const bool peer = pattern == 2;
+        opal_link_t l;
+        memset((void *)&l, 0, sizeof l);
+        LinkBounds ring[LINK_RING];
+        memset((void *)ring, 0, sizeof ring);
+        opal_peer pp;
+        pp.connected = true;
+        l.cap = 1u << 20;
+        l.nslots = 3;
+        l.nfields = 6;
+        l.bounded = !peer;
+        l.exchange2 = reinterpret_cast<opal_exchange2_fn>(&ring);  // (never called: non-null is all link_plan asks)
+        l.h_bounds = ring;
+        l.peer = peer ? &pp : nullptr;
+        unsigned mask_of[64], filed[64];
+        auto count = [](unsigned e, int side, int sp, int whose) { return 1000u + 37u * e + 11u * (unsigned)side + 5u * (unsigned)sp + 400u * (unsigned)whose; };
+        for (unsigned X = 0; X < 48; X++) {
+            const unsigned mask = pattern == 1 ? (X % 2 ? 2u : 1u) : 3u;
+            mask_of[X] = mask;
+            l.xseq = X;
+            if (int rc = link_plan(&l, mask)) return rc;
+            // the specification
+            unsigned want[2] = {(unsigned)l.cap, (unsigned)l.cap};
+            if (X >= (unsigned)LINK_ZONE) {
+                unsigned need[2] = {0, 0};
+                bool all = true;
+                for (int sp = 0; sp < 2 && all; sp++) {
+                    if (!(mask & (1u << sp))) continue;
+                    int found = -1;
+                    for (int e = (int)X - LINK_ZONE; e >= 0 && (int)X - e < LINK_RING; e--) {
+                        if (peer && (int)X - e > LINK_PEER_ZONE) break;
+                        if (filed[e] && (mask_of[e] & (1u << sp))) { found = e; break; }
+                    }
+                    if (found < 0) { all = false; break; }
+                    for (int side = 0; side < 2; side++) {
+                        unsigned n = count((unsigned)found, side, sp, 0) + count((unsigned)found, side, sp, 1);
+                        if (n > need[side]) need[side] = n;
+                    }
+                }
+                if (all)
+                    for (int side = 0; side < 2; side++) {
+                        unsigned slots = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+                        want[side] = slots < (unsigned)l.cap ? slots : (unsigned)l.cap;
+                    }
+            }
+            for (int side = 0; side < 2; side++) {
+                if (l.plan_cap[side] != want[side]) return fail("plan_cap", pattern, X, l.plan_cap[side], want[side]);
+                const unsigned ship = peer ? (unsigned)l.cap : want[side];  // a peer link ships what leaves, up to the capacity
+                if (l.send_cap[side] != ship) return fail("send_cap", pattern, X, l.send_cap[side], ship);
+            }
+            if (X >= 8 && want[0] == (unsigned)l.cap) return fail("plan_cap (no entry found where one exists)", pattern, X, want[0], 0);
+            // the tail kernel of exchange X files its counts (a peer link: every LINK_PEER_EVERY-th exchange)
+            filed[X] = !peer || X % LINK_PEER_EVERY == 0;
+            if (filed[X]) {
+                LinkBounds *b = &ring[X % LINK_RING];
+                for (int side = 0; side < 2; side++)
+                    for (int sp = 0; sp < 3; sp++) {
+                        b->mine[side][sp] = (mask & (1u << sp)) ? count(X, side, sp, 0) : 0u;
+                        b->theirs[side][sp] = (mask & (1u << sp)) ? count(X, side, sp, 1) : 0u;
+                    }
+                b->seq = X + 1;
+            }
+        }
+    }
+    return OPAL_OK;
+}
+
 int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges)
 {
     if (!l || !l->peer) {

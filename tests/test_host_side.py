@@ -37,6 +37,17 @@ def test_abi_exports_every_declared_symbol(oa):
     assert declared <= set(_lib.SIGNATURES), declared - set(_lib.SIGNATURES)
 
 
+def test_link_plan_follows_its_specification(oa):
+    """link.cpp: link_plan -- the sizes of the messages of called transports and the room populations reserve before a
+    step's arrivals -- played on a link in host memory (no device): every exchange counting every species, exchanges
+    alternating between species (an old ring entry stays valid there: the exchanges after it that did not count a species
+    did not push it either), and a peer link that files every 4th exchange (peer.hip: opal_link_plan_selftest)."""
+    from opal_amd import _lib
+    lib = _lib.load()
+    rc = lib.opal_link_plan_selftest()
+    assert rc == 0, lib.opal_last_error().decode()
+
+
 def test_no_gpu_fails_loudly(oa):
     """No silent CPU fallback: without a device the compute objects cannot even be created."""
     import torch
