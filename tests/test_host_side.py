@@ -48,6 +48,53 @@ def test_link_plan_follows_its_specification(oa):
     assert rc == 0, lib.opal_last_error().decode()
 
 
+def test_two_mailboxes_per_direction_suffice_without_acknowledgements():
+    """The hand-off rule of the peer-mapped mailboxes (peer_device.hpp), played as a model under random schedules: every
+    subdomain, per exchange k, writes its two messages into its neighbours' mailboxes k & 1 and then waits for and reads
+    its own two -- nothing else orders the subdomains.  Claim: a mailbox is never overwritten before its owner has read
+    it, because a neighbour can write exchange k + 2 only after finishing exchange k + 1, which needed my message k + 1,
+    which I sent after reading exchange k.  Checked for rings of 1, 2, 3 and 5 subdomains, open and periodic, with the
+    scheduler free to run any subdomain that is not blocked.  (The same model with ONE mailbox per direction finds the
+    overwrite within a few exchanges: the check has teeth.)"""
+    import random
+    for world, periodic, seed in [(1, True, 0), (2, True, 1), (3, True, 2), (5, True, 3), (3, False, 4), (5, False, 5)]:
+        rng = random.Random(seed)
+        K = 60
+        # box[r][side][parity] = exchange number of the message lying there (or -1); read[r][side] = last exchange read
+        box = [[[-1, -1], [-1, -1]] for _ in range(world)]
+        read = [[-1, -1] for _ in range(world)]
+        k = [0] * world            # exchange each subdomain is making
+        stage = [0] * world        # 0: about to send; 1: sent, about to wait / read
+        nb = lambda r, side: ((r - 1) % world if side == 0 else (r + 1) % world) if periodic or 0 <= r + (2 * side - 1) < world else None
+        done = 0
+        while done < world:
+            r = rng.randrange(world)
+            if k[r] >= K:
+                continue
+            if stage[r] == 0:
+                for side in (0, 1):
+                    n = nb(r, side)
+                    if n is None:
+                        continue
+                    theirs = 1 - side  # what I send left lands in my left neighbour's from-right mailbox
+                    # the hazard: the neighbour must have read what lay in this mailbox (exchange k - 2)
+                    assert read[n][theirs] >= k[r] - 2, (world, periodic, r, side, k[r], read[n][theirs])
+                    box[n][theirs][k[r] & 1] = k[r]
+                stage[r] = 1
+            else:
+                ready = all(nb(r, side) is None or box[r][side][k[r] & 1] == k[r] for side in (0, 1))
+                if not ready:
+                    continue  # blocked in peer_wait: the scheduler picks somebody else
+                for side in (0, 1):
+                    if nb(r, side) is not None:
+                        assert box[r][side][k[r] & 1] == k[r]  # not a stale or a future message
+                        read[r][side] = k[r]
+                k[r] += 1
+                stage[r] = 0
+                if k[r] == K:
+                    done += 1
+
+
 def test_no_gpu_fails_loudly(oa):
     """No silent CPU fallback: without a device the compute objects cannot even be created."""
     import torch
