@@ -185,6 +185,38 @@ def test_config_errors_and_typing(oa):
     assert c3.eval("critical(1.0)") == 8.854188e-12 * 9.109383e-31 / 1.602177e-19 ** 2
 
 
+def test_expression_grammar_and_builtins(oa):
+    """What an input file may say: meval's grammar and built-ins (the crate behind setup.rs:287-300) and the context
+    setup.rs:110-153 adds -- every function and constant once, against Python's math; precedence and associativity."""
+    import math
+    c = oa.Config(text="control:\n a: 1.0\nconstants:\n k: 3.0\n")
+    cases = {
+        "sqrt(2.0)": math.sqrt(2), "abs(-3.5)": 3.5, "exp(1.5)": math.exp(1.5), "ln(7.0)": math.log(7),
+        "sin(0.3)": math.sin(.3), "cos(0.3)": math.cos(.3), "tan(0.3)": math.tan(.3), "asin(0.3)": math.asin(.3),
+        "acos(0.3)": math.acos(.3), "atan(0.3)": math.atan(.3), "sinh(0.3)": math.sinh(.3), "cosh(0.3)": math.cosh(.3),
+        "tanh(0.3)": math.tanh(.3), "asinh(0.3)": math.asinh(.3), "acosh(1.3)": math.acosh(1.3), "atanh(0.3)": math.atanh(.3),
+        "floor(-2.5)": -3.0, "ceil(-2.5)": -2.0, "round(2.5)": 3.0, "round(-2.5)": -3.0, "signum(-2.0)": -1.0, "signum(0.0)": 1.0,
+        "atan2(1.0, -2.0)": math.atan2(1, -2), "max(1.0, 5.0, 3.0)": 5.0, "min(4.0, 2.0, 3.0)": 2.0, "pi": math.pi,
+        "2 + 3 * 4 ^ 2 / 8 - 1": 2 + 3 * 16 / 8 - 1, "2 ^ 3 ^ 2": 2.0 ** 9, "-(2 + 3)": -5.0, "10 % 4 * 2": 4.0, "1e3 + 2.5E-1": 1000.25,
+        "micro / nano": 1e-6 / 1e-9, "k * milli": 3e-3, "MeV / keV": 1e3, "mp / me": 1.672622e-27 / 9.109383e-31, "c": 2.997925e8,
+        "femto + pico": 1e-15 + 1e-12, "eV": 1.602177e-19, "m": 9.109383e-31,
+    }
+    for expr, want in cases.items():
+        got = c.eval(expr)
+        assert got == want or abs(got - want) <= 1e-15 * abs(want), (expr, got, want)
+    # the laser profiles (setup.rs:113-133) as functions of (t, x)
+    t, x, omega, sigma = 3.0e-15, 1.0e-6, 2.0 * math.pi * 2.997925e8 / 0.8e-6, 2.5
+    phi = omega * (t - x / 2.997925e8)
+    env = math.exp(-phi ** 2 / (2.0 * sigma ** 2))
+    re = c.eval(f"gauss_pulse_re({t!r}, {x!r}, {omega!r}, {sigma!r})")
+    im = c.eval(f"gauss_pulse_im({t!r}, {x!r}, {omega!r}, {sigma!r})")
+    assert abs(re - (math.sin(phi) + phi * math.cos(phi) / sigma ** 2) * env) < 1e-12
+    assert abs(im - (math.cos(phi) - phi * math.sin(phi) / sigma ** 2) * env) < 1e-12
+    for bad in ("2 +", "sin(", "nosuchfn(1.0)", "undefined_name * 2", "1 2"):
+        with pytest.raises(oa.OpalError):
+            c.eval(bad)
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference examples not present")
 def test_reference_examples_parse(oa):
     """The three shipped input files are accepted unchanged (docs/input.md)."""
