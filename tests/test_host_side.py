@@ -185,6 +185,29 @@ def test_config_errors_and_typing(oa):
     assert c3.eval("critical(1.0)") == 8.854188e-12 * 9.109383e-31 / 1.602177e-19 ** 2
 
 
+def test_yaml_subset_accepts_what_input_files_contain(oa):
+    """The library's own YAML reader (the reference uses yaml-rust) on the constructs input files use or might use:
+    comments, CRLF line endings, blank lines, any indentation width, with and without the document markers, quoted
+    and folded / literal block scalars (examples/colliding_beams.yaml folds its laser profile), integers read as reals."""
+    cases = {
+        "control:\n dx: 0.5 # half\n nx: 3\n": 0.5,
+        "control:\r\n dx: 0.5\r\n nx: 3\r\n": 0.5,
+        "control:\n\n dx: 0.5\n\n nx: 3\n": 0.5,
+        "control:\n    dx: 0.5\n    nx: 3\n": 0.5,
+        "---\ncontrol:\n dx: 0.5\n...\n": 0.5,
+        "control: \n dx:   0.5   \n": 0.5,
+        "control:\n dx: \"0.25 * 2\"\n": 0.5,
+        "control:\n dx: '0.25 * 2'\n": 0.5,
+        "control:\n dx: >\n  0.25\n  * 2\n": 0.5,
+        "control:\n dx: |\n  0.25 * 2\n": 0.5,
+        "# top\ncontrol:\n # inside\n dx: 0.5\n": 0.5,
+        "control:\n dx: 160\n": 160.0,
+        "control:\n dx: 2*micro\n": 2e-6,
+    }
+    for text, want in cases.items():
+        assert oa.Config(text=text).read_f64("control", "dx") == want, text
+
+
 def test_expression_grammar_and_builtins(oa):
     """What an input file may say: meval's grammar and built-ins (the crate behind setup.rs:287-300) and the context
     setup.rs:110-153 adds -- every function and constant once, against Python's math; precedence and associativity."""
