@@ -1025,6 +1025,9 @@ int oracle_ion_push(Ion *p, const double *E, const double *B, double dx, double 
 {
     return ion_push(p, E, B, dx, dt);
 }
+/* single-particle kinetic energies (electron.rs:122-126, ion.rs:128-134) for tests/test_golden_independent.py */
+double oracle_electron_kinetic_energy(const Electron *p) { return electron_ke(p); }
+double oracle_ion_kinetic_energy(const Ion *p) { return ion_ke(p); }
 
 /* ------------------------------------------------------------- RNG (own) */
 typedef struct { uint64_t s[4]; } Rng;

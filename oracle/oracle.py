@@ -621,3 +621,16 @@ def ion_create(cell, x, u, weight, dx, dt):
 
 def ion_push(e, E, B, dx, dt):
     return lib().oracle_ion_push(C.byref(e), (C.c_double * 3)(*E), (C.c_double * 3)(*B), dx, dt)
+
+
+def electron_kinetic_energy(e):
+    f = lib().oracle_electron_kinetic_energy
+    f.restype, f.argtypes = C.c_double, [C.c_void_p]
+    return f(C.byref(e))
+
+
+def ion_kinetic_energy(p):
+    f = lib().oracle_ion_kinetic_energy
+    f.restype, f.argtypes = C.c_double, [C.c_void_p]
+    return f(C.byref(p))
+
