@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/pic_step_vectors.json.
+"""Generates tests/golden/pic_step_vectors.json — a REGRESSION FREEZE of the oracle, not a parity pin.
+
+(The vectors below are the oracle's own output: tests that compare the oracle with this file only show that the oracle has
+not drifted since the file was written.  The parity pin of the hot path is tests/golden/pic_step_vectors_independent.json,
+written by a second restatement that shares nothing with the oracle: make_golden_pic_independent.py.)
 
 The reference is Rust and cannot be built or run here (no cargo/rustc in the image), so no vector
 can be captured from it.  These vectors are produced by the CPU oracle (oracle/opal_oracle.c), which

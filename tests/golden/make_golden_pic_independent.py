@@ -829,6 +829,9 @@ def vectors_deposit(rng):
         d = design_unbalanced(0, 1, nx, 0.0, dx, 8, INTERNAL, INTERNAL)
         g = YeeGrid(d)
         randomise(g, rng, comps=("Ex", "Ey", "Ez", "Bx", "By", "Bz"), amp={"E": 3e11, "B": 1e3})
+        # a state the loop can reach: the push always follows a synchronize, which makes the ghost cells copies of
+        # the cells they stand for (an implementation is free to read either image)
+        world_synchronize([g], lambda a, b: 0.0, lambda a, b: 0.0, 0.0, dt)
         cells = None if label != "edges" else [0, 0, 1, nx - 2, nx - 1, nx - 1, nx // 2]
         el = make_particles(rng, g, ne_, Electron, dt, uscale, 1.0e6, cells)
         io = make_particles(rng, g, ni_, Ion, dt, uscale * 1e-2, 3.0e5, cells, (6.0, 6.0, 12.0))
@@ -977,6 +980,7 @@ def vectors_world_runs(rng):
         grids = [YeeGrid(d) for d in designs]
         for g in grids:
             randomise(g, rng, comps=("Ex", "Ey", "Ez", "Bx", "By", "Bz"), amp={"E": 2e11, "B": 6e2})
+        world_synchronize(grids, lambda a, b: 0.0, lambda a, b: 0.0, 0.0, dt)  # ghosts = copies, as before any push
         el = [make_particles(rng, g, n_e, Electron, dt, us, 2.0e6) for g in grids]
         io = [make_particles(rng, g, n_i, Ion, dt, us * 0.05, 5.0e5, None, (1.0, 1.0, ELECTRON_MASS / PROTON_MASS)
                              if "three" in name else (6.0, 6.0, 12.0)) for g in grids]

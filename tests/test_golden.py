@@ -1,5 +1,7 @@
-"""Golden fixtures (tests/golden/pic_step_vectors.json; restatement-generated, see make_golden.py):
-the oracle must reproduce them bit for bit; the HIP path must match them to 1e-12."""
+"""Regression freeze of the oracle (tests/golden/pic_step_vectors.json is written BY the oracle, see make_golden.py):
+the oracle must still reproduce it bit for bit, i.e. it has not drifted; the HIP path must match it to 1e-12.
+This is not the parity pin -- that is tests/test_golden_independent.py, whose vectors come from a second,
+independent restatement of the reference."""
 import json
 import os
 
