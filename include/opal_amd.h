@@ -71,6 +71,10 @@ const char *opal_version(void);
 /* number of visible GPUs; OPAL_ERR_HIP when there is none */
 int opal_device_count(int *count);
 int opal_set_device(int device);
+/* Which card a rank really runs on: the PCI bus id (hipDeviceGetPCIBusId, "0000:xx:00.0") and the device name of HIP
+ * ordinal `device` (< 0: the current device).  No counterpart in the reference (MPI ranks are CPU processes); bench.py
+ * gathers it over the ranks so that an N-GPU line shows N distinct cards whatever the transport. */
+int opal_device_identity(int device, char *pci_bus_id, size_t len, char *name, size_t name_len);
 
 /* ------------------------------------------------------------------ GridDesign
  * src/grid/mod.rs:126-151 (unbalanced) and :157-206 (balanced).  nx / offset

@@ -53,6 +53,13 @@ def set_device(i):
     _check(_lib.load().opal_set_device(i))
 
 
+def device_identity(i=-1):
+    """(PCI bus id, device name) of HIP ordinal i (default: the current device)."""
+    bus, name = C.create_string_buffer(64), C.create_string_buffer(256)
+    _check(_lib.load().opal_device_identity(i, bus, 64, name, 256))
+    return bus.value.decode(), name.value.decode()
+
+
 def stream_create():
     """A HIP stream of the library's own runtime (an integer handle for every `stream=` argument here)."""
     h = C.c_void_p()

@@ -29,6 +29,7 @@ SIGNATURES = {
     "opal_version": (C.c_char_p, []),
     "opal_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "opal_set_device": (C.c_int, [C.c_int]),
+    "opal_device_identity": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "opal_design_unbalanced": (C.c_int, [C.c_int, sz, dbl, sz, vp, vp]),
     "opal_design_balanced": (C.c_int, [C.c_int, sz, dbl, dbl, sz, FN1, vp, vp, vp]),
     "opal_grid_build": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, C.c_int, dbl, dbl, vp, vp, vp]),

@@ -131,6 +131,18 @@ int opal_set_device(int device)
     return OPAL_OK;
 }
 
+int opal_device_identity(int device, char *pci_bus_id, size_t len, char *name, size_t name_len)
+{
+    if (device < 0) OPAL_HIP(hipGetDevice(&device));
+    if (pci_bus_id && len) OPAL_HIP(hipDeviceGetPCIBusId(pci_bus_id, (int)len, device));
+    if (name && name_len) {
+        hipDeviceProp_t prop;
+        OPAL_HIP(hipGetDeviceProperties(&prop, device));
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    return OPAL_OK;
+}
+
 int opal_stream_create(void **out)
 {
     if (!out) {

@@ -112,4 +112,7 @@ bool link_is_peer(const opal_link_t *l);
 // = where the halo is packed from, or null when the send messages already hold it
 int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, const HaloSrc *halo, PeerArgs &a);
 void link_peer_free(opal_link_t *l);
+// OPAL_ERR_LINK if a wait for a neighbour's message has ever timed out on this link (peer links; OPAL_OK for the others).
+// Synchronises with the link's stream: called where the host waits for the device anyway.
+int link_peer_check(opal_link_t *l);
 }  // namespace opal

@@ -353,6 +353,9 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
         } else {
             atomicAdd(&a.ctr->n_dead, 1u);
             char *msg = a.send_msg[send_side];
+            // a leaver stands within a cell of the cut on the far side after this exchange and may come back: it belongs
+            // to the zone count of the edge it crosses (neither end's push would count it otherwise: link.cpp)
+            if (a.zone) atomicAdd(reinterpret_cast<unsigned *>(msg) + a.zone_word, 1u);
             unsigned slot = atomicAdd(reinterpret_cast<unsigned *>(msg) + LINK_H_COUNT + a.send_slot, 1u);
             if (slot < a.send_cap[send_side]) {
                 *link_cell(msg, a.send_layout, a.send_slot, slot) = newc;
@@ -814,6 +817,9 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
         } else {
             atomicAdd(&a.ctr->n_dead, 1u);
             char *msg = a.send_msg[send_side];
+            // a leaver stands within a cell of the cut on the far side after this exchange and may come back: it belongs
+            // to the zone count of the edge it crosses (neither end's push would count it otherwise: link.cpp)
+            if (a.zone) atomicAdd(reinterpret_cast<unsigned *>(msg) + a.zone_word, 1u);
             unsigned slot = atomicAdd(reinterpret_cast<unsigned *>(msg) + LINK_H_COUNT + a.send_slot, 1u);
             if (slot < a.send_cap[send_side]) {
                 *link_cell(msg, a.send_layout, a.send_slot, slot) = newc;
@@ -1144,6 +1150,7 @@ struct UnpackArgs {
     LinkLayout layout;
     int slot;
     unsigned recv_cap[2];  // slots per species the message of that edge shipped
+    unsigned reserve[2];   // arrivals per species this population made room for through that edge (link_plan's bound)
     int *cell;
     double *f[5];
     double *prev_x;
@@ -1243,6 +1250,9 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
     if (!msg) return;
     unsigned count = reinterpret_cast<const unsigned *>(msg)[LINK_H_COUNT + a.slot];
     if (count > a.recv_cap[side]) count = a.recv_cap[side];  // the sender has flagged the overflow on its side
+    // (a peer link ships whatever leaves: more arrivals than the bound the host grew its slot count by would leave
+    // pushes sized from that count short of the last slots -- reported, not absorbed)
+    if (count > a.reserve[side] && threadIdx.x == 0) atomicOr(&a.ctr->err, 128);
     if (count == 0) return;
     if (threadIdx.x == 0) s_base = atomicAdd(&a.ctr->n_slots, count);
     __syncthreads();
@@ -1347,6 +1357,11 @@ int check_pop_err(opal_pop_t *p)
         if (err & 16) {
             set_error("population capacity exceeded by arrivals from a neighbouring subdomain");
             return OPAL_ERR_CAPACITY;
+        }
+        if (err & 128) {
+            set_error("more particles arrived through a subdomain edge in one step than the bound the population reserved room "
+                      "by (link.cpp: link_plan: the particles within the zone on both sides of the cut a few exchanges earlier)");
+            return OPAL_ERR_ASSERT;
         }
         if (err & 64) {
             set_error("a photon-electron pair gave a negative or non-finite interaction probability in absorb "
@@ -1751,6 +1766,8 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     u.layout = link->layout;
     u.recv_cap[0] = link->send_cap[0];  // an edge's two directions ship the same number of slots
     u.recv_cap[1] = link->send_cap[1];
+    u.reserve[0] = link->plan_cap[0];
+    u.reserve[1] = link->plan_cap[1];
     u.cell = p->d_cell[k];
     u.f[0] = p->d_x[k]; u.f[1] = p->d_ux[k]; u.f[2] = p->d_uy[k]; u.f[3] = p->d_uz[k]; u.f[4] = p->d_w[k];
     u.prev_x = p->prev_valid ? p->d_prev_x : nullptr;

@@ -58,6 +58,8 @@ int peer_exchange(void *user, const void *send_left, const void *send_right, voi
 
 }  // namespace
 
+extern "C" int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges);
+
 namespace opal {
 
 bool link_is_peer(const opal_link_t *l) { return l && l->peer && l->peer->connected; }
@@ -94,6 +96,12 @@ int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, 
         a.box[1] = p->box_mem + (1 * 2 + par) * p->stride;
     }
     return OPAL_OK;
+}
+
+int link_peer_check(opal_link_t *l)
+{
+    if (!l || !l->peer || !l->peer->d_err) return OPAL_OK;
+    return opal_link_peer_status(l, nullptr, nullptr, nullptr);
 }
 
 void link_peer_free(opal_link_t *l)
@@ -162,10 +170,15 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
         *out = nullptr;
         return hip_fail(e, "allocating the peer mailboxes");
     }
-    OPAL_HIP(hipMemset(p->box_mem, 0, total));
-    OPAL_HIP(hipMalloc((void **)&p->d_err, sizeof(unsigned)));
-    OPAL_HIP(hipMemset(p->d_err, 0, sizeof(unsigned)));
-    OPAL_HIP(hipDeviceSynchronize());
+    e = hipMemset(p->box_mem, 0, total);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(p->d_err, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {  // nothing of a half-built link survives a failure: the caller falls back to another transport
+        opal_link_free(l);
+        *out = nullptr;
+        return hip_fail(e, "setting up the peer mailboxes");
+    }
     return OPAL_OK;
 }
 
@@ -187,7 +200,7 @@ int opal_link_peer_export(opal_link_t *l, void *handle64)
         if (e == hipSuccess) break;
         (void)hipGetLastError();
         usleep(20000u << attempt);
-        if (attempt >= 1) {
+        if (attempt >= 1 && attempt < 3) {  // (a fresh allocation after the last attempt would never be exported)
             char *fresh = nullptr;
             if (peer_alloc(p, &fresh) == hipSuccess) {  // (while the old one is still held: another address)
                 hipFree(p->box_mem);

@@ -846,6 +846,9 @@ int opal_sim_sync(opal_sim_t *s)
         if (int rc = pop_check_err(s->ions)) return rc;
     if (s->photons)
         if (int rc = pop_check_err(s->photons)) return rc;
+    // a neighbour's message that never came (peer links: the kernels' waits are bounded and carry on) ends the run here,
+    // as a blocking MPI exchange that cannot complete ends the reference's (yee.rs:358-409, particle/mod.rs:303-354)
+    if (int rc = link_peer_check(s->link)) return rc;
     return OPAL_OK;
 }
 

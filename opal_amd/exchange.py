@@ -206,20 +206,25 @@ class PeerLink:
 
     def __init__(self, rank, world, device=None, particle_capacity=4096, group=None, stream=None, photon_emission=False,
                  photon_absorption=False):
-        self._lib = _lib.load()
-        # (what Simulation builds its output-time collectives from: the device the reductions run on and the group)
-        self.device = torch.device(device) if device is not None else torch.device("cpu")
-        self.transport = NeighbourTransport(rank, world, group)
-        slots, fields = (3, 15) if photon_absorption else (3, 12) if photon_emission else (2, 6)
-        # Every step below that can fail locally is followed by an exchange in which all subdomains take part whatever
-        # happened to them: a subdomain that cannot set its mailboxes up must not leave the others waiting for it.
+        # Every step below that can fail locally -- loading the library included -- is followed by an exchange in which
+        # all subdomains take part whatever happened to them: a subdomain that cannot set its mailboxes up must not
+        # leave the others waiting for it in a collective.
         h = C.c_void_p()
         err = None
         mine = C.create_string_buffer(64)
-        if self._lib.opal_link_create_peer(C.byref(h), rank, world, particle_capacity, slots, fields, stream):
-            err, h = self._lib.opal_last_error().decode(), None
-        elif self._lib.opal_link_peer_export(h, mine):
-            err = self._lib.opal_last_error().decode()
+        self.h = None
+        try:
+            self._lib = _lib.load()
+            # (what Simulation builds its output-time collectives from: the device the reductions run on and the group)
+            self.device = torch.device(device) if device is not None else torch.device("cpu")
+            self.transport = NeighbourTransport(rank, world, group)
+            slots, fields = (3, 15) if photon_absorption else (3, 12) if photon_emission else (2, 6)
+            if self._lib.opal_link_create_peer(C.byref(h), rank, world, particle_capacity, slots, fields, stream):
+                err, h = self._lib.opal_last_error().decode(), None
+            elif self._lib.opal_link_peer_export(h, mine):
+                err = self._lib.opal_last_error().decode()
+        except Exception as e:  # noqa: BLE001
+            err, h = f"{type(e).__name__}: {e}", None
         self.h = h
         left = right = None
         if world > 1:
@@ -228,7 +233,7 @@ class PeerLink:
             err = next((f"subdomain {r}: {e}" for r, (_, e) in enumerate(handles) if e), None)
             left = C.create_string_buffer(handles[(rank - 1 + world) % world][0], 64)
             right = C.create_string_buffer(handles[(rank + 1) % world][0], 64)
-        if not err and self._lib.opal_link_peer_connect(h, left, right):
+        if not err and h and self._lib.opal_link_peer_connect(h, left, right):
             err = self._lib.opal_last_error().decode()
         if world > 1:
             # every mailbox is mapped before anybody's first step writes into one -- and if mapping failed anywhere
@@ -292,6 +297,13 @@ def make_link(rank, world, device, particle_capacity, stream=None, photon_emissi
             ctl = dist.new_group(backend="gloo")
         except Exception as e:  # noqa: BLE001  (no usable host interface for gloo: the default group carries the votes)
             log(f"[opal_amd] no gloo control group ({e}); using the default process group")
+            ctl = None
+        # a control group is used only if EVERY subdomain has it: one that fell back to the default group would run
+        # its handshakes and votes on another group than its neighbours, and all would wait for ever
+        have = torch.tensor([1 if ctl is not None else 0], dtype=torch.int32,
+                            device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) == 0:
             ctl = None
     kw = dict(particle_capacity=particle_capacity, stream=stream, photon_emission=photon_emission,
               photon_absorption=photon_absorption)

@@ -321,12 +321,14 @@ constants:
 """
 
 
-def test_configs3_shape_laser_plasma(oa):
+@pytest.mark.parametrize("npc", [2000, 10000])
+def test_configs3_shape_laser_plasma(oa, npc):
     """BASELINE configs[3]'s physics on one GPU: examples/hole_boring.yaml's parameters (a0 = 300 pulse on an
-    overdense electron-carbon slab, laser + 200-cell absorber), 2000 + 2000 macro-particles per cell in the
-    5000-cell slab (2e7 particles).  Run until the pulse is boring into the slab, then check continuity cell by
+    overdense electron-carbon slab, laser + 200-cell absorber), npc + npc macro-particles per cell in the
+    5000-cell slab: 2e7 particles, and configs[3]'s NAMED size, 1e8 particles (npc = 10 000; 4.4 GB in HBM,
+    ~35 s of stepping).  Run until the pulse is boring into the slab, then check counts, ranges and continuity cell by
     cell over a step in which relativistic electrons cross cells and the transverse currents are live."""
-    npc, nx = 2000, 20000
+    nx = 20000
     sim = oa.Simulation(yaml_text=LASER_PLASMA.format(npc=npc))
     dt, dx = sim.dt, sim.grid.dx
     n0 = len(sim.electrons)
