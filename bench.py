@@ -169,6 +169,57 @@ constants:
 """
 
 
+# BASELINE configs[4]: examples/colliding_beams.yaml as shipped (gamma = 1000 electron beam against an a0 = 20 four-cycle
+# pulse, current_deposition off, stochastic photon emission on, photons kept within 50 mrad; interactions.rs:45-107,
+# photon.rs:150-183) with npc scaled: 500 cells x 20 000 = 1e7 electrons, which radiate ~4.7e7 photons in the collision.
+# The pulse meets the beam after ~1750 steps and the collision is over ~750 steps later: that stretch is the timed region.
+COLLIDING_BEAMS_YAML = """---
+control:
+ dx: 0.01*micro
+ nx: 4000
+ xmin: -15*micro
+ start: -24.0e-6/c
+ end: 6.0e-6/c
+ current_deposition: false
+ n_outputs: 5
+ balance: false
+qed:
+ photon_emission: true
+ photon_absorption: false
+ photon_angle_max: 50 * milli
+electrons:
+ npc: {npc}
+ ne: S * a0 * critical(omega) * step(x,xmin,xmax)
+ ux: -1000.0 * (1.0 + 0.01 * nrand)
+ uy: 0.0
+ uz: 0.0
+ output: [x, chi, x:chi, energy, x:energy]
+ions:
+ npc: 0
+photons:
+ npc: 0
+ output: [x, energy, energy:(log;energy), longitude:latitude, longitude:latitude:(energy)]
+laser:
+ Ey: >
+  (a0*m*c*omega/e)
+  *sin(omega*(t-x/c))
+  *exp(-ln(2.0)*(omega*(t-x/c))^2/(2.0*pi^2*ncycles^2))
+ Ez: 0.0
+constants:
+ S: 1.0e-6
+ a0: 20.0
+ omega: 2*pi*c/0.8e-6
+ ncycles: 4.0
+ xmin: (20 - 2.5) * micro
+ xmax: (20 + 2.5) * micro
+"""
+CB_NPC, CB_WARM, CB_STEPS, CB_SEG = 20000, 1750, 750, 50
+# algorithmic bytes per update: the electrons' advance with chi and the optical depth tracked reads cell,x,ux,uy,uz,w,tau
+# (52 B; 44 B when the uniform weight comes from the launch arguments) and writes cell,x,ux,uy,uz,chi,tau (52 B): SURVEY.md
+# 8d's 80 B + 8 B per extra read or written; a photon's push reads cell,x,kx,ky,kz (36 B) and writes cell,x (12 B)
+CB_BYTES_ELECTRON, CB_BYTES_PHOTON = 104.0, 48.0
+
+
 REHEAT_STEPS = int(os.environ.get("OPAL_BENCH_REHEAT", "40"))
 REHEAT_SECONDS = 0.05
 LONG_STEPS = 200   # a second timed region of this length follows a shorter --steps (the driver's 20): `steps_long`
@@ -435,6 +486,7 @@ def main():
     ap.add_argument("--no-elision", action="store_true", help="same as --elision off without the default_path measurement")
     ap.add_argument("--no-default-path", action="store_true", help="skip the default_path measurement")
     ap.add_argument("--no-laser-plasma", action="store_true", help="skip the laser-plasma interaction block of the N=1 line")
+    ap.add_argument("--no-colliding-beams", action="store_true", help="skip the colliding-beams (configs[4]) block")
     ap.add_argument("--workload", choices=["two_stream", "laser_plasma"], default="two_stream",
                     help="two_stream (default; BASELINE configs[2], strong scaling) or laser_plasma "
                          "(configs[3]'s physics, --npc per cell in 5000 of 20000 cells, strong scaling)")
@@ -719,6 +771,80 @@ def main():
                 "what": "the same simulation, the same kernel form, a second timed region of this many steps right behind the "
                         "first: the figure a short `--steps` does not depend on"}
 
+    def colliding_beams(link_cb, what):
+        """BASELINE configs[4] on this run's ranks: untimed up to the collision, then CB_STEPS timed steps through it in
+        segments of CB_SEG (the photon population grows by the step: each segment is credited with the electrons and the
+        mean of the photons it began and ended with).  updates = electrons + photons pushed; every kernel of the step
+        priced with its own bytes."""
+        oa.set_elision(True)
+        simc = oa.Simulation(yaml_text=COLLIDING_BEAMS_YAML.format(npc=CB_NPC), rank=rank, numtasks=world, link=link_cb, stream=stream)
+        barrier()
+        simc.step(CB_WARM)
+        simc.sync()
+        oa.prof_reset()
+        barrier()
+        oa.prof_enable(5)
+        upd_e = upd_p = 0.0
+        t0 = time.perf_counter()
+        n_p0 = simc.photons.counters()["slots"]
+        for _ in range(CB_STEPS // CB_SEG):
+            simc.step(CB_SEG)
+            simc.sync()
+            n_e, n_p1 = len(simc.electrons), simc.photons.counters()["slots"]
+            upd_e += float(n_e) * CB_SEG
+            upd_p += 0.5 * (n_p0 + n_p1) * CB_SEG
+            n_p0 = n_p1
+        barrier()
+        el_local = time.perf_counter() - t0
+        el = all_max(el_local)
+        oa.prof_enable(0)
+        tot_e, tot_p = all_sum(upd_e), all_sum(upd_p)
+        kern = {}
+        for key in ("advance", "photon", "radiate", "sort", "field"):
+            n_t, ms = oa.prof_get(key)
+            kern[key] = {"launches_timed": n_t, "launches_total": oa.prof_seen(key), "avg_launch_ms": ms / max(n_t, 1),
+                         "gpu_ms_in_timed_region": ms / max(n_t, 1) * oa.prof_seen(key)}
+        gpu_ms = sum(k["gpu_ms_in_timed_region"] for k in kern.values()) or 1.0
+        forms = oa.prof_forms()
+        w_arg = any(f & 4 for f, c in forms.items() if c)
+        be = CB_BYTES_ELECTRON - (8.0 if w_arg else 0.0)
+        ke, kp = kern["advance"], kern["photon"]
+        # per launch: this rank's electrons once; the photons it held then (mean over the timed launches)
+        e_per_launch = upd_e / max(ke["launches_total"], 1)
+        p_per_launch = upd_p / max(kp["launches_total"], 1)
+        for k, n_pl, b in ((ke, e_per_launch, be), (kp, p_per_launch, CB_BYTES_PHOTON)):
+            k["bytes_per_update"] = b
+            k["updates_per_launch"] = n_pl
+            k["achieved"] = b * n_pl / (k["avg_launch_ms"] * 1e-3) / 1e9 if k["launches_timed"] else 0.0
+            k["frac"] = k["achieved"] / HBM_PEAK_GBS
+        dom = ke if ke["gpu_ms_in_timed_region"] >= kp["gpu_ms_in_timed_region"] else kp
+        res = {"what": what, "value": (tot_e + tot_p) / el, "unit": "particle-updates/s (electrons + photons pushed)",
+               "electron_updates_per_s": tot_e / el, "photon_updates_per_s": tot_p / el, "steps": CB_STEPS, "warmup": CB_WARM,
+               "ms_per_step": 1e3 * el / CB_STEPS, "electrons_end": int(all_sum(float(len(simc.electrons)))),
+               "photons_end": int(all_sum(float(simc.photons.counters()["slots"]))), "t_end": simc.t,
+               "roofline": {"bound": "hbm", "kernel": "k_push<0, 0, true, 2, false> (electrons, optical depth + emitter list)"
+                            if dom is ke else "k_push_photon<false>", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": dom["frac"], "traffic": None,
+                            "traffic_note": "PMC passes of this block: profiles/r04_colliding_beams_* (scripts/profile_cb.sh)",
+                            "algorithmic_GBps_over_whole_step": (be * tot_e + CB_BYTES_PHOTON * tot_p) / el / 1e9 / world},
+               "kernels": {"electron_push": ke, "photon_push": kp, "k_radiate": kern["radiate"], "rebin": kern["sort"],
+                           "field_solve": kern["field"]},
+               "k_radiate_share_of_gpu_time": kern["radiate"]["gpu_ms_in_timed_region"] / gpu_ms,
+               "bytes_model": f"electron push {be:.0f} B/update (cell,x,u[3],tau" + ("" if w_arg else ",w")
+                              + " read; cell,x,u[3],chi,tau written), photon push 48 B/update (cell,x,k[3] read; cell,x written)"}
+        if world > 1:
+            pr = [None] * world
+            dist.all_gather_object(pr, {"rank": rank, "ms_per_step_own_clock": 1e3 * el_local / CB_STEPS,
+                                        "electrons": len(simc.electrons), "photons": simc.photons.counters()["slots"]})
+            res["per_rank"] = pr
+        del simc
+        return res
+
+    CB_WHAT = (f"colliding_beams (examples/colliding_beams.yaml physics, BASELINE configs[4]): gamma = 1000 beam, {CB_NPC} per "
+               f"cell in 500 of 4000 cells (1e7 electrons) against an a0 = 20 pulse, current deposition off, photon emission on "
+               f"(photons within 50 mrad kept), {CB_WARM} untimed steps up to the collision, then {CB_STEPS} timed steps "
+               f"through it (the photon population grows from ~0 to ~4.7e7); library default path")
+
     CONTRACT = ("general kernel, opal_set_elision(0): every attribute of every particle is read (44 B) and the kernel writes back "
                 "cell, x, ux, uy, uz (36 B) -- SURVEY.md 8d's 80 algorithmic bytes per update, which `roofline.frac` is priced "
                 "with -- except that an attribute no lane of a wave changed is not written back (results identical by "
@@ -838,39 +964,32 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    if world > 1 and args.workload == "two_stream" and not weak and not args.self_exchange and not args.unfused \
-            and not args.no_laser_plasma and (nx, npc) == (C3_CELLS, C3_NPC) and args.elision == "off":
-        # BASELINE configs[3] on the same N GPUs: hole_boring.yaml's physics with 1e8 particles, `balance: true`
-        # (subdomains of different sizes, GridDesign::balanced), laser and absorbing ends, timed inside the interaction.
-        # A second set of mailboxes (open ends, room for a relativistic front) is set up for it.  The two-stream line
-        # above is complete at this point: whatever happens here -- an error on some subdomain, a transport that never
-        # returns -- the line is written, with the failure in it, and every rank leaves with status 0: at once
-        # where the failure is seen, within seconds elsewhere (the rendezvous store carries the news), at the deadline at the latest.
+    def guarded(key, deadline, body):
+        """Runs one more block of a complete line on all ranks under a watchdog.  The line above it is complete at this
+        point: whatever happens in the block -- an error on some subdomain, a transport that never returns -- the line is
+        written, with the failure in it as out[key] = {"error": ...}, and every rank leaves with status 0: at once where
+        the failure is seen, within seconds elsewhere (the rendezvous store carries the news, which the others' watchdogs
+        poll every 2 s: RCCL does not notice a peer that left a collective), at the deadline at the latest."""
         import threading
-        lp_npc, lp_warm, lp_steps = 10000, 21000, 2000
-        deadline = float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300"))  # (well below torch.distributed's 600 s collective timeout)
-        once = threading.Lock()
         finished = threading.Event()
         try:
             store = dist.distributed_c10d._get_default_store()
         except Exception:  # noqa: BLE001
             store = None
-        ABORT = "opal_bench_lp_abort"
+        ABORT = f"opal_bench_abort_{key}"
 
         def give_up(why, tell=True):
-            if not once.acquire(blocking=False):
+            if not GIVE_UP_ONCE.acquire(blocking=False):
                 return
             if tell and store is not None:
-                # the other subdomains may sit in a collective that can no longer complete (RCCL does not notice a peer
-                # that left): tell them through the rendezvous store, which their watchdogs poll
                 try:
                     store.set(ABORT, f"rank {rank}: {why}")
                 except Exception:  # noqa: BLE001
                     pass
             if rank == 0:
-                out["laser_plasma_interaction"] = {"error": why}
+                out[key] = {"error": why}
                 write_line()
-            print(f"[bench] rank {rank}: laser-plasma block abandoned: {why}", file=sys.stderr)
+            print(f"[bench] rank {rank}: {key} block abandoned: {why}", file=sys.stderr)
             sys.stderr.flush()
             if rank == 0 and tell:
                 time.sleep(6.0)  # the store lives in this process: the others poll it every 2 s
@@ -895,6 +1014,28 @@ def main():
         watchdog = threading.Thread(target=watch, daemon=True)
         watchdog.start()
         try:
+            res = body()
+            if rank == 0:
+                out[key] = res
+        except BaseException as e:  # noqa: BLE001
+            # the other subdomains may be waiting in a collective of the block: no further collective from here
+            give_up(f"{type(e).__name__}: {e}")
+        finished.set()
+        if GIVE_UP_ONCE.locked():  # the watchdog fired while the block was finishing: it ends the process
+            time.sleep(3600)
+
+    import threading
+    GIVE_UP_ONCE = threading.Lock()
+    full_line = (args.workload == "two_stream" and not weak and not args.self_exchange and not args.unfused
+                 and (nx, npc) == (C3_CELLS, C3_NPC) and args.elision == "off")
+    if world > 1 and full_line and not args.no_laser_plasma:
+        # BASELINE configs[3] on the same N GPUs: hole_boring.yaml's physics with 1e8 particles, `balance: true`
+        # (subdomains of different sizes, GridDesign::balanced), laser and absorbing ends, timed inside the interaction.
+        # A second set of mailboxes (open ends, room for a relativistic front) is set up for it.
+        lp_npc, lp_warm, lp_steps = 10000, 21000, 2000
+
+        def lp_body():
+            nonlocal link
             link = None
             link3, kind3 = make_link(rank, world, link_device, lp_link_capacity(lp_npc), stream=stream, to_left=rank != 0,
                                      to_right=rank != world - 1, prefer=order,
@@ -909,20 +1050,33 @@ def main():
             t3 = sim3.t
             del sim3, link3
             oa.set_elision(True)
-            if rank == 0:
-                out["laser_plasma_interaction"] = block(
-                    m3, f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]) on "
-                        + (f"{world} GPUs" if backend == "nccl" else f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)")
-                        + f", {lp_npc} e- + {lp_npc} "
-                        f"C6+ per cell in 5000 of 20000 cells, balanced decomposition (subdomain sizes {sizes}), {lp_warm} "
-                        f"untimed steps to bring the pulse onto the slab, then {lp_steps} timed steps ending at "
-                        f"t = {t3:.3e} s; " + CONTRACT, lp_steps, {"link": kind3, "n_gpus": world})
-        except BaseException as e:  # noqa: BLE001
-            # the other subdomains may be waiting in a collective of the block: no further collective from here
-            give_up(f"{type(e).__name__}: {e}")
-        finished.set()
-        if not once.acquire(blocking=False):  # the watchdog fired while the block was finishing: it ends the process
-            time.sleep(3600)
+            return block(
+                m3, f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]) on "
+                    + (f"{world} GPUs" if backend == "nccl" else f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)")
+                    + f", {lp_npc} e- + {lp_npc} "
+                    f"C6+ per cell in 5000 of 20000 cells, balanced decomposition (subdomain sizes {sizes}), {lp_warm} "
+                    f"untimed steps to bring the pulse onto the slab, then {lp_steps} timed steps ending at "
+                    f"t = {t3:.3e} s; " + CONTRACT, lp_steps, {"link": kind3, "n_gpus": world})
+
+        guarded("laser_plasma_interaction", float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300")), lp_body)
+
+    if world > 1 and full_line and not args.no_colliding_beams:
+        # BASELINE configs[4] on the same N GPUs: 4000 cells in N subdomains, the beam and its photons crossing the cuts at
+        # c (links laid out for photon emission: 3 species slots, 12 fields per particle, open ends)
+        def cb_body():
+            nonlocal link
+            link = None
+            cap = int(os.environ.get("OPAL_BENCH_CB_CAPACITY") or (1 << 18))
+            link4, kind4 = make_link(rank, world, link_device, cap, stream=stream, photon_emission=True, to_left=rank != 0,
+                                     to_right=rank != world - 1, prefer=order,
+                                     log=lambda m_: print(m_.replace("[opal_amd]", "[bench]"), file=sys.stderr))
+            res = colliding_beams(link4, CB_WHAT + "; " + (f"{world} GPUs" if backend == "nccl" else
+                                                             f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)"))
+            res.update(link=kind4, n_gpus=world, link_particle_capacity=cap)
+            del link4
+            return res
+
+        guarded("colliding_beams", float(os.environ.get("OPAL_BENCH_CB_DEADLINE", "240")), cb_body)
 
     if rank == 0:
         if world == 1 and args.workload == "two_stream" and not weak and not args.no_secondary and not args.self_exchange \
@@ -955,6 +1109,8 @@ def main():
                         f"per cell in 5000 of 20000 cells, {lp_warm} untimed steps to bring the pulse onto the slab, then "
                         f"{lp_steps} timed steps ending at t = {t3:.3e} s; " + CONTRACT, lp_steps)
             oa.set_elision(True)
+            if not args.unfused and not args.no_colliding_beams:
+                out["colliding_beams"] = colliding_beams(None, CB_WHAT + "; 1 GPU")
         if not args.no_cpu_baseline and world == 1 and args.workload == "two_stream":
             out["cpu_baseline"] = cpu_baseline(oa, nx, npc)
         write_line()

@@ -411,7 +411,8 @@ int opal_stream_destroy(void *stream);
 int opal_prof_enable(int stride);
 int opal_prof_reset(void);
 /* kernel ids: 0 = fused advance+deposit (one launch covers both species when the driver pairs them),
- * 1 = advance, 2 = deposit, 3 = field solve, 4 = re-binning; launches = launches actually timed */
+ * 1 = advance (charged species), 2 = deposit, 3 = field solve, 4 = re-binning, 5 = the photons' push (photon.rs:150-183),
+ * 6 = the emission kernel (interactions.rs:45-107); launches = launches actually timed */
 int opal_prof_get(int kernel, uint64_t *launches, double *total_ms);
 /* launches of the kernel observed since the last reset while the timers were on (timed or not) */
 int opal_prof_seen(int kernel, uint64_t *launches_seen);

@@ -17,7 +17,7 @@ from ._lib import FN1, FN2, FN3
 BDY_INTERNAL, BDY_LASER, BDY_ABSORBING, BDY_CONDUCTING = 0, 1, 2, 3
 ELECTRON, ION, PHOTON = 0, 1, 2
 COMP = {"x": 0, "rho": 1, "jx": 2, "jy": 3, "jz": 4, "Ex": 5, "Ey": 6, "Ez": 7, "Bx": 8, "By": 9, "Bz": 10}
-KERNELS = {"fused": 0, "advance": 1, "deposit": 2, "field": 3, "sort": 4}
+KERNELS = {"fused": 0, "advance": 1, "deposit": 2, "field": 3, "sort": 4, "photon": 5, "radiate": 6}
 
 # src/constants.rs
 SPEED_OF_LIGHT = 2.997925e8

@@ -61,7 +61,8 @@ struct PublishBatch {
 };
 
 enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, EX_TAU_ABS = 6, EX_TAU_ST = 7, EX_BIRTH = 8, NEX = 9 };
-enum { KERNEL_FUSED = 0, KERNEL_ADVANCE = 1, KERNEL_DEPOSIT = 2, KERNEL_FIELD = 3, KERNEL_SORT = 4, KERNEL_COUNT = 5 };
+enum { KERNEL_FUSED = 0, KERNEL_ADVANCE = 1, KERNEL_DEPOSIT = 2, KERNEL_FIELD = 3, KERNEL_SORT = 4, KERNEL_PHOTON = 5,
+       KERNEL_RADIATE = 6, KERNEL_COUNT = 7 };  // (5: the photons' push; 6: k_radiate)
 // which form of the fused / advance push a launch ran (bench.py prices a launch's algorithmic bytes by it):
 // bit 0 electrostatic launch (uy, uz neither read nor written), bit 1 rho deposited, bit 2 / 3 the electrons' / ions'
 // weight taken from the launch arguments instead of streamed; bit 4 a single-species launch (k_push)

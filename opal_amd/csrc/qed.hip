@@ -497,7 +497,9 @@ int opal_emit_radiation(opal_pop_t *e, opal_pop_t *ph, uint64_t seed, uint32_t s
     a.pcap = (unsigned)ph->cap;
     a.seed = seed; a.step = step;
     a.min_energy = min_energy; a.max_angle = max_angle; a.max_formation_length = max_formation_length;
+    prof_begin(KERNEL_RADIATE, e->stream);
     k_radiate<<<(unsigned)std::min<size_t>((emitters + 255) / 256, 2048), 256, 0, e->stream>>>(a);
+    prof_end(KERNEL_RADIATE, e->stream);
     OPAL_HIP(hipGetLastError());
     ph->sorted_exact = false;
     ph->n_upper += emitters;  // upper bound: the filters may have dropped some

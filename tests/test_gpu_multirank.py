@@ -317,6 +317,74 @@ def test_decomposed_run_writes_the_reference_outputs(oracle, tmp_path, link_kind
     assert np.sum(np.abs(data - href["cts"]) > 1e-9 * scale) <= 4
 
 
+def _run_python_launcher(yml, world):
+    import subprocess
+    from test_exchange_gloo import _free_port
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OPAL_BACKEND="gloo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", "opal_amd", str(yml)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, outs[r][-3000:]
+    return outs
+
+
+@pytest.mark.parametrize("world,transport", [(1, None), (2, "peer"), (2, "socket"), (3, "peer")])
+def test_native_launcher_matches_the_python_one(tmp_path, world, transport):
+    """`opal_amd/bin/opal_amd -n N input.yaml` -- the reference's `mpirun -n N opal input.yaml` (main.rs:48-61) with no
+    Python anywhere: the C++ launcher forks N ranks before any GPU call, hands the mailboxes' IPC handles and the
+    transport votes round over Unix sockets, does the output-time reductions over them, rank 0 writes the outputs.
+    Each rank seeds its loader with its rank (main.rs:53), so the same N gives the same run: the files must be those of
+    `python -m opal_amd` on N ranks (grid rows 1e-9, energies to the 7 digits main.rs:35-38 prints)."""
+    import shutil
+    import subprocess
+    from test_gpu_driver import TWO_STREAM
+    exe = os.path.join(ROOT, "opal_amd", "bin", "opal_amd")
+    assert os.path.exists(exe), "opal_amd/bin/opal_amd is built by __graft_entry__.build()"
+    text = TWO_STREAM.replace("npc: 100", "npc: 20")
+    a, b = tmp_path / "native", tmp_path / "python"
+    for d in (a, b):
+        d.mkdir()
+        (d / "two_stream.yaml").write_text(text)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport:
+        env["OPAL_LINK"] = transport
+    cmd = [exe] + (["-n", str(world)] if world > 1 else []) + [str(a / "two_stream.yaml")]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = res.stdout.decode()
+    assert res.returncode == 0, out[-3000:]
+    assert "Output    4 at t =" in out
+    if world > 1:
+        assert {"peer": "Neighbour exchange: peer-mapped mailboxes", "socket": "Neighbour exchange: host-staged messages"}[transport] in out
+    _run_python_launcher(b / "two_stream.yaml", world)
+    files = sorted(f for f in os.listdir(a) if f != "two_stream.yaml")
+    assert files == sorted(f for f in os.listdir(b) if f != "two_stream.yaml")
+    assert files == sorted([f"{i}_{k}" for i in range(5) for k in ("grid.dat", "energy.dat", "electron_x-px.fits")])
+    for i in range(5):
+        ra, rb = np.loadtxt(a / f"{i}_grid.dat"), np.loadtxt(b / f"{i}_grid.dat")
+        assert ra.shape == rb.shape == (1000, 11) and np.array_equal(ra[:, 0], rb[:, 0])
+        for c in range(1, 11):
+            scale = max(np.max(np.abs(rb[:, c])), 1e-300)
+            assert np.max(np.abs(ra[:, c] - rb[:, c])) <= 1e-9 * scale, (i, c)
+        ea = [line.split() for line in open(a / f"{i}_energy.dat")]
+        eb = [line.split() for line in open(b / f"{i}_energy.dat")]
+        assert [k for k, _ in ea] == [k for k, _ in eb]
+        for (k, va), (_, vb) in zip(ea, eb):
+            assert float(va) == pytest.approx(float(vb), rel=2e-6, abs=1e-300), (i, k)
+        assert (a / f"{i}_electron_x-px.fits").stat().st_size == (b / f"{i}_electron_x-px.fits").stat().st_size
+    # a rank that fails ends the whole job with a non-zero status (the reference's panics end an MPI job the same way)
+    bad = tmp_path / "bad.yaml"
+    bad.write_text(text.replace("nx: 1000", "nx: banana"))
+    res = subprocess.run([exe] + (["-n", str(world)] if world > 1 else []) + [str(bad)], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=120)
+    assert res.returncode != 0
+    shutil.rmtree(a)
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_launcher_runs_an_input_file(tmp_path, world):
     """`python -m opal_amd input.yaml`, alone and as 2 ranks (gloo rehearsal of the torchrun + RCCL launch):
