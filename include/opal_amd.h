@@ -343,6 +343,16 @@ typedef int (*opal_exchange2_fn)(void *user, const void *send_left, const void *
 int opal_link_set_exchange2(opal_link_t *l, opal_exchange2_fn exchange2);
 /* on = 0: ship all slots every time even though the transport could take sizes (diagnostic; default on) */
 int opal_link_set_bounded(opal_link_t *l, int on);
+/* Growth.  The reference's receive_vec (particle/mod.rs:308-354) takes messages of any size; a link has buffers.  With
+ * growth on, an edge whose bound -- the particles within reach of the cut on both sides, the numbers both of its ends hold
+ * (link.cpp: link_plan) -- exceeds its room gets larger buffers before the push that could overflow them is enqueued; on a
+ * peer link the two ends hand each other the handle of larger mailboxes through a control line in the old ones, with no
+ * host channel.  Default: on for peer links (what travels is only ever the leavers, so room costs memory, not time), off
+ * for transports that are told a size (their messages follow the bound: a larger room means larger messages); a link whose
+ * buffers belong to the caller (opal_link_set_buffers) cannot grow.  Without growth an overflow is the error it always was. */
+int opal_link_set_growth(opal_link_t *l, int on);
+/* room per species of the left / right edge now, and how often an edge of this link has grown */
+int opal_link_growth(const opal_link_t *l, size_t *cap_left, size_t *cap_right, unsigned *grows);
 /* bytes the last whole-message exchange moved over the left / right edge (0 where there is no neighbour) */
 int opal_link_last_exchange_bytes(const opal_link_t *l, size_t *left, size_t *right);
 int opal_link_free(opal_link_t *l);

@@ -105,6 +105,8 @@ SIGNATURES = {
     "opal_link_create": (C.c_int, [pp, C.c_int, C.c_int, C.c_int, sz, EXCHANGE_FN, vp, vp]),
     "opal_link_set_exchange2": (C.c_int, [vp, EXCHANGE2_FN]),
     "opal_link_set_bounded": (C.c_int, [vp, C.c_int]),
+    "opal_link_set_growth": (C.c_int, [vp, C.c_int]),
+    "opal_link_growth": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint)]),
     "opal_link_last_exchange_bytes": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz)]),
     "opal_link_rccl_ranks": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "opal_link_create_peer": (C.c_int, [pp, C.c_int, C.c_int, sz, C.c_int, C.c_int, vp]),

@@ -82,9 +82,9 @@ int link_begin(opal_link_t *l, hipStream_t st, unsigned species_mask)
 // others reserve the link's capacity).
 int link_plan(opal_link_t *l, unsigned species_mask)
 {
-    const unsigned full = (unsigned)l->cap;
-    l->send_cap[0] = l->send_cap[1] = full;
-    l->plan_cap[0] = l->plan_cap[1] = full;
+    unsigned full[2] = {(unsigned)l->cap_side[0], (unsigned)l->cap_side[1]};
+    l->send_cap[0] = l->plan_cap[0] = full[0];
+    l->send_cap[1] = l->plan_cap[1] = full[1];
     const unsigned X = l->xseq;
     l->ring_mask[X % LINK_RING] = species_mask;
     // A transport that is told a size per edge ships the bound; a peer link ships what leaves (its kernels read the
@@ -146,9 +146,60 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     }
     for (int side = 0; side < 2; side++) {
         unsigned slots = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
-        l->plan_cap[side] = slots < full ? slots : full;
+        if (slots > full[side] && l->growable && need[side]) {
+            // More particles stand within reach of this cut than its messages have room for: the edge grows before the
+            // push that could overflow it is enqueued (the reference's receive_vec takes messages of any size,
+            // particle/mod.rs:308-354).  The other end of the edge reads the same numbers for the same exchange and
+            // grows to the same capacity; a pile-up that moves on leaves the room behind (no shrinking: the memory is
+            // what the densest moment of the run needed at this cut).
+            size_t want = (size_t)slots + slots / 4, cap2 = 1024;
+            while (cap2 < want) cap2 *= 2;
+            if (int rc = link_grow(l, side, cap2)) return rc;
+            full[side] = (unsigned)l->cap_side[side];
+            l->send_cap[side] = full[side];
+        }
+        l->plan_cap[side] = slots < full[side] ? slots : full[side];
         if (sizes_messages) l->send_cap[side] = l->plan_cap[side];
+        else l->send_cap[side] = full[side];
     }
+    return OPAL_OK;
+}
+
+int link_grow(opal_link_t *l, int side, size_t new_cap)
+{
+    new_cap = (new_cap + 63) / 64 * 64;
+    if (new_cap <= l->cap_side[side]) return OPAL_OK;
+    if (l->external) {
+        set_error("link: edge %d needs room for %zu particles per species, but its buffers belong to the caller "
+                  "(opal_link_set_buffers)", side, new_cap);
+        return OPAL_ERR_CAPACITY;
+    }
+    OPAL_HIP(hipStreamSynchronize(l->stream));  // nothing in flight reads or writes the buffers about to go
+    const size_t nb = link_prefix_bytes(l, (unsigned)new_cap);
+    char **dev[2] = {side == 0 ? &l->d_send_left : &l->d_send_right, side == 0 ? &l->d_recv_left : &l->d_recv_right};
+    for (auto d : dev) {
+        char *fresh = nullptr;
+        OPAL_HIP(hipMalloc((void **)&fresh, nb));
+        OPAL_HIP(hipMemset(fresh, 0, nb));
+        // (the header of a send message carries the zone counts of the exchange before: kept)
+        OPAL_HIP(hipMemcpy(fresh, *d, LINK_HEAD_BYTES, hipMemcpyDeviceToDevice));
+        OPAL_HIP(hipFree(*d));
+        *d = fresh;
+    }
+    if (!l->device_buffers) {
+        char **host[2] = {side == 0 ? &l->h_send_left : &l->h_send_right, side == 0 ? &l->h_recv_left : &l->h_recv_right};
+        for (auto h : host) {
+            OPAL_HIP(hipHostFree(*h));
+            OPAL_HIP(hipHostMalloc((void **)h, nb));
+            memset(*h, 0, nb);
+        }
+    }
+    if (l->peer)
+        if (int rc = link_peer_grow(l, side, new_cap)) return rc;
+    l->cap_side[side] = new_cap;
+    l->nbytes_side[side] = nb;
+    l->nbytes = l->nbytes_side[0] > l->nbytes_side[1] ? l->nbytes_side[0] : l->nbytes_side[1];
+    l->grows++;
     return OPAL_OK;
 }
 
@@ -163,8 +214,9 @@ bool link_can_use_stream(const opal_link_t *l, hipStream_t st)
 static int link_move(opal_link_t *l, size_t n_left, size_t n_right, bool to_left, bool to_right, hipStream_t st)
 {
     if (l->set_stream) l->set_stream(l->user, st);
-    if (n_left > l->nbytes || n_right > l->nbytes) {
-        set_error("link exchange: %zu / %zu bytes exceed the link's message size %zu", n_left, n_right, l->nbytes);
+    if (n_left > l->nbytes_side[0] || n_right > l->nbytes_side[1]) {
+        set_error("link exchange: %zu / %zu bytes exceed the edges' message sizes %zu / %zu", n_left, n_right,
+                  l->nbytes_side[0], l->nbytes_side[1]);
         return OPAL_ERR_ARG;
     }
     if (!l->device_buffers) {
@@ -203,8 +255,8 @@ int link_exchange_particles(opal_link_t *l, bool to_left, bool to_right, hipStre
 {
     // without a per-edge transport both edges (and every subdomain) must use one size: the full one
     const bool per_edge = l->exchange2 != nullptr;
-    const size_t n_left = per_edge ? link_prefix_bytes(l, l->send_cap[0]) : l->nbytes;
-    const size_t n_right = per_edge ? link_prefix_bytes(l, l->send_cap[1]) : l->nbytes;
+    const size_t n_left = per_edge ? link_prefix_bytes(l, l->send_cap[0]) : l->nbytes_side[0];
+    const size_t n_right = per_edge ? link_prefix_bytes(l, l->send_cap[1]) : l->nbytes_side[1];
     l->last_bytes[0] = to_left ? n_left : 0;
     l->last_bytes[1] = to_right ? n_right : 0;
     int rc = link_move(l, n_left, n_right, to_left, to_right, st);
@@ -247,6 +299,8 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
     l->layout.nslots = (unsigned)species_slots;
     l->layout.blk = LINK_ROWS * (unsigned)(sizeof(int32_t) + (size_t)fields_per_particle * sizeof(double));
     l->nbytes = link_prefix_bytes(l, (unsigned)particle_capacity);
+    l->cap_side[0] = l->cap_side[1] = particle_capacity;
+    l->nbytes_side[0] = l->nbytes_side[1] = l->nbytes;
     l->send_cap[0] = l->send_cap[1] = (unsigned)particle_capacity;
     l->plan_cap[0] = l->plan_cap[1] = (unsigned)particle_capacity;
     l->bounded = true;  // takes effect once a per-edge transport is set (opal_link_set_exchange2, native links)
@@ -292,6 +346,32 @@ int opal_link_set_exchange2(opal_link_t *l, opal_exchange2_fn exchange2)
         return OPAL_ERR_ARG;
     }
     l->exchange2 = exchange2;
+    return OPAL_OK;
+}
+
+int opal_link_set_growth(opal_link_t *l, int on)
+{
+    if (!l) {
+        set_error("opal_link_set_growth: null link");
+        return OPAL_ERR_ARG;
+    }
+    if (on && l->external) {
+        set_error("opal_link_set_growth: the link's buffers belong to the caller (opal_link_set_buffers)");
+        return OPAL_ERR_ARG;
+    }
+    l->growable = on != 0;
+    return OPAL_OK;
+}
+
+int opal_link_growth(const opal_link_t *l, size_t *cap_left, size_t *cap_right, unsigned *grows)
+{
+    if (!l) {
+        set_error("opal_link_growth: null link");
+        return OPAL_ERR_ARG;
+    }
+    if (cap_left) *cap_left = l->cap_side[0];
+    if (cap_right) *cap_right = l->cap_side[1];
+    if (grows) *grows = l->grows;
     return OPAL_OK;
 }
 

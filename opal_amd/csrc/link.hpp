@@ -62,11 +62,16 @@ struct opal_link {
     bool device_buffers;
     bool external;  // buffers the transport sees belong to the caller
     bool counts_clean;  // the send messages' leaver counts are known to be zero (see link_begin)
-    size_t cap;     // particles per species per direction the buffers have room for
+    size_t cap;     // particles per species per direction the link was created with room for (the smaller of cap_side)
+    size_t cap_side[2];   // ... and what the buffers (and, peer links, the mailboxes) of the left / right edge have room for NOW:
+                          // an edge grows when the bound on what can cross it exceeds its room (link_plan, link_grow)
+    size_t nbytes_side[2];  // bytes of a message of that edge with every slot in use
+    bool growable;        // edges grow instead of overflowing (default: peer links; opal_link_set_growth)
+    unsigned grows;       // how often an edge of this link has grown (diagnostic)
     int nslots;     // species blocks per message: 2 (electrons, ions) or 3 (+ photons)
     int nfields;    // doubles per particle: 6 (x ux uy uz w prev_x), 12 (+ chi work y z tau id) or 15 (+ tau_abs tau_st birth)
     opal::LinkLayout layout;
-    size_t nbytes;  // a message with all `cap` slots
+    size_t nbytes;  // a message with all `cap` slots (the larger edge's: max of nbytes_side)
     opal_exchange_fn exchange;
     opal_exchange2_fn exchange2;  // optional: per-edge sizes (see link_exchange_particles)
     void *user;
@@ -112,6 +117,12 @@ bool link_is_peer(const opal_link_t *l);
 // = where the halo is packed from, or null when the send messages already hold it
 int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, const HaloSrc *halo, PeerArgs &a);
 void link_peer_free(opal_link_t *l);
+// Makes room for `new_cap` particles per species on edge `side` (0 left, 1 right): new send / recv buffers, and on a peer
+// link new mailboxes, whose handle the two ends of the edge hand each other through a control line in the OLD mailboxes
+// (peer.hip).  Both ends of an edge call it for the same exchange with the same capacity (link_plan decides from numbers
+// both hold).  Drains the link's stream.
+int link_grow(opal_link_t *l, int side, size_t new_cap);
+int link_peer_grow(opal_link_t *l, int side, size_t new_cap);
 // OPAL_ERR_LINK if a wait for a neighbour's message has ever timed out on this link (peer links; OPAL_OK for the others).
 // Synchronises with the link's stream: called where the host waits for the device anyway.
 int link_peer_check(opal_link_t *l);

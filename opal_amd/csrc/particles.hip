@@ -48,9 +48,6 @@ constexpr int BLOCK = 256;
 #ifndef OPAL_ES_PPT
 #define OPAL_ES_PPT 16  // the same for a population the electrostatic launch serves (see pop_max_ppt)
 #endif
-#ifndef OPAL_PPT_ROUNDS
-#define OPAL_PPT_ROUNDS 1  // chunk lengths of the electrostatic launch chosen by whole rounds of the chip (pop_max_ppt)
-#endif
 #ifndef OPAL_TWO_SIDED_TAIL
 #define OPAL_TWO_SIDED_TAIL 1  // chunks of arrivals are taken by two workgroups, one per half of the subdomain (push_body)
 #endif
@@ -85,37 +82,12 @@ int pop_max_ppt(const opal_pop_t *p)
     static const int forced = getenv("OPAL_PPT") ? atoi(getenv("OPAL_PPT")) : 0;  // experiments
     if (forced > 0) return std::min(forced, 32);
     if (!(g_elision && p->cold_yz && p->species != OPAL_PHOTON)) return OPAL_MAX_PPT;
-    static const int rounds_aware = getenv("OPAL_PPT_ROUNDS") ? atoi(getenv("OPAL_PPT_ROUNDS")) : OPAL_PPT_ROUNDS;
-    if (!rounds_aware) {
-        const size_t by_size = p->n_upper / ((size_t)BLOCK * 8192);  // keep >= 8192 workgroups per species
-        return (int)std::min<size_t>(OPAL_ES_PPT, std::max<size_t>(OPAL_MAX_PPT, by_size));
-    }
-    // Round 4: the chunk length that makes the launch a whole number of ROUNDS of the chip.  The electrostatic launch keeps 8
-    // workgroups per CU resident (64 VGPRs, 19 KB of LDS each): R = 8 x CUs at a time, and a launch of W workgroups of L
-    // slots costs about ceil(W / R) x (L + F), F being a workgroup's fixed cost in slot-times (tile set-up, replica fold:
-    // ~12 % of a 2048-slot chunk as measured by what 4096-slot chunks gained at 1e8 particles).  With 1.25e7 slots in the
-    // paired launch (one GPU's share of configs[2] at N = 8) 2048-slot chunks make 2.98 rounds, 4096-slot chunks 1.49 --
-    // i.e. two, a third of the second one idle -- and 6144-slot chunks exactly one.
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
-    static const double F = getenv("OPAL_PPT_FIXED") ? atof(getenv("OPAL_PPT_FIXED")) : 250.0;
-    const double R = 8.0 * cus, S = 2.0 * (double)p->n_upper;  // both species of the paired launch, of similar size
-    int best = OPAL_MAX_PPT;
-    double best_cost = 1e300;
-    for (int ppt = OPAL_MAX_PPT; ppt <= 32; ppt += 2) {
-        const double L = (double)BLOCK * ppt, W = std::ceil(S / L);
-        const double cost = std::ceil(W / R) * (L + F);
-        if (cost < best_cost * 0.995) {  // (ties go to the shorter chunk)
-            best_cost = cost;
-            best = ppt;
-        }
-    }
-    return best;
+    const size_t by_size = p->n_upper / ((size_t)BLOCK * 8192);  // keep >= 8192 workgroups per species
+    // (Round 4 tried chunk lengths that make the launch a whole number of rounds of the chip -- 6144 slots at one GPU's
+    // share of configs[2] at N = 8: exactly one round instead of 2.98 -- and lost 15 % there, 4 % at configs[1], 2-3 % at
+    // configs[2]: profiles/r04_ab/ab_ppt_rounds.txt.  Workgroups that all start together stay in step; it is the
+    // staggered rounds that keep the memory system busy while some of them set up tiles or fold replicas.)
+    return (int)std::min<size_t>(OPAL_ES_PPT, std::max<size_t>(OPAL_MAX_PPT, by_size));
 }
 enum { EDGE_WRAP = 0, EDGE_DELETE = 1, EDGE_SEND = 2 };
 

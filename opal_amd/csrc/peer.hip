@@ -5,20 +5,34 @@
 #include <unistd.h>
 #include "peer_device.hpp"
 
+#include <chrono>
 #include <cstring>
 
 using namespace opal;
 
 struct opal_peer {
-    char *box_mem = nullptr;   // my four mailboxes: [from left | from right] x [parity 0 | 1], each `stride` bytes
-    size_t stride = 0;         // flag line + message, rounded up to 256
-    char *peer_base[2] = {nullptr, nullptr};  // where my messages go: the left neighbour's from-right pair, the right neighbour's from-left pair
-    size_t total = 0;                         // bytes of box_mem
+    // my mailboxes for the messages FROM the left / right neighbour: a control line (PEER_CTL_BYTES), then parity 0 | 1,
+    // each stride[side] bytes.  At creation both sides live in one allocation (base0: one IPC handle to hand round); an
+    // edge that has grown has an allocation of its own.
+    char *box_mem[2] = {nullptr, nullptr};
+    size_t stride[2] = {0, 0};      // flag line + message, rounded up to 256
+    char *base0 = nullptr;          // the allocation of creation
+    bool own[2] = {false, false};   // box_mem[side] is an allocation of its own (grown)
+    char *peer_base[2] = {nullptr, nullptr};  // the neighbour's mailboxes for MY messages (its control line first)
+    size_t total0 = 0;                        // bytes of base0
     void *mapped[2] = {nullptr, nullptr};     // hipIpcOpenMemHandle mappings to close (null: the neighbour is in this process)
+    bool self[2] = {false, false};            // the neighbour on that side is this very link
     unsigned *d_err = nullptr;
     unsigned seq = 0;          // exchanges made so far
+    unsigned gen[2] = {0, 0};  // growths of each edge so far
     bool connected = false;
     int alloc_kind = 0;        // 0 uncached, 1 fine-grained, 2 plain device memory
+};
+
+// what travels through an edge's control line when it grows
+struct PeerCtl {
+    unsigned gen, cap;
+    char handle[OPAL_PEER_HANDLE_BYTES];
 };
 
 namespace {
@@ -32,7 +46,7 @@ __global__ __launch_bounds__(1024) void k_peer_move(PeerArgs a, char *recv_left,
     for (int side = 0; side < 2; side++) {
         if (!a.box[side]) continue;
         const char *msg = a.box[side] + PEER_FLAG_BYTES;
-        const unsigned words = peer_prefix_words(msg, a);
+        const unsigned words = peer_prefix_words(msg, a, side);
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(side == 0 ? recv_left : recv_right);
         for (unsigned i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
@@ -77,7 +91,8 @@ int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, 
     a.enabled = 1;
     a.seq = p->seq;
     a.layout = l->layout;
-    a.cap = (unsigned)l->cap;
+    a.cap[0] = (unsigned)l->cap_side[0];
+    a.cap[1] = (unsigned)l->cap_side[1];
     a.head_only = head_only;
     a.err = p->d_err;
     if (halo) {
@@ -87,13 +102,13 @@ int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, 
     // what I send left lands in the left neighbour's from-right mailbox, and the other way round
     if (to_left) {
         a.send[0] = l->d_send_left;
-        a.dst[0] = p->peer_base[0] + par * p->stride;
-        a.box[0] = p->box_mem + (0 * 2 + par) * p->stride;
+        a.dst[0] = p->peer_base[0] + PEER_CTL_BYTES + par * p->stride[0];
+        a.box[0] = p->box_mem[0] + PEER_CTL_BYTES + par * p->stride[0];
     }
     if (to_right) {
         a.send[1] = l->d_send_right;
-        a.dst[1] = p->peer_base[1] + par * p->stride;
-        a.box[1] = p->box_mem + (1 * 2 + par) * p->stride;
+        a.dst[1] = p->peer_base[1] + PEER_CTL_BYTES + par * p->stride[1];
+        a.box[1] = p->box_mem[1] + PEER_CTL_BYTES + par * p->stride[1];
     }
     return OPAL_OK;
 }
@@ -110,7 +125,9 @@ void link_peer_free(opal_link_t *l)
     if (!p) return;
     for (int s = 0; s < 2; s++)
         if (p->mapped[s] && (s == 0 || p->mapped[1] != p->mapped[0])) hipIpcCloseMemHandle(p->mapped[s]);
-    if (p->box_mem) hipFree(p->box_mem);
+    for (int s = 0; s < 2; s++)
+        if (p->own[s] && p->box_mem[s]) hipFree(p->box_mem[s]);
+    if (p->base0) hipFree(p->base0);
     if (p->d_err) hipFree(p->d_err);
     delete p;
     l->peer = nullptr;
@@ -119,29 +136,136 @@ void link_peer_free(opal_link_t *l)
 }  // namespace opal
 
 // memory both ends see coherently: uncached, else fine-grained; OPAL_PEER_ALLOC=plain|fine|uncached overrides
-static hipError_t peer_alloc(opal_peer *p, char **mem)
+static hipError_t peer_alloc(opal_peer *p, char **mem, size_t bytes)
 {
     const char *want = getenv("OPAL_PEER_ALLOC");
     hipError_t e = hipErrorUnknown;
     if (!want || !strcmp(want, "uncached")) {
-        e = hipExtMallocWithFlags((void **)mem, p->total, hipDeviceMallocUncached);
+        e = hipExtMallocWithFlags((void **)mem, bytes, hipDeviceMallocUncached);
         p->alloc_kind = 0;
     }
     if (e != hipSuccess && (!want || !strcmp(want, "fine"))) {
-        e = hipExtMallocWithFlags((void **)mem, p->total, hipDeviceMallocFinegrained);
+        e = hipExtMallocWithFlags((void **)mem, bytes, hipDeviceMallocFinegrained);
         p->alloc_kind = 1;
     }
     if (e != hipSuccess && want && !strcmp(want, "plain")) {
-        e = hipMalloc((void **)mem, p->total);
+        e = hipMalloc((void **)mem, bytes);
         p->alloc_kind = 2;
     }
     if (e != hipSuccess) (void)hipGetLastError();
     return e;
 }
 
-extern "C" {
+static size_t peer_stride(const opal_link_t *l, size_t cap)
+{
+    return (PEER_FLAG_BYTES + link_prefix_bytes(l, (unsigned)cap) + 255) / 256 * 256;
+}
 
-int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges);
+// The export of a fresh allocation has been seen to fail once ("invalid argument", one of four processes sharing a card,
+// right after each had freed an exported allocation): tried again, then with another allocation, before the caller is told
+// to use another transport.
+static int peer_export(opal_peer *p, char **mem, size_t bytes, void *handle64)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == OPAL_PEER_HANDLE_BYTES, "IPC handle size");
+    hipIpcMemHandle_t h;
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        e = hipIpcGetMemHandle(&h, *mem);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        usleep(20000u << attempt);
+        if (attempt >= 1 && attempt < 3) {  // (a fresh allocation after the last attempt would never be exported)
+            char *fresh = nullptr;
+            if (peer_alloc(p, &fresh, bytes) == hipSuccess) {  // (while the old one is still held: another address)
+                hipFree(*mem);
+                *mem = fresh;
+                OPAL_HIP(hipMemset(*mem, 0, bytes));
+                OPAL_HIP(hipDeviceSynchronize());
+            }
+        }
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipIpcGetMemHandle(mailboxes), 4 attempts");
+    memcpy(handle64, &h, sizeof h);
+    return OPAL_OK;
+}
+
+namespace opal {
+
+// Edge `side` gets mailboxes with room for `new_cap` particles per species.  Both ends of the edge are here for the same
+// exchange (link_plan decides from numbers both hold) and have drained their streams: my tail kernel of the exchange
+// before has consumed the neighbour's last message, so the neighbour has written its last word into my old mailboxes, and
+// I mine into its.  Each end allocates, exports, writes {generation, capacity, handle} into the control line of the other's
+// OLD mailboxes (a plain copy through the mapping it already holds), waits for the other's record in its own control line,
+// maps the new mailboxes and lets the old ones go.  No host channel is needed, and nobody but the two ends takes part.
+int link_peer_grow(opal_link_t *l, int side, size_t new_cap)
+{
+    opal_peer *p = l->peer;
+    if (!p || !p->connected) return OPAL_OK;  // (not connected yet: opal_link_peer_connect takes the capacities as they are)
+    OPAL_HIP(hipDeviceSynchronize());
+    const size_t stride = peer_stride(l, new_cap), bytes = PEER_CTL_BYTES + 2 * stride;
+    char *fresh = nullptr;
+    hipError_t e = peer_alloc(p, &fresh, bytes);
+    if (e != hipSuccess) return hip_fail(e, "allocating larger peer mailboxes");
+    OPAL_HIP(hipMemset(fresh, 0, bytes));
+    OPAL_HIP(hipDeviceSynchronize());
+    const unsigned gen = ++p->gen[side];
+    auto retire = [&](int s) {  // my old mailboxes of side s
+        if (p->own[s]) hipFree(p->box_mem[s]);
+        p->own[s] = true;
+        if (p->base0 && p->own[0] && p->own[1]) {
+            hipFree(p->base0);
+            p->base0 = nullptr;
+        }
+    };
+    if (p->self[side]) {
+        // a lone periodic subdomain is its own neighbour: what it sends through this side lands in the mailboxes of its
+        // OTHER side, which link_plan grows in the same call (the two edges read the same numbers)
+        retire(side);
+        p->box_mem[side] = fresh;
+        p->stride[side] = stride;
+        p->peer_base[1 - side] = fresh;
+        return OPAL_OK;
+    }
+    PeerCtl mine;
+    memset(&mine, 0, sizeof mine);
+    mine.gen = gen;
+    mine.cap = (unsigned)new_cap;
+    if (int rc = peer_export(p, &fresh, bytes, mine.handle)) return rc;
+    OPAL_HIP(hipMemcpy(p->peer_base[side], &mine, sizeof mine, hipMemcpyHostToDevice));
+    PeerCtl theirs;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        OPAL_HIP(hipMemcpy(&theirs, p->box_mem[side], sizeof theirs, hipMemcpyDeviceToHost));
+        if (theirs.gen == gen) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+            set_error("peer link: the neighbour on side %d never sent the handle of its larger mailboxes (growth %u to %zu "
+                      "particles per species)", side, gen, new_cap);
+            return OPAL_ERR_LINK;
+        }
+        usleep(200);
+    }
+    if (theirs.cap != mine.cap) {
+        set_error("peer link: the two ends of edge %d disagree on its new capacity (%u here, %u there)", side, mine.cap, theirs.cap);
+        return OPAL_ERR_LINK;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, theirs.handle, sizeof h);
+    void *map = nullptr;
+    OPAL_HIP(hipIpcOpenMemHandle(&map, h, hipIpcMemLazyEnablePeerAccess));
+    // the mapping of the neighbour's old mailboxes is shared by both sides when both neighbours are one subdomain
+    void *old = p->mapped[side];
+    p->mapped[side] = map;
+    if (old && old != p->mapped[1 - side]) hipIpcCloseMemHandle(old);
+    p->peer_base[side] = static_cast<char *>(map);
+    retire(side);
+    p->box_mem[side] = fresh;
+    p->stride[side] = stride;
+    return OPAL_OK;
+}
+
+}  // namespace opal
+
+extern "C" {
 
 int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle_capacity, int species_slots,
                           int fields_per_particle, void *hip_stream)
@@ -158,19 +282,22 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
     l->exchange2 = peer_exchange2;
     l->bounded = false;  // no message size to plan: the sending kernel ships what the leavers occupy (link_plan still
                          // keeps plan_cap, the room the populations reserve for arrivals)
+    l->growable = !getenv("OPAL_LINK_NO_GROWTH");  // an edge grows when more particles stand near it than it has room for
     opal_peer *p = new opal_peer();
     l->peer = p;
-    p->stride = (PEER_FLAG_BYTES + l->nbytes + 255) / 256 * 256;
-    const size_t total = 4 * p->stride;
-    p->total = total;
-    hipError_t e = peer_alloc(p, &p->box_mem);
+    p->stride[0] = p->stride[1] = peer_stride(l, l->cap);
+    const size_t region = PEER_CTL_BYTES + 2 * p->stride[0];
+    p->total0 = 2 * region;
+    hipError_t e = peer_alloc(p, &p->base0, p->total0);
     if (e != hipSuccess) {
-        p->box_mem = nullptr;
+        p->base0 = nullptr;
         opal_link_free(l);
         *out = nullptr;
         return hip_fail(e, "allocating the peer mailboxes");
     }
-    e = hipMemset(p->box_mem, 0, total);
+    p->box_mem[0] = p->base0;
+    p->box_mem[1] = p->base0 + region;
+    e = hipMemset(p->base0, 0, p->total0);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(p->d_err, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -188,31 +315,14 @@ int opal_link_peer_export(opal_link_t *l, void *handle64)
         set_error("opal_link_peer_export: not a link made by opal_link_create_peer");
         return OPAL_ERR_ARG;
     }
-    static_assert(sizeof(hipIpcMemHandle_t) == OPAL_PEER_HANDLE_BYTES, "IPC handle size");
-    hipIpcMemHandle_t h;
     opal_peer *p = l->peer;
-    // The export of a fresh allocation has been seen to fail once ("invalid argument", one of four processes sharing a
-    // card, right after each had freed an exported allocation): tried again, then with another allocation, before the
-    // caller is told to use another transport.
-    hipError_t e = hipSuccess;
-    for (int attempt = 0; attempt < 4; attempt++) {
-        e = hipIpcGetMemHandle(&h, p->box_mem);
-        if (e == hipSuccess) break;
-        (void)hipGetLastError();
-        usleep(20000u << attempt);
-        if (attempt >= 1 && attempt < 3) {  // (a fresh allocation after the last attempt would never be exported)
-            char *fresh = nullptr;
-            if (peer_alloc(p, &fresh) == hipSuccess) {  // (while the old one is still held: another address)
-                hipFree(p->box_mem);
-                p->box_mem = fresh;
-                OPAL_HIP(hipMemset(p->box_mem, 0, p->total));
-                OPAL_HIP(hipDeviceSynchronize());
-            }
-        }
+    char *before = p->base0;
+    int rc = peer_export(p, &p->base0, p->total0, handle64);
+    if (p->base0 != before) {  // (exported from a fresh allocation)
+        p->box_mem[0] = p->base0;
+        p->box_mem[1] = p->base0 + p->total0 / 2;
     }
-    if (e != hipSuccess) return hip_fail(e, "hipIpcGetMemHandle(mailboxes), 4 attempts");
-    memcpy(handle64, &h, sizeof h);
-    return OPAL_OK;
+    return rc;
 }
 
 int opal_link_peer_connect(opal_link_t *l, const void *left_handle64, const void *right_handle64)
@@ -230,7 +340,8 @@ int opal_link_peer_connect(opal_link_t *l, const void *left_handle64, const void
     char *base[2];
     for (int s = 0; s < 2; s++) {
         if (!hs[s]) {
-            base[s] = p->box_mem;  // the neighbour on that side is this very link (a lone periodic subdomain)
+            base[s] = p->base0;  // the neighbour on that side is this very link (a lone periodic subdomain)
+            p->self[s] = true;
         } else if (s == 1 && hs[0] && !memcmp(hs[0], hs[1], OPAL_PEER_HANDLE_BYTES)) {
             p->mapped[1] = p->mapped[0];  // two subdomains: both neighbours are the same one, mapped once
             base[1] = base[0];
@@ -241,8 +352,9 @@ int opal_link_peer_connect(opal_link_t *l, const void *left_handle64, const void
             base[s] = static_cast<char *>(p->mapped[s]);
         }
     }
-    p->peer_base[0] = base[0] + 2 * p->stride;  // the left neighbour's from-right pair
-    p->peer_base[1] = base[1];                  // the right neighbour's from-left pair
+    // (every subdomain is created with the same capacity: the neighbours' regions are as long as mine)
+    p->peer_base[0] = base[0] + p->total0 / 2;  // the left neighbour's from-right mailboxes
+    p->peer_base[1] = base[1];                  // the right neighbour's from-left mailboxes
     p->connected = true;
     return OPAL_OK;
 }
@@ -318,6 +430,7 @@ int opal_link_plan_selftest(void)
         opal_peer pp;
         pp.connected = true;
         l.cap = 1u << 20;
+        l.cap_side[0] = l.cap_side[1] = l.cap;
         l.nslots = 3;
         l.nfields = 6;
         l.bounded = !peer;

@@ -25,6 +25,8 @@
 
 namespace opal {
 constexpr size_t PEER_FLAG_BYTES = 64;          // the sequence number's line, in front of the message
+constexpr size_t PEER_CTL_BYTES = 256;          // in front of an edge's two mailboxes: the line through which the two ends of
+                                                // the edge hand each other the handle of LARGER mailboxes (peer.hip: link_peer_grow)
 constexpr long long PEER_TIMEOUT_TICKS = 2000000000LL;  // 20 s of wall_clock64() (100 MHz)
 
 // what a packed halo is read from (grid rows), when the sending kernel packs it itself
@@ -41,7 +43,7 @@ struct PeerArgs {
     const char *box[2];    // my mailboxes for this exchange: [0] from the left neighbour, [1] from the right one
     unsigned seq;          // this exchange's sequence number (>= 1, monotonic)
     LinkLayout layout;
-    unsigned cap;          // slots per species a message has room for
+    unsigned cap[2];       // slots per species a message of the left / right edge has room for
     int head_only;         // halo-only exchange (yee.rs:358-409 on its own): header + halo, no leavers
     int pack_halo;         // the halo is taken from the grid rows (HaloSrc) instead of the send message
     HaloSrc halo;
@@ -60,14 +62,14 @@ __device__ inline double halo_value(const HaloSrc &h, int side, int r)
 }
 
 // bytes of a message that carry something: header + halo + the row blocks its leavers reach into
-__device__ inline unsigned peer_prefix_words(const char *msg, const PeerArgs &a)
+__device__ inline unsigned peer_prefix_words(const char *msg, const PeerArgs &a, int side)
 {
     if (a.head_only) return (unsigned)(LINK_HEAD_BYTES / 8);
     const unsigned *head = reinterpret_cast<const unsigned *>(msg);
     unsigned m = 0;
     for (unsigned s = 0; s < a.layout.nslots; s++) {
         unsigned c = head[LINK_H_COUNT + s];
-        c = c < a.cap ? c : a.cap;
+        c = c < a.cap[side] ? c : a.cap[side];
         m = m > c ? m : c;
     }
     const unsigned blocks = (m + LINK_ROWS - 1) / LINK_ROWS;
@@ -95,7 +97,7 @@ __device__ inline void peer_send(const PeerArgs &a)
     for (int side = 0; side < 2; side++) {
         const char *msg = a.send[side];
         if (!msg) continue;
-        const unsigned words = peer_prefix_words(msg, a);
+        const unsigned words = peer_prefix_words(msg, a, side);
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES);
         for (unsigned i = HEAD_WORDS + threadIdx.x; i < words; i += blockDim.x)

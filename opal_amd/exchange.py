@@ -279,6 +279,12 @@ class PeerLink:
     def set_bounded(self, on=True):
         pass  # nothing to plan: a message is as long as the leavers it carries
 
+    def growth(self):
+        """(room per species of the left edge, of the right edge, how often an edge has grown)"""
+        a, b, n = C.c_size_t(), C.c_size_t(), C.c_uint()
+        self._lib.opal_link_growth(self.h, C.byref(a), C.byref(b), C.byref(n))
+        return a.value, b.value, n.value
+
 
 def make_link(rank, world, device, particle_capacity, stream=None, photon_emission=False, photon_absorption=False,
               to_left=True, to_right=True, prefer=("peer", "rccl", "torch"), log=None):

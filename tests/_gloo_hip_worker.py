@@ -121,6 +121,8 @@ def main():
     kind = os.environ.get("OPAL_TEST_LINK", "gloo")
     peer = kind == "peer"
     cap = 128 if mode != "qed" else 1024
+    if os.environ.get("OPAL_TEST_LINK_CAP"):
+        cap = int(os.environ["OPAL_TEST_LINK_CAP"])
     if world == 1:
         link = None
     elif kind == "auto":
@@ -161,7 +163,8 @@ def main():
             g.synchronize(zero, zero, t, dt, link)
             g.advance(dt)
             t += dt
-        dump(outdir, rank, g, pe, pi)
+        pe.total_kinetic_energy()  # (a status check: an overflow of the link surfaces here)
+        dump(outdir, rank, g, pe, pi, {"link_growth": np.array(link.growth() if hasattr(link, "growth") else (0, 0, 0))})
     elif mode == "qed":
         deposit = nx == 1  # argv[3] doubles as the current_deposition switch in this mode
         text = QED_YAML.replace("current_deposition: false", "current_deposition: true") if deposit else QED_YAML

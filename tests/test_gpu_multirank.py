@@ -207,6 +207,53 @@ def test_receiving_subdomain_grows_its_storage(oracle, tmp_path, link_kind):
         assert len(a["x"]) == 0 or np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
 
 
+def test_a_link_grows_instead_of_overflowing(oracle, tmp_path, monkeypatch):
+    """The reference's receive_vec takes messages of any size (particle/mod.rs:308-354).  A peer link created with room
+    for 64 leavers per cut and species meets a bunch that sends ~500 per step through the cut: the edge must grow -- the two
+    ends hand each other larger mailboxes through the old ones, no host channel -- BEFORE anything overflows, and the run
+    must end with the oracle world's populations.  With growth switched off the same run ends in the overflow error."""
+    o = oracle
+    world, nx, npc, steps = 2, 48, 600, 70
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    monkeypatch.setenv("OPAL_TEST_LINK", "peer")
+    monkeypatch.setenv("OPAL_TEST_LINK_CAP", "64")
+    _launch("_gloo_hip_worker.py", world, ["grow", tmp_path, nx, npc, steps, 1])
+    nxs, offs = o.design_unbalanced(world, nx, dx)
+    rng = np.random.default_rng(9)
+    n = nx * npc
+    cell = rng.integers(0, nx // 2, n)
+    st = (cell, rng.random(n), 0.5 + 0.05 * rng.standard_normal(n), np.zeros(n), np.zeros(n),
+          1.0e3 * (1.0 + 1e-9 * np.arange(n)))
+    grids = [o.Grid(r, world, o.BDY_LASER, o.BDY_ABSORBING, 0.0, dx, nxs, offs) for r in range(world)]
+    pes = [o.Population.from_soa(o.ELECTRON, *split(st, nxs, r), dx, dt) for r in range(world)]
+    pis = [o.Population.from_soa(o.ION, *split(st, nxs, r), dx, dt) for r in range(world)]
+    t, most = 0.0, 0
+    zero = lambda t_, x_: 0.0
+    for _ in range(steps):
+        before = len(pes[1])
+        assert o.world_step(grids, pes, pis, True, t, dt, laser_y=zero, laser_z=zero) == 0
+        most = max(most, len(pes[1]) - before)   # (rank 1 only gains here: its own leavers go out of the far, open end much later)
+        t += dt
+    assert most > 4 * 64  # several times the room the link was created with crossed the cut in one step
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    for r in range(world):
+        cl, cr, grows = [int(v) for v in got[r]["link_growth"]]
+        assert grows >= 1 and (cr if r == 0 else cl) >= most, (r, cl, cr, grows, most)
+        assert len(got[r]["e_w"]) == len(pes[r]) and len(got[r]["i_w"]) == len(pis[r])
+        a = _by_w(got[r], "e")
+        ref = pes[r].soa()
+        order = np.argsort(ref["w"], kind="stable")
+        assert np.array_equal(a["w"], ref["w"][order])
+        assert np.array_equal(a["cell"], ref["cell"][order].astype(np.int32))
+        assert len(a["x"]) == 0 or np.max(np.abs(a["x"] - ref["x"][order])) < 1e-9
+    # the same run on a link that may not grow: the overflow is reported, not absorbed
+    monkeypatch.setenv("OPAL_LINK_NO_GROWTH", "1")
+    (tmp_path / "nogrow").mkdir()
+    with pytest.raises(AssertionError, match="leaver buffer overflow"):
+        _launch("_gloo_hip_worker.py", world, ["grow", tmp_path / "nogrow", nx, npc, steps, 1])
+
+
 @pytest.mark.parametrize("world,deposit", [(2, 0), (3, 0), (2, 1)])
 def test_photon_emission_across_subdomains(oracle, tmp_path, world, deposit, link_kind):
     """Config C5's physics decomposed: electrons carry their optical depths and ids across the cuts, photons
