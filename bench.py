@@ -228,7 +228,7 @@ LONG_STEPS = 200   # a second timed region of this length follows a shorter --st
 def lp_link_capacity(npc):
     """Room in a laser-plasma link for the leavers of one step through one cut, per species: at most the occupants of
     the cell next to the cut (nobody moves a whole cell per step).  The hole-boring front piles the particles up:
-    scripts/lp_pileup_probe.py finds up to 47 (electrons) / 93 (ions, which cross at a fraction of a cell per step) times the
+    scripts/archive/lp_pileup_probe.py finds up to 47 (electrons) / 93 (ions, which cross at a fraction of a cell per step) times the
     initial particles per cell in one cell during the interaction, so 2 npc (a front at the initial density) and then 32 npc overflowed -- reported as the
     error it is -- at 4, 5 and 6 subdomains with 1e8 particles.  128 npc; what travels is still only the actual
     leavers: capacity costs mailbox memory (0.5 GB per subdomain at npc = 10 000)."""

@@ -36,7 +36,7 @@ def main(argv):
         # room in the buffers for the leavers of one step through one cut, per species (an overflow is reported as an
         # error); what travels each step is sized to the particles within 3 cells of each cut, not to this
         # (a hole-boring front piles the particles up to 47 (electrons) / 93 (ions) times the initial density before it meets a cut --
-        # scripts/lp_pileup_probe.py --: room for 128 cells' worth of the densest species, at least 65536)
+        # scripts/archive/lp_pileup_probe.py --: room for 128 cells' worth of the densest species, at least 65536)
         npc = 0
         for sec in ("electrons", "ions"):
             try:

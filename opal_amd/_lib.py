@@ -180,7 +180,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         if "OPAL_AMD_LIB" in os.environ and not hasattr(lib, name):
-            continue  # A/B runs of an older build (scripts/ab_run2.sh); the in-tree library must export everything
+            continue  # A/B runs of an older build (scripts/archive/ab_run2.sh); the in-tree library must export everything
         fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
