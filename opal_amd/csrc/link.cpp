@@ -144,62 +144,82 @@ int link_plan(opal_link_t *l, unsigned species_mask)
             need[side] = need[side] > n ? need[side] : n;
         }
     }
+    unsigned slots[2];
+    size_t grow_to[2] = {0, 0};
     for (int side = 0; side < 2; side++) {
-        unsigned slots = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
-        if (slots > full[side] && l->growable && need[side]) {
+        slots[side] = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+        if (slots[side] > full[side] && l->growable && need[side]) {
             // More particles stand within reach of this cut than its messages have room for: the edge grows before the
             // push that could overflow it is enqueued (the reference's receive_vec takes messages of any size,
             // particle/mod.rs:308-354).  The other end of the edge reads the same numbers for the same exchange and
             // grows to the same capacity; a pile-up that moves on leaves the room behind (no shrinking: the memory is
             // what the densest moment of the run needed at this cut).
-            size_t want = (size_t)slots + slots / 4, cap2 = 1024;
+            size_t want = (size_t)slots[side] + slots[side] / 4, cap2 = 1024;
             while (cap2 < want) cap2 *= 2;
-            if (int rc = link_grow(l, side, cap2)) return rc;
-            full[side] = (unsigned)l->cap_side[side];
-            l->send_cap[side] = full[side];
+            grow_to[side] = cap2;
         }
-        l->plan_cap[side] = slots < full[side] ? slots : full[side];
-        if (sizes_messages) l->send_cap[side] = l->plan_cap[side];
-        else l->send_cap[side] = full[side];
+    }
+    if (grow_to[0] || grow_to[1]) {
+        if (int rc = link_grow(l, grow_to)) return rc;
+        full[0] = (unsigned)l->cap_side[0];
+        full[1] = (unsigned)l->cap_side[1];
+    }
+    for (int side = 0; side < 2; side++) {
+        l->plan_cap[side] = slots[side] < full[side] ? slots[side] : full[side];
+        l->send_cap[side] = sizes_messages ? l->plan_cap[side] : full[side];
     }
     return OPAL_OK;
 }
 
-int link_grow(opal_link_t *l, int side, size_t new_cap)
+int link_grow(opal_link_t *l, const size_t new_cap_in[2])
 {
-    new_cap = (new_cap + 63) / 64 * 64;
-    if (new_cap <= l->cap_side[side]) return OPAL_OK;
+    size_t new_cap[2];
+    bool any = false;
+    for (int side = 0; side < 2; side++) {
+        new_cap[side] = (new_cap_in[side] + 63) / 64 * 64;
+        if (new_cap[side] <= l->cap_side[side]) new_cap[side] = 0;
+        any = any || new_cap[side];
+    }
+    if (!any) return OPAL_OK;
     if (l->external) {
-        set_error("link: edge %d needs room for %zu particles per species, but its buffers belong to the caller "
-                  "(opal_link_set_buffers)", side, new_cap);
+        set_error("link: an edge needs room for %zu particles per species, but the link's buffers belong to the caller "
+                  "(opal_link_set_buffers)", new_cap[0] > new_cap[1] ? new_cap[0] : new_cap[1]);
         return OPAL_ERR_CAPACITY;
     }
-    OPAL_HIP(hipStreamSynchronize(l->stream));  // nothing in flight reads or writes the buffers about to go
-    const size_t nb = link_prefix_bytes(l, (unsigned)new_cap);
-    char **dev[2] = {side == 0 ? &l->d_send_left : &l->d_send_right, side == 0 ? &l->d_recv_left : &l->d_recv_right};
-    for (auto d : dev) {
-        char *fresh = nullptr;
-        OPAL_HIP(hipMalloc((void **)&fresh, nb));
-        OPAL_HIP(hipMemset(fresh, 0, nb));
-        // (the header of a send message carries the zone counts of the exchange before: kept)
-        OPAL_HIP(hipMemcpy(fresh, *d, LINK_HEAD_BYTES, hipMemcpyDeviceToDevice));
-        OPAL_HIP(hipFree(*d));
-        *d = fresh;
-    }
-    if (!l->device_buffers) {
-        char **host[2] = {side == 0 ? &l->h_send_left : &l->h_send_right, side == 0 ? &l->h_recv_left : &l->h_recv_right};
-        for (auto h : host) {
-            OPAL_HIP(hipHostFree(*h));
-            OPAL_HIP(hipHostMalloc((void **)h, nb));
-            memset(*h, 0, nb);
+    OPAL_HIP(hipDeviceSynchronize());  // nothing in flight reads or writes the buffers about to go
+    void *state[2] = {nullptr, nullptr};
+    if (l->peer)  // every record is on its way before anybody waits for one (peer.hip)
+        for (int side = 0; side < 2; side++)
+            if (new_cap[side])
+                if (int rc = link_peer_grow_begin(l, side, new_cap[side], &state[side])) return rc;
+    for (int side = 0; side < 2; side++) {
+        if (!new_cap[side]) continue;
+        const size_t nb = link_prefix_bytes(l, (unsigned)new_cap[side]);
+        char **dev[2] = {side == 0 ? &l->d_send_left : &l->d_send_right, side == 0 ? &l->d_recv_left : &l->d_recv_right};
+        for (auto d : dev) {
+            char *fresh = nullptr;
+            OPAL_HIP(hipMalloc((void **)&fresh, nb));
+            OPAL_HIP(hipMemset(fresh, 0, nb));
+            // (the header of a send message carries the zone counts of the exchange before: kept)
+            OPAL_HIP(hipMemcpy(fresh, *d, LINK_HEAD_BYTES, hipMemcpyDeviceToDevice));
+            OPAL_HIP(hipFree(*d));
+            *d = fresh;
         }
+        if (!l->device_buffers) {
+            char **host[2] = {side == 0 ? &l->h_send_left : &l->h_send_right, side == 0 ? &l->h_recv_left : &l->h_recv_right};
+            for (auto h : host) {
+                OPAL_HIP(hipHostFree(*h));
+                OPAL_HIP(hipHostMalloc((void **)h, nb));
+                memset(*h, 0, nb);
+            }
+        }
+        if (l->peer)
+            if (int rc = link_peer_grow_finish(l, side, state[side])) return rc;
+        l->cap_side[side] = new_cap[side];
+        l->nbytes_side[side] = nb;
+        l->grows++;
     }
-    if (l->peer)
-        if (int rc = link_peer_grow(l, side, new_cap)) return rc;
-    l->cap_side[side] = new_cap;
-    l->nbytes_side[side] = nb;
     l->nbytes = l->nbytes_side[0] > l->nbytes_side[1] ? l->nbytes_side[0] : l->nbytes_side[1];
-    l->grows++;
     return OPAL_OK;
 }
 

@@ -117,12 +117,13 @@ bool link_is_peer(const opal_link_t *l);
 // = where the halo is packed from, or null when the send messages already hold it
 int link_peer_next(opal_link_t *l, bool to_left, bool to_right, bool head_only, const HaloSrc *halo, PeerArgs &a);
 void link_peer_free(opal_link_t *l);
-// Makes room for `new_cap` particles per species on edge `side` (0 left, 1 right): new send / recv buffers, and on a peer
-// link new mailboxes, whose handle the two ends of the edge hand each other through a control line in the OLD mailboxes
+// Makes room for new_cap[side] particles per species on the left / right edge: new send / recv buffers, and on a peer link
+// new mailboxes, whose handle the two ends of an edge hand each other through a control line in the OLD mailboxes
 // (peer.hip).  Both ends of an edge call it for the same exchange with the same capacity (link_plan decides from numbers
-// both hold).  Drains the link's stream.
-int link_grow(opal_link_t *l, int side, size_t new_cap);
-int link_peer_grow(opal_link_t *l, int side, size_t new_cap);
+// both hold).  Drains the device.
+int link_grow(opal_link_t *l, const size_t new_cap[2]);  // (0: that edge stays as it is)
+int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state);
+int link_peer_grow_finish(opal_link_t *l, int side, void *state);
 // OPAL_ERR_LINK if a wait for a neighbour's message has ever timed out on this link (peer links; OPAL_OK for the others).
 // Synchronises with the link's stream: called where the host waits for the device anyway.
 int link_peer_check(opal_link_t *l);

@@ -195,20 +195,51 @@ namespace opal {
 // exchange (link_plan decides from numbers both hold) and have drained their streams: my tail kernel of the exchange
 // before has consumed the neighbour's last message, so the neighbour has written its last word into my old mailboxes, and
 // I mine into its.  Each end allocates, exports, writes {generation, capacity, handle} into the control line of the other's
-// OLD mailboxes (a plain copy through the mapping it already holds), waits for the other's record in its own control line,
-// maps the new mailboxes and lets the old ones go.  No host channel is needed, and nobody but the two ends takes part.
-int link_peer_grow(opal_link_t *l, int side, size_t new_cap)
+// OLD mailboxes (a plain copy through the mapping it already holds) -- link_peer_grow_begin --, then waits for the other's
+// record in its own control line, maps the new mailboxes and lets the old ones go -- link_peer_grow_finish.  Two phases
+// because a subdomain may grow both its edges for the same exchange: every record is written before anybody waits for one
+// (round a periodic ring, "left first, then right" would have every subdomain wait for its left neighbour's right edge).
+// No host channel is needed, and nobody but the two ends of an edge takes part.
+struct PeerGrowth {
+    char *fresh = nullptr;
+    size_t stride = 0, cap = 0;
+    unsigned gen = 0;
+};
+
+int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state)
 {
+    *state = nullptr;
     opal_peer *p = l->peer;
     if (!p || !p->connected) return OPAL_OK;  // (not connected yet: opal_link_peer_connect takes the capacities as they are)
     OPAL_HIP(hipDeviceSynchronize());
-    const size_t stride = peer_stride(l, new_cap), bytes = PEER_CTL_BYTES + 2 * stride;
-    char *fresh = nullptr;
-    hipError_t e = peer_alloc(p, &fresh, bytes);
-    if (e != hipSuccess) return hip_fail(e, "allocating larger peer mailboxes");
-    OPAL_HIP(hipMemset(fresh, 0, bytes));
+    PeerGrowth *gr = new PeerGrowth();
+    gr->stride = peer_stride(l, new_cap);
+    gr->cap = new_cap;
+    const size_t bytes = PEER_CTL_BYTES + 2 * gr->stride;
+    hipError_t e = peer_alloc(p, &gr->fresh, bytes);
+    if (e != hipSuccess) {
+        delete gr;
+        return hip_fail(e, "allocating larger peer mailboxes");
+    }
+    OPAL_HIP(hipMemset(gr->fresh, 0, bytes));
     OPAL_HIP(hipDeviceSynchronize());
-    const unsigned gen = ++p->gen[side];
+    gr->gen = ++p->gen[side];
+    *state = gr;
+    if (p->self[side]) return OPAL_OK;
+    PeerCtl mine;
+    memset(&mine, 0, sizeof mine);
+    mine.gen = gr->gen;
+    mine.cap = (unsigned)new_cap;
+    if (int rc = peer_export(p, &gr->fresh, bytes, mine.handle)) return rc;
+    OPAL_HIP(hipMemcpy(p->peer_base[side], &mine, sizeof mine, hipMemcpyHostToDevice));
+    return OPAL_OK;
+}
+
+int link_peer_grow_finish(opal_link_t *l, int side, void *state)
+{
+    opal_peer *p = l->peer;
+    PeerGrowth *gr = static_cast<PeerGrowth *>(state);
+    if (!p || !gr) return OPAL_OK;
     auto retire = [&](int s) {  // my old mailboxes of side s
         if (p->own[s]) hipFree(p->box_mem[s]);
         p->own[s] = true;
@@ -221,31 +252,26 @@ int link_peer_grow(opal_link_t *l, int side, size_t new_cap)
         // a lone periodic subdomain is its own neighbour: what it sends through this side lands in the mailboxes of its
         // OTHER side, which link_plan grows in the same call (the two edges read the same numbers)
         retire(side);
-        p->box_mem[side] = fresh;
-        p->stride[side] = stride;
-        p->peer_base[1 - side] = fresh;
+        p->box_mem[side] = gr->fresh;
+        p->stride[side] = gr->stride;
+        p->peer_base[1 - side] = gr->fresh;
+        delete gr;
         return OPAL_OK;
     }
-    PeerCtl mine;
-    memset(&mine, 0, sizeof mine);
-    mine.gen = gen;
-    mine.cap = (unsigned)new_cap;
-    if (int rc = peer_export(p, &fresh, bytes, mine.handle)) return rc;
-    OPAL_HIP(hipMemcpy(p->peer_base[side], &mine, sizeof mine, hipMemcpyHostToDevice));
     PeerCtl theirs;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         OPAL_HIP(hipMemcpy(&theirs, p->box_mem[side], sizeof theirs, hipMemcpyDeviceToHost));
-        if (theirs.gen == gen) break;
+        if (theirs.gen == gr->gen) break;
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
             set_error("peer link: the neighbour on side %d never sent the handle of its larger mailboxes (growth %u to %zu "
-                      "particles per species)", side, gen, new_cap);
+                      "particles per species)", side, gr->gen, gr->cap);
             return OPAL_ERR_LINK;
         }
         usleep(200);
     }
-    if (theirs.cap != mine.cap) {
-        set_error("peer link: the two ends of edge %d disagree on its new capacity (%u here, %u there)", side, mine.cap, theirs.cap);
+    if (theirs.cap != (unsigned)gr->cap) {
+        set_error("peer link: the two ends of edge %d disagree on its new capacity (%zu here, %u there)", side, gr->cap, theirs.cap);
         return OPAL_ERR_LINK;
     }
     hipIpcMemHandle_t h;
@@ -258,8 +284,9 @@ int link_peer_grow(opal_link_t *l, int side, size_t new_cap)
     if (old && old != p->mapped[1 - side]) hipIpcCloseMemHandle(old);
     p->peer_base[side] = static_cast<char *>(map);
     retire(side);
-    p->box_mem[side] = fresh;
-    p->stride[side] = stride;
+    p->box_mem[side] = gr->fresh;
+    p->stride[side] = gr->stride;
+    delete gr;
     return OPAL_OK;
 }
 
