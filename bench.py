@@ -226,13 +226,13 @@ LONG_STEPS = 200   # a second timed region of this length follows a shorter --st
 
 
 def lp_link_capacity(npc):
-    """Room in a laser-plasma link for the leavers of one step through one cut, per species: at most the occupants of
-    the cell next to the cut (nobody moves a whole cell per step).  The hole-boring front piles the particles up:
-    scripts/archive/lp_pileup_probe.py finds up to 47 (electrons) / 93 (ions, which cross at a fraction of a cell per step) times the
-    initial particles per cell in one cell during the interaction, so 2 npc (a front at the initial density) and then 32 npc overflowed -- reported as the
-    error it is -- at 4, 5 and 6 subdomains with 1e8 particles.  128 npc; what travels is still only the actual
-    leavers: capacity costs mailbox memory (0.5 GB per subdomain at npc = 10 000)."""
-    return int(os.environ.get("OPAL_BENCH_LP_CAPACITY") or max(4096, 128 * npc))
+    """Room a laser-plasma link is CREATED with for the leavers of one step through one cut, per species: what stands within
+    8 cells of a cut on both sides at the initial density (16 cells' worth; 20 are reserved).  The hole-boring front piles the particles up
+    (scripts/archive/lp_pileup_probe.py: up to 47 x the initial electrons and 93 x the ions in one cell); rounds 2-3 created
+    every link for that (128 npc: 0.5 GB per subdomain at npc = 10 000) and still called an overflow an error.  Round 4:
+    the edge a pile-up approaches GROWS -- from the zone counts both of its ends hold, before the push that could overflow
+    it (link.cpp: link_grow) -- and the others stay small."""
+    return int(os.environ.get("OPAL_BENCH_LP_CAPACITY") or max(4096, 20 * npc))
 
 
 def src_sha():
@@ -540,9 +540,10 @@ def main():
         else:
             nx = args.cells or C3_CELLS
             npc = args.npc if args.npc is not None else C3_NPC
-        # two-stream flux through a cut: npc <|v_x|> dt / dx ~ 0.009 npc per step; 1024 is > 40x headroom
-        # up to npc = 2441 (an overflow is reported as an error, never silent)
-        link_capacity = max(1024, npc // 2)
+        # two-stream flux through a cut: npc <|v_x|> dt / dx ~ 0.009 npc per step.  The room is what stands within 8 cells
+        # of a cut on both sides (16 npc: the bound an edge is held to, link.cpp) and a margin, so that no edge ever has
+        # to grow in this uniform plasma; what travels is the leavers only
+        link_capacity = max(4096, 20 * npc)
 
     dist = None
     link = None
@@ -733,9 +734,13 @@ def main():
             # what each subdomain did: its own clock between the same two barriers (the slowest one IS the step), its
             # particles and its kernel -- imbalance (configs[3]) is otherwise invisible in the whole-job number
             per_rank = [None] * world
-            dist.all_gather_object(per_rank, {"rank": rank, "ms_per_step_own_clock": 1e3 * elapsed_local / steps,
-                                              "particles": n_local, "push_avg_ms": avg_ms,
-                                              "cells": int(sim.grid.size), "rebins": oa.prof_seen("sort")})
+            mine = {"rank": rank, "ms_per_step_own_clock": 1e3 * elapsed_local / steps, "particles": n_local,
+                    "push_avg_ms": avg_ms, "cells": int(sim.grid.size), "rebins": oa.prof_seen("sort")}
+            lk = getattr(sim, "_bench_link", None)
+            if lk is not None and hasattr(lk, "growth"):
+                cl, cr, ng = lk.growth()
+                mine["link_room_left_right"], mine["link_edges_grown"] = [cl, cr], ng
+            dist.all_gather_object(per_rank, mine)
         return {"value": value, "elapsed": elapsed, "n_total": n_total, "preheat": done, "roofline": roof, "per_rank": per_rank,
                 "ms_per_step": 1e3 * elapsed / steps,
                 "frac_of_hbm_roofline_whole_step": value * bpu / (world * HBM_PEAK_GBS * 1e9)}
@@ -863,6 +868,7 @@ def main():
     else:
         wkey = f"two_stream:{nx}x{npc}"
         sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
+    sim._bench_link = link
     sim.set_fused(not args.unfused)
     if args.self_exchange and world == 1:
         sim.grid.set_self_exchange(True)
@@ -1044,6 +1050,7 @@ def main():
                 raise RuntimeError("failure requested through OPAL_BENCH_LP_FAIL_RANK")
             oa.set_elision(False)
             sim3 = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=lp_npc), rank=rank, numtasks=world, link=link3, stream=stream)
+            sim3._bench_link = link3
             sizes = [None] * world
             dist.all_gather_object(sizes, int(sim3.grid.size))
             m3 = measure(sim3, lp_steps, lp_warm, preheat=False, workload_key=f"laser_plasma:{lp_npc}")

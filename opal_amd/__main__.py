@@ -33,17 +33,18 @@ def main(argv):
                                 **({"device_id": device} if backend == "nccl" else {}))
         cfg = oa.Config(path=argv[1])
         emission, absorption = cfg.read_bool("qed", "photon_emission"), cfg.read_bool("qed", "photon_absorption")
-        # room in the buffers for the leavers of one step through one cut, per species (an overflow is reported as an
-        # error); what travels each step is sized to the particles within 3 cells of each cut, not to this
-        # (a hole-boring front piles the particles up to 47 (electrons) / 93 (ions) times the initial density before it meets a cut --
-        # scripts/archive/lp_pileup_probe.py --: room for 128 cells' worth of the densest species, at least 65536)
+        # Room in the buffers for the leavers of one step through one cut, per species.  A peer link's edges GROW when more
+        # particles stand within 8 cells of a cut than they have room for (link.cpp: link_plan / link_grow), from the zone
+        # counts of earlier exchanges -- so a link only has to be created with room for what can cross before that history
+        # exists: the particles within 8 cells on both sides of a cut at the initial density, 16 cells' worth of the densest
+        # species (it used to be created for the worst pile-up ever measured, 128 cells' worth: 0.5 GB at npc = 10 000).
         npc = 0
         for sec in ("electrons", "ions"):
             try:
                 npc = max(npc, cfg.read_usize(sec, "npc")) if cfg.contains(sec) else npc
             except oa.OpalError:
                 pass  # (the run itself will report a malformed section)
-        cap = int(os.environ.get("OPAL_LINK_CAPACITY", str(max(65536, 128 * npc))))
+        cap = int(os.environ.get("OPAL_LINK_CAPACITY", str(max(4096, 20 * npc))))
         stream = torch.cuda.current_stream().cuda_stream
         open_ends = cfg.contains("laser")  # laser + absorbing boundaries: the first and last subdomain have one neighbour
         want = os.environ.get("OPAL_LINK")

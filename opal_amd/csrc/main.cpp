@@ -259,11 +259,12 @@ int run_rank(Comm &c, const char *path)
         int emission = 0, absorption = 0;
         opal_config_read_bool(cfg, "qed", "photon_emission", &emission);
         opal_config_read_bool(cfg, "qed", "photon_absorption", &absorption);
-        // room for the leavers of one step through one cut, per species; what travels is only the leavers themselves
+        // room for the leavers of one step through one cut, per species, at creation: what stands within 8 cells of a cut on
+        // both sides at the initial density (an edge grows from there when the particles near it require it: link_grow)
         size_t npc = 0, v = 0;
         for (const char *sec : {"electrons", "ions"})
             if (opal_config_contains(cfg, sec) == 1 && opal_config_read_usize(cfg, sec, "npc", &v) == OPAL_OK) npc = std::max(npc, v);
-        size_t cap = std::max<size_t>(65536, 128 * npc);
+        size_t cap = std::max<size_t>(4096, 20 * npc);
         if (const char *e = getenv("OPAL_LINK_CAPACITY")) cap = (size_t)strtoull(e, nullptr, 10);
         const bool open_ends = opal_config_contains(cfg, "laser") == 1;  // laser + absorbing ends: one neighbour at each end
         opal_config_free(cfg);

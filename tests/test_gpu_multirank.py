@@ -218,11 +218,16 @@ def test_a_link_grows_instead_of_overflowing(oracle, tmp_path, monkeypatch):
     dt = 0.95 * dx / C
     monkeypatch.setenv("OPAL_TEST_LINK", "peer")
     monkeypatch.setenv("OPAL_TEST_LINK_CAP", "64")
+    # the bunch starts 10 cells short of the cut: growth is planned from the zone counts of earlier exchanges (a link must
+    # be created with room for what can cross in its first LINK_ZONE exchanges: the launchers size it by the initial
+    # density near the cuts)
+    gap = 10
+    monkeypatch.setenv("OPAL_TEST_GROW_GAP", str(gap))
     _launch("_gloo_hip_worker.py", world, ["grow", tmp_path, nx, npc, steps, 1])
     nxs, offs = o.design_unbalanced(world, nx, dx)
     rng = np.random.default_rng(9)
     n = nx * npc
-    cell = rng.integers(0, nx // 2, n)
+    cell = rng.integers(0, nx // 2 - gap, n)
     st = (cell, rng.random(n), 0.5 + 0.05 * rng.standard_normal(n), np.zeros(n), np.zeros(n),
           1.0e3 * (1.0 + 1e-9 * np.arange(n)))
     grids = [o.Grid(r, world, o.BDY_LASER, o.BDY_ABSORBING, 0.0, dx, nxs, offs) for r in range(world)]
