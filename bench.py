@@ -784,18 +784,25 @@ def main():
         oa.set_elision(True)
         simc = oa.Simulation(yaml_text=COLLIDING_BEAMS_YAML.format(npc=CB_NPC), rank=rank, numtasks=world, link=link_cb, stream=stream)
         barrier()
+        tw = time.perf_counter()
         simc.step(CB_WARM)
         simc.sync()
+        if os.environ.get("OPAL_BENCH_CB_VERBOSE"):
+            print(f"[bench] rank {rank} colliding beams: {CB_WARM} warm-up steps in {time.perf_counter() - tw:.2f} s, "
+                  f"{len(simc.electrons)} electrons here", file=sys.stderr, flush=True)
         oa.prof_reset()
         barrier()
         oa.prof_enable(5)
         upd_e = upd_p = 0.0
         t0 = time.perf_counter()
         n_p0 = simc.photons.counters()["slots"]
-        for _ in range(CB_STEPS // CB_SEG):
+        for seg in range(CB_STEPS // CB_SEG):
             simc.step(CB_SEG)
             simc.sync()
             n_e, n_p1 = len(simc.electrons), simc.photons.counters()["slots"]
+            if os.environ.get("OPAL_BENCH_CB_VERBOSE"):
+                print(f"[bench] rank {rank} colliding beams segment {seg}: {n_e} electrons, {n_p1} photons, "
+                      f"{time.perf_counter() - t0:.2f} s", file=sys.stderr, flush=True)
             upd_e += float(n_e) * CB_SEG
             upd_p += 0.5 * (n_p0 + n_p1) * CB_SEG
             n_p0 = n_p1

@@ -1753,12 +1753,19 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     // step or two later pull its bound on the slots in use back down to the true count
     if (int rc = opal::pop_tighten_upper(p)) return rc;
     if (p->n_upper + incoming > p->cap) {
-        // compact first (synchronises); the true slot count replaces the running upper bound
-        if (p->n_upper)
-            if (int rc = do_sort(p, g)) return rc;
+        // The host's bound has run into the capacity.  It is a bound: `incoming` is what CAN cross (at a pile-up hundreds
+        // of times what does), added every step and taken back by snapshots that land steps later.  The true slot count
+        // first -- one small synchronous copy; round 3 re-binned the whole population here, 523 times in 2000 steps of the
+        // 4-subdomain laser-plasma rehearsal once the links' bound followed the pile-up -- and, if that is not enough,
+        // room for several steps' worth of the bound (HBM is plentiful; vacated slots are the re-binning policy's business).
+        unsigned n_true = 0;
+        OPAL_HIP(hipMemcpyAsync(&n_true, &p->d_ctr->n_slots, sizeof n_true, hipMemcpyDeviceToHost, p->stream));
+        OPAL_HIP(hipStreamSynchronize(p->stream));
+        if (int rc = opal::pop_tighten_upper(p)) return rc;  // (a snapshot in flight has landed: the stream is drained)
+        p->n_upper = n_true;
+        p->added_since_snapshot = 0;
         if (p->n_upper + incoming > p->cap) {
-            // a subdomain that plasma is moving into: make room (1.5x what is needed now)
-            size_t want = (p->n_upper + incoming) + (p->n_upper + incoming) / 2;
+            size_t want = p->n_upper + 6 * incoming + p->n_upper / 4;
             if (int rc = grow(p, want)) return rc;
         }
     }
