@@ -785,11 +785,16 @@ def main():
         simc = oa.Simulation(yaml_text=COLLIDING_BEAMS_YAML.format(npc=CB_NPC), rank=rank, numtasks=world, link=link_cb, stream=stream)
         barrier()
         tw = time.perf_counter()
-        simc.step(CB_WARM)
-        simc.sync()
         if os.environ.get("OPAL_BENCH_CB_VERBOSE"):
-            print(f"[bench] rank {rank} colliding beams: {CB_WARM} warm-up steps in {time.perf_counter() - tw:.2f} s, "
-                  f"{len(simc.electrons)} electrons here", file=sys.stderr, flush=True)
+            for k in range(CB_WARM // 250):
+                simc.step(250)
+                simc.sync()
+                print(f"[bench] rank {rank} colliding beams warm-up: {250 * (k + 1)} steps, {time.perf_counter() - tw:.2f} s, "
+                      f"{len(simc.electrons)} electrons here, link room {link_cb.growth() if link_cb is not None and hasattr(link_cb, 'growth') else None}",
+                      file=sys.stderr, flush=True)
+        else:
+            simc.step(CB_WARM)
+            simc.sync()
         oa.prof_reset()
         barrier()
         oa.prof_enable(5)
