@@ -33,6 +33,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "link.hpp"
@@ -160,7 +162,11 @@ int link_plan(opal_link_t *l, unsigned species_mask)
         }
     }
     if (grow_to[0] || grow_to[1]) {
+        if (getenv("OPAL_LINK_DEBUG"))
+            fprintf(stderr, "[link] rank %d exchange %u: need %u / %u, room %u / %u -> grow to %zu / %zu\n", l->rank, X, need[0],
+                    need[1], full[0], full[1], grow_to[0], grow_to[1]);
         if (int rc = link_grow(l, grow_to)) return rc;
+        if (getenv("OPAL_LINK_DEBUG")) fprintf(stderr, "[link] rank %d exchange %u: grown\n", l->rank, X);
         full[0] = (unsigned)l->cap_side[0];
         full[1] = (unsigned)l->cap_side[1];
     }

@@ -232,6 +232,8 @@ int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state)
     mine.cap = (unsigned)new_cap;
     if (int rc = peer_export(p, &gr->fresh, bytes, mine.handle)) return rc;
     OPAL_HIP(hipMemcpy(p->peer_base[side], &mine, sizeof mine, hipMemcpyHostToDevice));
+    if (getenv("OPAL_LINK_DEBUG"))
+        fprintf(stderr, "[link] rank %d side %d: record of growth %u (%zu slots, %zu bytes) written\n", l->rank, side, gr->gen, new_cap, bytes);
     return OPAL_OK;
 }
 
