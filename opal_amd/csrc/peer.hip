@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <vector>
 
 using namespace opal;
 
@@ -25,6 +26,10 @@ struct opal_peer {
     unsigned *d_err = nullptr;
     unsigned seq = 0;          // exchanges made so far
     unsigned gen[2] = {0, 0};  // growths of each edge so far
+    // mailboxes and mappings an edge has outgrown: let go with the link, not during the run (the neighbour may still hold
+    // a mapping of mine, and I one of its: nothing is unmapped or freed while the other end could be looking)
+    std::vector<char *> old_boxes;
+    std::vector<void *> old_maps;
     bool connected = false;
     int alloc_kind = 0;        // 0 uncached, 1 fine-grained, 2 plain device memory
 };
@@ -125,8 +130,10 @@ void link_peer_free(opal_link_t *l)
     if (!p) return;
     for (int s = 0; s < 2; s++)
         if (p->mapped[s] && (s == 0 || p->mapped[1] != p->mapped[0])) hipIpcCloseMemHandle(p->mapped[s]);
+    for (void *m : p->old_maps) hipIpcCloseMemHandle(m);
     for (int s = 0; s < 2; s++)
         if (p->own[s] && p->box_mem[s]) hipFree(p->box_mem[s]);
+    for (char *b : p->old_boxes) hipFree(b);
     if (p->base0) hipFree(p->base0);
     if (p->d_err) hipFree(p->d_err);
     delete p;
@@ -242,13 +249,9 @@ int link_peer_grow_finish(opal_link_t *l, int side, void *state)
     opal_peer *p = l->peer;
     PeerGrowth *gr = static_cast<PeerGrowth *>(state);
     if (!p || !gr) return OPAL_OK;
-    auto retire = [&](int s) {  // my old mailboxes of side s
-        if (p->own[s]) hipFree(p->box_mem[s]);
+    auto retire = [&](int s) {  // my old mailboxes of side s (the allocation of creation goes with the link)
+        if (p->own[s]) p->old_boxes.push_back(p->box_mem[s]);
         p->own[s] = true;
-        if (p->base0 && p->own[0] && p->own[1]) {
-            hipFree(p->base0);
-            p->base0 = nullptr;
-        }
     };
     if (p->self[side]) {
         // a lone periodic subdomain is its own neighbour: what it sends through this side lands in the mailboxes of its
@@ -262,6 +265,7 @@ int link_peer_grow_finish(opal_link_t *l, int side, void *state)
     }
     PeerCtl theirs;
     const auto t0 = std::chrono::steady_clock::now();
+    if (getenv("OPAL_LINK_DEBUG")) fprintf(stderr, "[link] rank %d side %d: waiting for the neighbour's record %u\n", l->rank, side, gr->gen);
     for (;;) {
         OPAL_HIP(hipMemcpy(&theirs, p->box_mem[side], sizeof theirs, hipMemcpyDeviceToHost));
         if (theirs.gen == gr->gen) break;
@@ -279,11 +283,12 @@ int link_peer_grow_finish(opal_link_t *l, int side, void *state)
     hipIpcMemHandle_t h;
     memcpy(&h, theirs.handle, sizeof h);
     void *map = nullptr;
+    if (getenv("OPAL_LINK_DEBUG")) fprintf(stderr, "[link] rank %d side %d: record %u here, mapping\n", l->rank, side, gr->gen);
     OPAL_HIP(hipIpcOpenMemHandle(&map, h, hipIpcMemLazyEnablePeerAccess));
     // the mapping of the neighbour's old mailboxes is shared by both sides when both neighbours are one subdomain
     void *old = p->mapped[side];
     p->mapped[side] = map;
-    if (old && old != p->mapped[1 - side]) hipIpcCloseMemHandle(old);
+    if (old && old != p->mapped[1 - side]) p->old_maps.push_back(old);
     p->peer_base[side] = static_cast<char *>(map);
     retire(side);
     p->box_mem[side] = gr->fresh;
