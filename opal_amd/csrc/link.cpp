@@ -158,7 +158,17 @@ int link_plan(opal_link_t *l, unsigned species_mask)
             // what the densest moment of the run needed at this cut).
             size_t want = (size_t)slots[side] + slots[side] / 4, cap2 = 1024;
             while (cap2 < want) cap2 *= 2;
-            grow_to[side] = cap2;
+            if (l->peer) {
+                // An edge's two mailboxes are one IPC-shared allocation, and one of 2 GiB or more could not be mapped by
+                // the neighbour (hipIpcOpenMemHandle never returned for 2.5 GB where 1.26 GB had taken milliseconds:
+                // round 4, two processes on one MI355X).  An edge stops growing below that; a bound beyond it -- the bound
+                // counts what COULD cross, newborn photons of every electron near the cut included -- is then not
+                // covered by room, and a real overflow would be the error it always was.
+                const size_t per_slot = (size_t)l->layout.nslots * l->layout.blk / LINK_ROWS;
+                const size_t most = ((((size_t)1 << 31) - 65536) / 2 - LINK_HEAD_BYTES) / per_slot;
+                while (cap2 > most) cap2 /= 2;
+            }
+            if (cap2 > full[side]) grow_to[side] = cap2;
         }
     }
     if (grow_to[0] || grow_to[1]) {
