@@ -322,6 +322,15 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
     p->stride[0] = p->stride[1] = peer_stride(l, l->cap);
     const size_t region = PEER_CTL_BYTES + 2 * p->stride[0];
     p->total0 = 2 * region;
+    if (p->total0 >= ((size_t)1 << 31)) {
+        // (an IPC-shared allocation of 2 GiB or more could not be mapped by the neighbour: link.cpp, link_plan)
+        opal_link_free(l);
+        *out = nullptr;
+        set_error("opal_link_create_peer: room for %zu particles per species makes mailboxes of %zu bytes; IPC-shared allocations "
+                  "must stay below 2 GiB (create the link smaller: its edges grow where the particles require it)",
+                  particle_capacity, p->total0);
+        return OPAL_ERR_ARG;
+    }
     hipError_t e = peer_alloc(p, &p->base0, p->total0);
     if (e != hipSuccess) {
         p->base0 = nullptr;
