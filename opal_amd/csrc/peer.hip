@@ -42,11 +42,47 @@ struct PeerCtl {
 
 namespace {
 
-// One workgroup: send both messages, wait for the neighbours', copy what arrived into the link's recv buffers (the
-// unpack and synchronize kernels of the unfused paths read them there).
-__global__ __launch_bounds__(1024) void k_peer_move(PeerArgs a, char *recv_left, char *recv_right)
+// The exchange as a launch of its own (the unfused paths: opal_grid_synchronize's halo-only exchange, the separate-operator
+// and emission steps' whole messages): send both messages, wait for the neighbours', copy what arrived into the link's recv
+// buffers, where the unpack and synchronize kernels read them.
+// Round 4: PEER_MOVE_BLOCKS workgroups share the payload (a single one moved a colliding-beams step's 9 MB of photons at
+// ~10 GB/s: 2 ms per step at four subdomains).  Header and halo go out from workgroup 0; every workgroup stores its share of
+// the row blocks (system-scope write-through stores), fences, and takes a ticket; whoever draws the last ticket knows that
+// every share is out and publishes the sequence numbers.  No workgroup waits for another one of its own launch, so the
+// launch needs no co-residency; all of them then poll their own mailboxes for the neighbours' numbers (bounded).
+constexpr unsigned PEER_MOVE_BLOCKS = 64;
+__global__ __launch_bounds__(1024) void k_peer_move(PeerArgs a, char *recv_left, char *recv_right, unsigned *ticket)
 {
-    peer_send(a);
+    constexpr unsigned HEAD_WORDS = (unsigned)(LINK_HEAD_BYTES / 8);
+    const unsigned nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        for (int side = 0; side < 2; side++) {
+            const char *msg = a.send[side];
+            if (!msg || threadIdx.x >= HEAD_WORDS) continue;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES) + threadIdx.x,
+                               reinterpret_cast<const unsigned long long *>(msg)[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    for (int side = 0; side < 2; side++) {
+        const char *msg = a.send[side];
+        if (!msg) continue;
+        const unsigned words = peer_prefix_words(msg, a, side);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES);
+        for (unsigned i = HEAD_WORDS + gtid; i < words; i += nthreads)
+            __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();  // (every wave waits for its stores before it arrives)
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {  // every workgroup's share is out
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch: stream order)
+            for (int side = 0; side < 2; side++)
+                if (a.send[side])
+                    __hip_atomic_store(reinterpret_cast<unsigned *>(a.dst[side]), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     peer_wait(a);
     for (int side = 0; side < 2; side++) {
         if (!a.box[side]) continue;
@@ -54,7 +90,7 @@ __global__ __launch_bounds__(1024) void k_peer_move(PeerArgs a, char *recv_left,
         const unsigned words = peer_prefix_words(msg, a, side);
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(side == 0 ? recv_left : recv_right);
-        for (unsigned i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        for (unsigned i = gtid; i < words; i += nthreads) dst[i] = src[i];
     }
 }
 
@@ -67,7 +103,9 @@ int peer_exchange2(void *user, const void *send_left, const void *send_right, vo
     if (link_peer_next(l, send_left != nullptr, send_right != nullptr, head_only, nullptr, a)) return 1;
     a.send[0] = static_cast<const char *>(send_left);
     a.send[1] = static_cast<const char *>(send_right);
-    k_peer_move<<<1, 1024, 0, l->stream>>>(a, static_cast<char *>(recv_left), static_cast<char *>(recv_right));
+    // (a halo-only exchange is 88 words: one workgroup)
+    k_peer_move<<<head_only ? 1 : PEER_MOVE_BLOCKS, 1024, 0, l->stream>>>(a, static_cast<char *>(recv_left), static_cast<char *>(recv_right),
+                                                                           l->peer->d_err + 1);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 int peer_exchange(void *user, const void *send_left, const void *send_right, void *recv_left, void *recv_right, size_t nbytes)
@@ -341,8 +379,8 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
     p->box_mem[0] = p->base0;
     p->box_mem[1] = p->base0 + region;
     e = hipMemset(p->base0, 0, p->total0);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(p->d_err, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, 2 * sizeof(unsigned));  // [0] error word, [1] k_peer_move's ticket
+    if (e == hipSuccess) e = hipMemset(p->d_err, 0, 2 * sizeof(unsigned));
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {  // nothing of a half-built link survives a failure: the caller falls back to another transport
         opal_link_free(l);
