@@ -246,6 +246,10 @@ int opal_qed_cross_sections_batch(size_t n, const double *k, const double *p, co
  * evaluated on the device for n inputs in host memory (out: 3n / 4n / n doubles). */
 int opal_qed_sample_batch(size_t n, const double *chi, const double *gamma, const double *r1, const double *r2,
                           const double *r3, int classical, double *out);
+/* Electron::radiate's event (electron.rs:213-240) for n electrons with the three uniforms given: out[9 i ..] = the
+ * photon's k[3], the electron's u[3] after the recoil, its gamma and chi, the formation length. */
+int opal_qed_radiate_batch(size_t n, const double *chi, const double *ux, const double *uy, const double *uz, const double *r1,
+                           const double *r2, const double *r3, double *out);
 int opal_qed_randoms_batch(size_t n, uint64_t seed, const uint64_t *id, uint32_t step, double *out);
 int opal_qed_rate_batch(size_t n, const double *chi, const double *gamma, double *out);
 

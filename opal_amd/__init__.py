@@ -419,6 +419,17 @@ def qed_sample(chi, gamma, r1, r2, r3, classical=False):
     return out
 
 
+def qed_radiate(chi, u, r1, r2, r3):
+    """Electron::radiate's event on the device with the three uniforms given: (n, 9) array of the photon's k[3], the
+    electron's u[3] after the recoil, its gamma and chi, the formation length (electron.rs:213-240)."""
+    chi = np.ascontiguousarray(chi, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    a = [chi] + [np.ascontiguousarray(u[:, k]) for k in range(3)] + [np.ascontiguousarray(r, dtype=np.float64) for r in (r1, r2, r3)]
+    out = np.empty((len(chi), 9))
+    _check(_lib.load().opal_qed_radiate_batch(len(chi), *[_ptr(v) for v in a], _ptr(out)))
+    return out
+
+
 def qed_randoms(seed, ids, step):
     ids = np.ascontiguousarray(ids, dtype=np.uint64)
     out = np.empty((len(ids), 4))

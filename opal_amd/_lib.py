@@ -89,6 +89,7 @@ SIGNATURES = {
     "opal_qed_cross_sections_batch": (C.c_int, [sz, vp, vp, vp, vp, vp, vp]),
     "opal_qed_sample_batch": (C.c_int, [sz, vp, vp, vp, vp, vp, C.c_int, vp]),
     "opal_qed_randoms_batch": (C.c_int, [sz, C.c_uint64, vp, C.c_uint32, vp]),
+    "opal_qed_radiate_batch": (C.c_int, [sz, vp, vp, vp, vp, vp, vp, vp, vp]),
     "opal_qed_rate_batch": (C.c_int, [sz, vp, vp, vp]),
     "opal_pop_hist_range": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(C.c_int), vp, vp, C.POINTER(sz)]),
     "opal_pop_hist_fill": (C.c_int, [vp, vp, C.c_char_p, vp, vp, sz, pp]),

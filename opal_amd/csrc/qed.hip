@@ -335,6 +335,21 @@ __global__ __launch_bounds__(256) void k_radiate(RadiateArgs a)
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n_list; e += gridDim.x * blockDim.x) radiate_one(a, a.list[e]);
 }
 
+// electron.rs:219-240: the photon's momentum at polar angle theta around the electron's direction from the sampled
+// (omega / mc^2, theta, phi), the formation length (:231), the recoil (:234-239: u, chi)
+__device__ inline V3 radiate_core(V3 &u, double chi, double gamma, const Sample &smp, double &formation_length, double &chi_new)
+{
+    V3 parallel = normalize(u);
+    V3 perp = rotate_around(orthogonal(parallel), parallel, smp.phi);
+    double st, ct;
+    sincos(smp.theta, &st, &ct);
+    V3 k = smp.omega_mc2 * (ct * parallel + st * perp);
+    formation_length = 2.0 * (gamma * gamma) * smp.theta * SPEED_OF_LIGHT * COMPTON_TIME / chi;
+    u = u - k;
+    chi_new = chi * sqrt(1.0 + dot(u, u)) / gamma;
+    return k;
+}
+
 __device__ void radiate_one(const RadiateArgs &a, size_t i)
 {
 
@@ -352,17 +367,10 @@ __device__ void radiate_one(const RadiateArgs &a, size_t i)
         atomicOr(&a.ectr->err, 32);  // photon_emission.rs:143-144: chi >= 100 is unimplemented!() there
         return;
     }
-    // electron.rs:220-229: photon momentum at polar angle theta around the electron's direction
-    V3 parallel = normalize(u);
-    V3 perp = rotate_around(orthogonal(parallel), parallel, smp.phi);
-    double st, ct;
-    sincos(smp.theta, &st, &ct);
-    V3 k = smp.omega_mc2 * (ct * parallel + st * perp);
-    double formation_length = 2.0 * (gamma * gamma) * smp.theta * SPEED_OF_LIGHT * COMPTON_TIME / chi;  // :231
-    // recoil, electron.rs:234-239
-    u = u - k;
+    double formation_length, chi_new;
+    V3 k = radiate_core(u, chi, gamma, smp, formation_length, chi_new);
     a.ux[i] = u.x; a.uy[i] = u.y; a.uz[i] = u.z;
-    a.chi[i] = chi * sqrt(1.0 + dot(u, u)) / gamma;
+    a.chi[i] = chi_new;
 
     // interactions.rs:73-98
     double k0 = sqrt(dot(k, k));
@@ -407,6 +415,25 @@ __global__ void k_sample_batch(int n, const double *chi, const double *gamma, co
     if (classical) s = classical_sample(chi[i], gamma[i], r1[i], r2[i], r3[i]);
     else if (!quantum_sample(chi[i], gamma[i], r1[i], r2[i], r3[i], s)) atomicAdd(bad, 1);
     out[3 * i] = s.omega_mc2; out[3 * i + 1] = s.theta; out[3 * i + 2] = s.phi;
+}
+
+// the emission event with the three uniforms given (tests/test_gpu_qed.py against tests/golden/qed_radiate_independent.json)
+__global__ void k_radiate_batch(int n, const double *chi, const double *ux, const double *uy, const double *uz, const double *r1,
+                                const double *r2, const double *r3, double *out, int *bad)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 u = {ux[i], uy[i], uz[i]};
+    const double gamma = sqrt(1.0 + dot(u, u));
+    Sample smp = {0.0, 0.0, 0.0};
+    if (!quantum_sample(chi[i], gamma, r1[i], r2[i], r3[i], smp)) {
+        atomicAdd(bad, 1);
+        return;
+    }
+    double fl, chi_new;
+    V3 k = radiate_core(u, chi[i], gamma, smp, fl, chi_new);
+    double *o = out + 9 * (size_t)i;
+    o[0] = k.x; o[1] = k.y; o[2] = k.z; o[3] = u.x; o[4] = u.y; o[5] = u.z; o[6] = sqrt(1.0 + dot(u, u)); o[7] = chi_new; o[8] = fl;
 }
 
 __global__ void k_randoms_batch(int n, unsigned long long seed, const unsigned long long *id, unsigned step, double *out)
@@ -535,6 +562,32 @@ int opal_qed_sample_batch(size_t n, const double *chi, const double *gamma, cons
     hipFree(d_bad);
     if (bad) {
         set_error("opal_qed_sample_batch: %d inputs have chi >= 100, which the reference's sampler does not implement (photon_emission.rs:143-144)", bad);
+        return OPAL_ERR_ASSERT;
+    }
+    return OPAL_OK;
+}
+
+int opal_qed_radiate_batch(size_t n, const double *chi, const double *ux, const double *uy, const double *uz, const double *r1,
+                           const double *r2, const double *r3, double *out)
+{
+    if (!n) return OPAL_OK;
+    double *d = nullptr;
+    int *d_bad = nullptr;
+    OPAL_HIP(hipMalloc(&d, sizeof(double) * n * 16));
+    OPAL_HIP(hipMalloc(&d_bad, sizeof(int)));
+    OPAL_HIP(hipMemset(d_bad, 0, sizeof(int)));
+    const double *src[7] = {chi, ux, uy, uz, r1, r2, r3};
+    for (int k = 0; k < 7; k++) OPAL_HIP(hipMemcpy(d + k * n, src[k], sizeof(double) * n, hipMemcpyHostToDevice));
+    k_radiate_batch<<<(unsigned)((n + 127) / 128), 128>>>((int)n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n, d + 6 * n,
+                                                           d + 7 * n, d_bad);
+    OPAL_HIP(hipGetLastError());
+    OPAL_HIP(hipMemcpy(out, d + 7 * n, sizeof(double) * 9 * n, hipMemcpyDeviceToHost));
+    int bad = 0;
+    OPAL_HIP(hipMemcpy(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+    hipFree(d);
+    hipFree(d_bad);
+    if (bad) {
+        set_error("opal_qed_radiate_batch: %d inputs have chi >= 100, which the reference's sampler does not implement (photon_emission.rs:143-144)", bad);
         return OPAL_ERR_ASSERT;
     }
     return OPAL_OK;

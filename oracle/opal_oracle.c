@@ -1929,13 +1929,9 @@ size_t oracle_histogram(const Population *p, const YeeGrid *g, int dim, const in
 /* ------------------------------------------------- emit_radiation */
 /* electron.rs:208-251 (default features).  Returns 1 and fills photon / formation_length on emission,
  * -1 where the reference panics (chi >= 100). */
-static int electron_radiate(Electron *e, uint64_t seed, uint32_t step, double t, Photon *photon, double *formation_length)
+/* electron.rs:219-240: the photon's momentum from the sampled (omega / mc^2, theta, phi), the formation length, the recoil */
+static Vec3 radiate_core(Electron *e, const double smp[3], double *formation_length)
 {
-    if (!(e->tau < 0.0)) return 0;
-    double rnd[4], smp[3];
-    oracle_emission_randoms(seed, e->id, step, rnd);
-    e->tau = -log(1.0 - rnd[0]);
-    if (oracle_qed_sample(e->chi, e->gamma, rnd[1], rnd[2], rnd[3], smp)) return -1;
     double omega_mc2 = smp[0], theta = smp[1], cphi = smp[2];
     Vec3 eu = v3(e->u[0], e->u[1], e->u[2]);
     Vec3 parallel = vnormalize(eu);
@@ -1947,6 +1943,32 @@ static int electron_radiate(Electron *e, uint64_t seed, uint32_t step, double t,
     e->chi = e->chi * new_gamma / e->gamma;
     e->gamma = new_gamma;
     e->u[0] = eu.x; e->u[1] = eu.y; e->u[2] = eu.z;
+    return k;
+}
+/* the same with the three uniforms given (tests/test_qed_radiate_independent.py): out = k[3], u'[3], gamma', chi',
+ * formation length; -1 where the reference panics (chi >= 100) */
+int oracle_radiate_with_randoms(double chi, double gamma, const double *u, double r1, double r2, double r3, double *out)
+{
+    Electron e;
+    memset(&e, 0, sizeof e);
+    e.chi = chi; e.gamma = gamma; e.u[0] = u[0]; e.u[1] = u[1]; e.u[2] = u[2];
+    double smp[3], fl;
+    if (oracle_qed_sample(chi, gamma, r1, r2, r3, smp)) return -1;
+    Vec3 k = radiate_core(&e, smp, &fl);
+    out[0] = k.x; out[1] = k.y; out[2] = k.z;
+    out[3] = e.u[0]; out[4] = e.u[1]; out[5] = e.u[2];
+    out[6] = e.gamma; out[7] = e.chi; out[8] = fl;
+    return 0;
+}
+
+static int electron_radiate(Electron *e, uint64_t seed, uint32_t step, double t, Photon *photon, double *formation_length)
+{
+    if (!(e->tau < 0.0)) return 0;
+    double rnd[4], smp[3];
+    oracle_emission_randoms(seed, e->id, step, rnd);
+    e->tau = -log(1.0 - rnd[0]);
+    if (oracle_qed_sample(e->chi, e->gamma, rnd[1], rnd[2], rnd[3], smp)) return -1;
+    Vec3 k = radiate_core(e, smp, formation_length);
     double kk[3] = {k.x, k.y, k.z};
     /* Photon::create(cell, x, u, weight, 0.0, 0.0): dt/dx = 0/0, so prev_x starts as NaN in the
      * reference too; it is overwritten by the first push and photons are never deposited */

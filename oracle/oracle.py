@@ -634,3 +634,14 @@ def ion_kinetic_energy(p):
     f.restype, f.argtypes = C.c_double, [C.c_void_p]
     return f(C.byref(p))
 
+
+def radiate_with_randoms(chi, gamma, u, r1, r2, r3):
+    """electron.rs:213-240 with the three uniforms given: (k[3], u'[3], gamma', chi', formation length)."""
+    f = lib().oracle_radiate_with_randoms
+    f.restype = C.c_int
+    f.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    out = (C.c_double * 9)()
+    if f(chi, gamma, (C.c_double * 3)(*u), r1, r2, r3, out):
+        raise ValueError("chi >= 100: the reference's sampler panics (photon_emission.rs:143-144)")
+    return np.array(out)
+

@@ -568,6 +568,57 @@ class Ion:  # ion.rs:14-26
         self.cell, self.x, self.prev_x = step_cell(self.cell, self.x, self.prev_x)
 
 
+class Photon:  # photon.rs:16-32 (polarisation members and optical depths: not on this path)
+    species = "photon"
+
+    def __init__(self, cell, x, u, weight_, dx, dt):  # create, photon.rs:95-119
+        k = (u[0], u[1], u[2])
+        k0 = math.sqrt(norm_sqr(k))
+        self.cell = cell
+        self.prev_x = x - SPEED_OF_LIGHT * k[0] * dt / (k0 * dx)
+        self.x = x
+        self.y = 0.0
+        self.z = 0.0
+        self.weight = weight_
+        self.k = k
+        self.u = k  # (what the dumps call the momentum)
+        self.chi = 0.0
+
+    def location(self):  # photon.rs:185-187
+        return self.cell, self.x, self.prev_x
+
+    def charge(self):  # photon.rs:197-199
+        return 0.0
+
+    def velocity(self):  # photon.rs:213-217
+        k0 = math.sqrt(norm_sqr(self.k))
+        return vdiv(smul(SPEED_OF_LIGHT, self.k), k0)
+
+    def energy(self):  # photon.rs:219-221
+        return math.sqrt(norm_sqr(self.k)) * ELECTRON_MASS_MEV
+
+    def total_kinetic_energy(self):  # photon.rs:223-225
+        return self.weight * self.energy() * 1.0e6 * ELEMENTARY_CHARGE
+
+    def shift_cell(self, delta):  # photon.rs:193-195
+        self.cell = self.cell + delta
+
+    def push(self, E, B, dx, dt):  # photon.rs:150-183
+        E = (E[0], E[1], E[2])
+        B = (B[0], B[1], B[2])
+        k0 = math.sqrt(norm_sqr(self.k))
+        v = vdiv(smul(SPEED_OF_LIGHT, self.k), k0)
+        self.chi = math.sqrt(norm_sqr(vadd(smul(k0, E), smul(SPEED_OF_LIGHT, vcross(self.k, B))))
+                             - powi2(vdot(E, self.k))) / CRITICAL_FIELD
+        self.prev_x = self.x
+        dxi = v[0] * dt / dx
+        assert dxi < 1.0
+        self.x = self.x + dxi
+        self.y = self.y + v[1] * dt
+        self.z = self.z + v[2] * dt
+        self.cell, self.x, self.prev_x = step_cell(self.cell, self.x, self.prev_x)
+
+
 # ---------------------------------------------------------------------------------------------------
 # particle/mod.rs:247-376 — Population::advance over a whole world
 # ---------------------------------------------------------------------------------------------------
@@ -815,7 +866,40 @@ def state_dump(pts):
     if pts and isinstance(pts[0], Electron):
         d.update(chi=hx([p.chi for p in pts]), work=hx([p.work for p in pts]), y=hx([p.y for p in pts]),
                  z=hx([p.z for p in pts]), gamma=hx([p.gamma for p in pts]))
+    if pts and isinstance(pts[0], Photon):
+        d.update(chi=hx([p.chi for p in pts]), y=hx([p.y for p in pts]), z=hx([p.z for p in pts]))
     return d
+
+
+def vectors_photons(rng):
+    """Photon::create + push (photon.rs:95-119, 150-183) through Population::advance on one periodic subdomain of random
+    fields: straight lines at c (a cell crossing almost every step), chi from the gathered fields, y and z, the kinetic
+    energy (photon.rs:219-225); three steps, the state after each."""
+    out = []
+    dx = 1.0e-8
+    dt = 0.95 * dx / SPEED_OF_LIGHT
+    for label, kscale in (("MeV photons", 5.0), ("soft photons, all directions", 1.0e-3)):
+        d = design_unbalanced(0, 1, 20, 0.0, dx, 8, INTERNAL, INTERNAL)
+        g = YeeGrid(d)
+        randomise(g, rng, comps=("Ex", "Ey", "Ez", "Bx", "By", "Bz"), amp={"E": 3e12, "B": 1e4})
+        world_synchronize([g], lambda a, b: 0.0, lambda a, b: 0.0, 0.0, dt)
+        ph = []
+        for _ in range(40):
+            k = [kscale * rng.gauss(0, 1) for _ in range(3)]
+            ph.append(Photon(rng.randrange(g.size), rng.random(), k, 7.0e5 * (0.5 + rng.random()), dx, dt))
+        ph.append(Photon(3, 0.5, [kscale, 0.0, 0.0], 7.0e5, dx, dt))     # along +x: |dxi| = 0.95
+        ph.append(Photon(3, 0.5, [-kscale, 0.0, 0.0], 7.0e5, dx, dt))
+        ph.append(Photon(3, 0.5, [0.0, kscale, 0.0], 7.0e5, dx, dt))     # never leaves its cell
+        rec = {"name": label, "design": design_dump(d), "dt": hx(dt),
+               "fields": grid_dump(g, ("Ex", "Ey", "Ez", "Bx", "By", "Bz")), "created": created_dump(ph),
+               "created_prev_x": hx([p.prev_x for p in ph]), "steps": []}
+        for _ in range(3):
+            world_pop_advance([ph], [g], dt)
+            st = state_dump(ph)
+            st["kinetic_energy_sequential_sum"] = hx(sum_seq([p.total_kinetic_energy() for p in ph]))
+            rec["steps"].append(st)
+        out.append(rec)
+    return out
 
 
 def vectors_deposit(rng):
@@ -1142,6 +1226,7 @@ def main():
     out["fields_at"] = vectors_fields_at(rng)
     out["electron_push"], out["ion_push"] = vectors_pushes(rng)
     out["deposit"] = vectors_deposit(rng)
+    out["photon_push"] = vectors_photons(random.Random(404))
     out["synchronize_advance"] = vectors_sync_advance(rng)
     out["design_unbalanced"], out["design_balanced"] = vectors_design()
     out["world_runs"] = vectors_world_runs(rng)

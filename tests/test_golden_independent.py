@@ -296,3 +296,27 @@ def test_world_runs(oracle, gold):
             assert_bits(g.em_field_energy(), fh(rec["em_field_energy_local"][r]), f"{rec['name']} rank {r} energy")
             check_pop(el[r], rec["electrons"][r], f"{rec['name']} rank {r} electrons", True)
             check_pop(io[r], rec["ions"][r], f"{rec['name']} rank {r} ions", False)
+
+
+def test_photon_push(oracle, gold):
+    """Photon::create + push through Population::advance (photon.rs:95-119, 150-183; KE :219-225), three steps."""
+    o = oracle
+    for rec in gold["photon_push"]:
+        d = rec["design"]
+        dx, dt = fh(d["dx"]), fh(rec["dt"])
+        g = build_world(o, d)[0]
+        load_grid(g, rec["fields"])
+        ph = make_pop(o, o.PHOTON, rec["created"], dx, dt)
+        assert_bits(ph.soa()["prev_x"], fh(rec["created_prev_x"]), f"{rec['name']}: create's prev_x")
+        for k, want in enumerate(rec["steps"]):
+            assert ph.advance(g, dt) == 0
+            s = ph.soa()
+            what = f"photons, {rec['name']}, step {k}"
+            assert s["cell"].tolist() == want["cell"], what
+            for key in ("x", "prev_x", "ux", "uy", "uz", "w"):
+                assert_bits(s[key], fh(want[key]), f"{what}: {key}")
+            ex = ph.photon_extras()
+            for key in ("chi", "y", "z"):
+                assert_bits(ex[key], fh(want[key]), f"{what}: {key}")
+            assert_bits(ph.total_kinetic_energy(), fh(want["kinetic_energy_sequential_sum"]), f"{what}: KE")
+

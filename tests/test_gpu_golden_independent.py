@@ -405,3 +405,39 @@ def test_world_runs(oa, gold, fused):
                     close(got[1], exp[1], 1.0, TOL_RUN, f"{what}: {name} x")
                     for k in (2, 3, 4):
                         close(got[k], exp[k], us, TOL_RUN, f"{what}: {name} u")
+
+
+def test_photon_push(oa, gold):
+    """opal_pop_advance for the photon species with chi, y, z tracked (photon.rs:150-183) and its kinetic energy
+    (photon.rs:219-225), three steps on random fields."""
+    for rec in gold["photon_push"]:
+        d = rec["design"]
+        dx, dt = fh(d["dx"]), fh(rec["dt"])
+        g = build(oa, d, 0)
+        load(g, rec["fields"])
+        ph = make_pop(oa, oa.PHOTON, rec["created"], dx, dt)
+        ph.track_extras(True)
+        fields = {c: fh(rec["fields"][c]) for c in FIELDS}
+        e_s, b_s = max(np.abs(fields[c]).max() for c in ("Ex", "Ey", "Ez")), max(np.abs(fields[c]).max() for c in ("Bx", "By", "Bz"))
+        kmax = max(np.abs(fh(rec["created"][c])).max() for c in ("ux", "uy", "uz")) * np.sqrt(3.0)
+        S = (kmax * e_s + 2.997925e8 * kmax * b_s) / 1.323285e18      # the terms chi's difference of squares is made of
+        for k, want in enumerate(rec["steps"]):
+            ph.advance(g, dt)
+            s = ph.soa(prev_x=True)
+            ex = ph.extras()
+            what = f"photons, {rec['name']}, step {k}"
+            wc = np.array(want["cell"], dtype=np.int64)
+            got = canon(s["cell"].astype(np.int64), s["x"], s["prev_x"], s["ux"], s["uy"], s["uz"], ex["chi"], ex["y"], ex["z"])
+            exp = canon(wc, *[fh(want[key]) for key in ("x", "prev_x", "ux", "uy", "uz", "chi", "y", "z")])
+            assert np.array_equal(got[0], exp[0]), f"{what}: cells"
+            close(got[1], exp[1], 1.0, TOL, f"{what}: x")
+            close(got[2], exp[2], 1.0, TOL, f"{what}: prev_x")
+            for q in (3, 4, 5):
+                assert np.array_equal(got[q], exp[q]), f"{what}: a photon's momentum never changes"
+            close(got[6] ** 2, exp[6] ** 2, S * S, 8 * TOL, f"{what}: chi^2")
+            ys = max(np.abs(exp[7]).max(), np.abs(exp[8]).max(), 1e-300)
+            close(got[7], exp[7], ys, 4 * TOL, f"{what}: y")
+            close(got[8], exp[8], ys, 4 * TOL, f"{what}: z")
+            ke = fh(want["kinetic_energy_sequential_sum"])
+            close(ph.total_kinetic_energy(), ke, abs(ke), 1e-11, f"{what}: KE")
+

@@ -645,3 +645,29 @@ def test_emission_statistics_in_a_static_magnetic_field(oa):
     # photons are beamed along the electron's motion, i.e. into the x-y plane: angles of a few 1 / gamma
     # (soft photons wider, ~ (omega_c / omega)^(1/3) / gamma), against 0.5 for an isotropic source
     assert np.abs(s["uz"] / (f * gamma)).mean() < 20.0 / gamma
+
+
+def test_radiate_event_against_independent_vectors(oa):
+    """Electron::radiate's event on the device -- sampled (omega, theta, phi) -> the photon's momentum about the electron's
+    direction, the formation length, the recoil (electron.rs:213-240; vec3.rs:115-144) -- with the three uniforms given,
+    against tests/golden/qed_radiate_independent.json (a pure-Python restatement on the reference's tables, no oracle):
+    1e-12 of each quantity's scale."""
+    import json
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qed_radiate_independent.json")))["cases"]
+
+    def fh(v):
+        return float.fromhex(v) if isinstance(v, str) else np.array([fh(a) for a in v])
+    chi = np.array([fh(c["chi"]) for c in cases])
+    u = np.array([fh(c["u"]) for c in cases])
+    r = np.array([fh(c["r"]) for c in cases])
+    out = oa.qed_radiate(chi, u, r[:, 0], r[:, 1], r[:, 2])
+    k = np.array([fh(c["k"]) for c in cases])
+    ua = np.array([fh(c["u_after"]) for c in cases])
+    ks = np.linalg.norm(k, axis=1)[:, None]
+    us = np.linalg.norm(u, axis=1)[:, None]
+    assert np.max(np.abs(out[:, 0:3] - k) / ks) < 1e-12
+    assert np.max(np.abs(out[:, 3:6] - ua) / us) < 1e-12
+    for col, key in ((6, "gamma_after"), (7, "chi_after"), (8, "formation_length")):
+        w = np.array([fh(c[key]) for c in cases])
+        assert np.max(np.abs(out[:, col] - w) / np.abs(w)) < 1e-12, key
+
