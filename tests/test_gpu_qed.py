@@ -667,7 +667,14 @@ def test_radiate_event_against_independent_vectors(oa):
     us = np.linalg.norm(u, axis=1)[:, None]
     assert np.max(np.abs(out[:, 0:3] - k) / ks) < 1e-12
     assert np.max(np.abs(out[:, 3:6] - ua) / us) < 1e-12
-    for col, key in ((6, "gamma_after"), (7, "chi_after"), (8, "formation_length")):
+    for col, key in ((6, "gamma_after"), (7, "chi_after")):
         w = np.array([fh(c[key]) for c in cases])
         assert np.max(np.abs(out[:, col] - w) / np.abs(w)) < 1e-12, key
+    # the formation length is proportional to theta = acos(c) with 1 - c ~ theta^2 / 2: an ulp of c moves theta by
+    # 2e-16 / sin(theta), theta ~ 1 / gamma (the tolerance test_sample_reproduces_the_reference_table_vectors gives theta)
+    fl = np.array([fh(c["formation_length"]) for c in cases])
+    g = np.array([fh(c["gamma"]) for c in cases])
+    theta = fl * chi / (2.0 * g * g * 2.997925e8 * 1.28808867e-21)
+    tol = 1e-12 + 1e-15 / (np.maximum(np.sin(theta), 1e-9) * theta)
+    assert np.all(np.abs(out[:, 8] - fl) / fl < tol), float(np.max(np.abs(out[:, 8] - fl) / fl / tol))
 
