@@ -209,3 +209,13 @@ def test_unfused_driver_equals_fused(tmp_path):
         a, b = out[False][k], out[True][k]
         assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300), k
     assert np.allclose(out[False]["ke"], out[True]["ke"], rtol=1e-10)
+
+
+def test_device_identity(oa):
+    """opal_device_identity: the PCI bus id and name of the card a rank runs on (what bench.py's `config.ranks` reports)."""
+    import re
+    bus, name = oa.device_identity()
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", bus), bus
+    assert "gfx" in name
+    assert oa.device_identity(0) == (bus, name) or oa.device_count() > 1
+
