@@ -211,9 +211,10 @@ def test_unfused_driver_equals_fused(tmp_path):
     assert np.allclose(out[False]["ke"], out[True]["ke"], rtol=1e-10)
 
 
-def test_device_identity(oa):
+def test_device_identity():
     """opal_device_identity: the PCI bus id and name of the card a rank runs on (what bench.py's `config.ranks` reports)."""
     import re
+    import opal_amd as oa
     bus, name = oa.device_identity()
     assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", bus), bus
     assert "gfx" in name
