@@ -29,7 +29,7 @@ class World:
 class InProcLink:
     """opal_link_t whose transport is a rendezvous of the threads of `world` (host-staged messages)."""
 
-    def __init__(self, world, rank, particle_capacity=1024, stream=None, photon_emission=False, periodic=True):
+    def __init__(self, world, rank, particle_capacity=1024, stream=None, photon_emission=False, periodic=True, growth=False):
         self._lib = _lib.load()
         self.world, self.rank = world, rank
         self.periodic = periodic
@@ -42,8 +42,15 @@ class InProcLink:
         self.h = h
         if self._lib.opal_link_set_exchange2(h, self._cb2):
             raise RuntimeError(self._lib.opal_last_error().decode())
+        if growth and self._lib.opal_link_set_growth(h, 1):  # (off by default for transports that are told a size)
+            raise RuntimeError(self._lib.opal_last_error().decode())
         self.calls = 0
         self.bytes = 0
+
+    def growth(self):
+        a, b, n = C.c_size_t(), C.c_size_t(), C.c_uint()
+        self._lib.opal_link_growth(self.h, C.byref(a), C.byref(b), C.byref(n))
+        return a.value, b.value, n.value
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -71,14 +71,14 @@ constants:
 """
 
 
-def _run_hip_world(world, text, steps, capacity, sort_interval=None, fused=True):
+def _run_hip_world(world, text, steps, capacity, sort_interval=None, fused=True, growth=False):
     import opal_amd as oa
     from _inproc_world import InProcLink, grid_dump, run_world, soa_dump
     streams = [oa.stream_create() for _ in range(world)]
 
     def body(r, w):
         st = streams[r]
-        link = InProcLink(w, r, particle_capacity=capacity, stream=st)
+        link = InProcLink(w, r, particle_capacity=capacity, stream=st, growth=growth)
         sim = oa.Simulation(yaml_text=text, rank=r, numtasks=world, link=link, stream=st)
         sim.set_fused(fused)
         if sort_interval:
@@ -94,6 +94,7 @@ def _run_hip_world(world, text, steps, capacity, sort_interval=None, fused=True)
         out["energies"] = sim.energies()
         out["steps"], out["t"], out["dt"] = n, sim.t, sim.dt
         out["calls"], out["bytes"] = link.calls, link.bytes
+        out["link_growth"] = link.growth()
         out["rebins"] = sim.electrons.counters()["steps_since_sort"]
         del sim, link
         return out
@@ -148,12 +149,16 @@ def test_configs2_cut_into_8_subdomains(oracle):
     assert moved > 704 * 2
 
 
-@pytest.mark.parametrize("world,end", [(4, 3.0), (8, 3.0)])
-def test_balanced_laser_plasma_world(oracle, tmp_path, world, end):
+@pytest.mark.parametrize("world,end,capacity", [(4, 3.0, 4096), (8, 3.0, 4096), (4, 3.0, 64)])
+def test_balanced_laser_plasma_world(oracle, tmp_path, world, end, capacity):
+    """(capacity 64: links created far too small for the front, with growth switched on -- the edges of a transport that is
+    told its sizes grow from the bound both ends hold, link.cpp: link_grow -- must give the same world.)"""
     import opal_amd as oa
     o = oracle
     text = LASER_PLASMA.format(end=end)
-    got = _run_hip_world(world, text, 0, capacity=4096)
+    got = _run_hip_world(world, text, 0, capacity=capacity, growth=capacity < 4096)
+    if capacity < 4096:
+        assert all(g["link_growth"][2] >= 1 for g in got[:-1]), [g["link_growth"] for g in got]
     cfgp = tmp_path / "lp.yaml"
     cfgp.write_text(text)
     cfg = oa.Config(path=cfgp)
