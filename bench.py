@@ -804,7 +804,10 @@ def main():
         for seg in range(CB_STEPS // CB_SEG):
             simc.step(CB_SEG)
             simc.sync()
-            n_e, n_p1 = len(simc.electrons), simc.photons.counters()["slots"]
+            # (slot counts: one small copy each; len() would bring the whole cell array to the host -- 40 MB and 1e7
+            # comparisons per call, which round 4's first version of this block did inside the timed loop: 0.63 ms/step
+            # where the run takes 0.40)
+            n_e, n_p1 = simc.electrons.counters()["slots"], simc.photons.counters()["slots"]
             if os.environ.get("OPAL_BENCH_CB_VERBOSE"):
                 print(f"[bench] rank {rank} colliding beams segment {seg}: {n_e} electrons, {n_p1} photons, "
                       f"{time.perf_counter() - t0:.2f} s", file=sys.stderr, flush=True)
