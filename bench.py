@@ -800,14 +800,14 @@ def main():
         oa.prof_enable(5)
         upd_e = upd_p = 0.0
         t0 = time.perf_counter()
-        n_p0 = simc.photons.counters()["slots"]
+        n_p0 = simc.photons.live()
         for seg in range(CB_STEPS // CB_SEG):
             simc.step(CB_SEG)
             simc.sync()
-            # (slot counts: one small copy each; len() would bring the whole cell array to the host -- 40 MB and 1e7
+            # (live counts from the device's counters: one small copy each; len() would bring the whole cell array to the host -- 40 MB and 1e7
             # comparisons per call, which round 4's first version of this block did inside the timed loop: 0.63 ms/step
             # where the run takes 0.40)
-            n_e, n_p1 = simc.electrons.counters()["slots"], simc.photons.counters()["slots"]
+            n_e, n_p1 = simc.electrons.live(), simc.photons.live()
             if os.environ.get("OPAL_BENCH_CB_VERBOSE"):
                 print(f"[bench] rank {rank} colliding beams segment {seg}: {n_e} electrons, {n_p1} photons, "
                       f"{time.perf_counter() - t0:.2f} s", file=sys.stderr, flush=True)
@@ -841,7 +841,7 @@ def main():
         res = {"what": what, "value": (tot_e + tot_p) / el, "unit": "particle-updates/s (electrons + photons pushed)",
                "electron_updates_per_s": tot_e / el, "photon_updates_per_s": tot_p / el, "steps": CB_STEPS, "warmup": CB_WARM,
                "ms_per_step": 1e3 * el / CB_STEPS, "electrons_end": int(all_sum(float(len(simc.electrons)))),
-               "photons_end": int(all_sum(float(simc.photons.counters()["slots"]))), "t_end": simc.t,
+               "photons_end": int(all_sum(float(simc.photons.live()))), "t_end": simc.t,
                "roofline": {"bound": "hbm", "kernel": "k_push<0, 0, true, 2, false> (electrons, optical depth + emitter list)"
                             if dom is ke else "k_push_photon<false>", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": dom["frac"], "traffic": None,
@@ -855,7 +855,7 @@ def main():
         if world > 1:
             pr = [None] * world
             dist.all_gather_object(pr, {"rank": rank, "ms_per_step_own_clock": 1e3 * el_local / CB_STEPS,
-                                        "electrons": len(simc.electrons), "photons": simc.photons.counters()["slots"]})
+                                        "electrons": simc.electrons.live(), "photons": simc.photons.live()})
             res["per_rank"] = pr
         del simc
         return res

@@ -156,6 +156,9 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
 int opal_pop_download_soa(const opal_pop_t *p, int32_t *cell, double *x, double *prev_x, double *ux,
                           double *uy, double *uz, double *w);
 int opal_pop_len(const opal_pop_t *p, size_t *n);  /* store.len() */
+/* the same from the device's counters (slots in use minus slots vacated since the last re-binning): one small copy instead of
+ * the whole cell array; exact between the library's own operators */
+int opal_pop_live(opal_pop_t *p, size_t *n);
 /* Population::advance, mod.rs:247-376: gather + push + migration to the neighbours
  * of `grid` through `link` (NULL = single subdomain: periodic self-wrap, or deletion
  * at open edges).  Stores prev_x for a later opal_grid_deposit. */

@@ -240,6 +240,12 @@ class Population:
         _check(self._lib.opal_pop_len(self.h, C.byref(n)))
         return n.value
 
+    def live(self):
+        """Live particles from the device's counters (no download of the cell array, unlike len())."""
+        n = C.c_size_t()
+        _check(self._lib.opal_pop_live(self.h, C.byref(n)))
+        return n.value
+
     def soa(self, prev_x=False, fields=("x", "ux", "uy", "uz", "w")):
         """Live particles in slot order; `fields` limits what is copied back (cell always is)."""
         n = len(self)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "opal_pop_upload_soa": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, dbl, dbl]),
     "opal_pop_download_soa": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "opal_pop_len": (C.c_int, [vp, C.POINTER(sz)]),
+    "opal_pop_live": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "opal_pop_advance": (C.c_int, [vp, vp, vp, dbl]),
     "opal_pop_advance_deposit": (C.c_int, [vp, vp, vp, dbl]),
     "opal_pop_total_kinetic_energy": (C.c_int, [vp, C.POINTER(dbl)]),

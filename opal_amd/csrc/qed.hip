@@ -567,6 +567,20 @@ int opal_qed_sample_batch(size_t n, const double *chi, const double *gamma, cons
     return OPAL_OK;
 }
 
+/* live particles of a population without bringing its cell array to the host (opal_pop_len does, for exactness after any
+ * operator): slots in use minus the slots vacated -- deleted at an open edge, absorbed, or sent to a neighbour -- since the last
+ * re-binning, from the device's counters (one small synchronous copy).  bench.py counts photon and electron updates by it. */
+int opal_pop_live(opal_pop_t *p, size_t *n)
+{
+    if (!p || !n) {
+        set_error("opal_pop_live: null argument");
+        return OPAL_ERR_ARG;
+    }
+    if (int rc = pop_check_err(p)) return rc;
+    *n = (size_t)p->h_ctr->n_slots - (size_t)std::min(p->h_ctr->n_dead, p->h_ctr->n_slots);
+    return OPAL_OK;
+}
+
 int opal_qed_radiate_batch(size_t n, const double *chi, const double *ux, const double *uy, const double *uz, const double *r1,
                            const double *r2, const double *r3, double *out)
 {
