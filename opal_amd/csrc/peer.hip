@@ -108,6 +108,23 @@ int peer_exchange2(void *user, const void *send_left, const void *send_right, vo
                                                                            l->peer->d_err + 1);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+// An edge's growth record into the control line of the neighbour's mailboxes: written the way the messages are (system-scope
+// stores from a kernel over the mapping the link already uses), not by a host copy into another device's memory.
+__global__ void k_peer_ctl_write(unsigned long long *dst, PeerCtl rec)
+{
+    static_assert(sizeof(PeerCtl) % 8 == 0 && sizeof(PeerCtl) <= PEER_CTL_BYTES, "control record");
+    constexpr unsigned W = sizeof(PeerCtl) / 8;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&rec);
+    // everything but the first word (generation, capacity), then the fence, then that word: a reader that sees the
+    // generation sees the handle
+    if (threadIdx.x >= 1 && threadIdx.x < W) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(dst, src[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 int peer_exchange(void *user, const void *send_left, const void *send_right, void *recv_left, void *recv_right, size_t nbytes)
 {
     return peer_exchange2(user, send_left, send_right, recv_left, recv_right, nbytes, nbytes);
@@ -276,7 +293,9 @@ int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state)
     mine.gen = gr->gen;
     mine.cap = (unsigned)new_cap;
     if (int rc = peer_export(p, &gr->fresh, bytes, mine.handle)) return rc;
-    OPAL_HIP(hipMemcpy(p->peer_base[side], &mine, sizeof mine, hipMemcpyHostToDevice));
+    k_peer_ctl_write<<<1, 64, 0, l->stream>>>(reinterpret_cast<unsigned long long *>(p->peer_base[side]), mine);
+    OPAL_HIP(hipGetLastError());
+    OPAL_HIP(hipStreamSynchronize(l->stream));
     if (getenv("OPAL_LINK_DEBUG"))
         fprintf(stderr, "[link] rank %d side %d: record of growth %u (%zu slots, %zu bytes) written\n", l->rank, side, gr->gen, new_cap, bytes);
     return OPAL_OK;
