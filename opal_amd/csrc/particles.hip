@@ -1194,16 +1194,19 @@ struct UnpackBatch {
     LinkBounds *bounds;                            // ring entry of this exchange (mapped host memory), or null
     unsigned seq;
     int zone_at;                                   // header word of this exchange's zone counts (link_h_zone)
+    int parts;      // workgroups per (species, side): 1, or TAIL_PARTS where a front may be crossing (unpack_arrivals)
 };
+constexpr int TAIL_PARTS = 8;
 
-__device__ void unpack_one(const UnpackArgs &a, int side);
+__device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigned of);
 
 template <int NT, bool ADV>
 __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
 {
     static_assert(!ADV || NT == ADV_TILE, "the field solve's workgroups are ADV_TILE threads");
     __shared__ double s_adv[ADV ? 2 * 5 * (ADV_EDGE + 2 * ADV_HALO) : 1];
-    const unsigned n_unpack = b.n ? 2u * (unsigned)b.n : 1u;
+    const unsigned parts = (unsigned)b.parts;
+    const unsigned n_unpack = b.n ? 2u * (unsigned)b.n * parts : 1u;
     if (ADV && blockIdx.x > n_unpack) {
         // an interior tile of the field solve: nothing synchronize or the neighbours' messages touch -- no waiting
         advance_interior(b.adv, (int)(blockIdx.x - n_unpack) - 1, s_adv);
@@ -1213,11 +1216,35 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
     // that SENDS over a peer link: it reads this subdomain's edge cells for the halo, and must have done so before it
     // overlays the neighbours' halos on them
     const bool boss = b.has_sync ? blockIdx.x == n_unpack : blockIdx.x == 0;
+    // (species index, side, share) of a workgroup that unpacks
+    const unsigned pair = blockIdx.x / parts, part = blockIdx.x % parts;
     if (b.peer.enabled) {
-        if (boss) peer_send(b.peer);  // (ends behind a barrier: the send messages have been read)
+        if (parts == 1) {
+            if (boss) peer_send(b.peer);  // (ends behind a barrier: the send messages have been read)
+        } else {
+            // A cut a front may be crossing: the message is shared out.  The workgroup that runs synchronize sends header,
+            // halo and the row blocks of species slots nobody unpacks; the workgroups of (species, side) send that species'
+            // row blocks of the message that LEAVES through that side, a share each; the last ticket publishes.
+            const bool unpacker = b.n && blockIdx.x < n_unpack;
+            if (boss) {
+                unsigned covered = 0;
+                for (int i = 0; i < b.n; i++) covered |= 1u << b.a[i].slot;
+                peer_send_head(b.peer, ((1u << b.peer.layout.nslots) - 1u) & ~covered);
+            }
+            if (unpacker) peer_send_rows(b.peer, (int)(pair & 1u), (unsigned)b.a[pair >> 1].slot, part, parts);
+            if (boss || unpacker)
+                if (peer_publish(b.peer, b.peer.err + 1, (b.n ? n_unpack : 0u) + (b.has_sync || !b.n ? 1u : 0u)))
+                    // every sender has read the leaver counts: they (and the next push's zone counts) can be zeroed -- by
+                    // whoever knows that, not by the workgroup that runs synchronize at a time of its own
+                    for (int w = 0; w < 16; w++)
+                        if (w < b.zone_at || w >= b.zone_at + 4) {
+                            if (b.zero[0]) b.zero[0][w] = 0u;
+                            if (b.zero[1]) b.zero[1][w] = 0u;
+                        }
+        }
         peer_wait(b.peer);
     }
-    if (boss && threadIdx.x < 16 && (threadIdx.x < b.zone_at || threadIdx.x >= b.zone_at + 4)) {
+    if (boss && !(b.peer.enabled && parts > 1) && threadIdx.x < 16 && (threadIdx.x < b.zone_at || threadIdx.x >= b.zone_at + 4)) {
         // the leaver counts have been shipped, and the OTHER set of zone counts is the next push's; this exchange's set
         // stays as it is until the next tail (the first workgroup is reading it)
         if (b.zero[0]) b.zero[0][threadIdx.x] = 0u;
@@ -1246,20 +1273,24 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
         if (ADV && b.has_adv) advance_edges(b.adv, s_adv);  // the cells synchronize wrote, and their stencil neighbours
         return;
     }
-    if (b.n) unpack_one(b.a[blockIdx.x >> 1], blockIdx.x & 1);
+    if (b.n) unpack_one(b.a[pair >> 1], (int)(pair & 1u), part, parts);
 }
 
-__device__ void unpack_one(const UnpackArgs &a, int side)
+// arrivals [first, first + count) of one species through one side: share `part` of `of` (whole row blocks each)
+__device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigned of)
 {
     __shared__ unsigned s_base;
     const char *msg = a.recv[side];
     if (!msg) return;
-    unsigned count = reinterpret_cast<const unsigned *>(msg)[LINK_H_COUNT + a.slot];
-    if (count > a.recv_cap[side]) count = a.recv_cap[side];  // the sender has flagged the overflow on its side
+    unsigned total = reinterpret_cast<const unsigned *>(msg)[LINK_H_COUNT + a.slot];
+    if (total > a.recv_cap[side]) total = a.recv_cap[side];  // the sender has flagged the overflow on its side
     // (a peer link ships whatever leaves: more arrivals than the bound the host grew its slot count by would leave
     // pushes sized from that count short of the last slots -- reported, not absorbed)
-    if (count > a.reserve[side] && threadIdx.x == 0) atomicOr(&a.ctr->err, 128);
-    if (count == 0) return;
+    if (total > a.reserve[side] && threadIdx.x == 0 && part == 0) atomicOr(&a.ctr->err, 128);
+    const unsigned per = ((total + of - 1) / of + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+    const unsigned first = part * per;
+    if (first >= total) return;
+    const unsigned count = total - first < per ? total - first : per;
     if (threadIdx.x == 0) s_base = atomicAdd(&a.ctr->n_slots, count);
     __syncthreads();
     unsigned base = s_base;
@@ -1270,7 +1301,8 @@ __device__ void unpack_one(const UnpackArgs &a, int side)
         }
         return;
     }
-    for (unsigned k = threadIdx.x; k < count; k += blockDim.x) {
+    base -= first;  // (slot of arrival k is base + k below)
+    for (unsigned k = first + threadIdx.x; k < first + count; k += blockDim.x) {
         a.cell[base + k] = *link_cell(msg, a.layout, a.slot, k) + (side == 1 ? a.my_size : 0);
 #pragma unroll
         for (int c = 0; c < 5; c++) a.f[c][base + k] = *link_field(msg, a.layout, a.slot, c, k);
@@ -1866,7 +1898,12 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
         b.seq = link->xseq;
     }
     b.zone_at = link_h_zone(link->xseq ? link->xseq - 1 : 0u);
-    const unsigned nblk = (b.n ? 2 * b.n : 1) + b.has_sync;
+    // Where many particles stand near a cut (the bound the link is held to: a front, a hot dense plasma) a step's leavers can
+    // be megabytes: sending and unpacking are then shared among TAIL_PARTS workgroups per species and side.  Two-stream
+    // links (bound ~25 000 slots, ~30 leavers a step) keep the single workgroups.
+    static const unsigned parts_at = getenv("OPAL_TAIL_PARTS_AT") ? (unsigned)atoi(getenv("OPAL_TAIL_PARTS_AT")) : 65536u;  // (tests)
+    b.parts = (peer_exchange && std::max(link->plan_cap[0], link->plan_cap[1]) >= parts_at) ? TAIL_PARTS : 1;
+    const unsigned nblk = (b.n ? 2 * b.n * b.parts : 1) + b.has_sync;
     if (b.has_adv) k_link_tail<ADV_TILE, true><<<nblk + grid_interior_tiles(b.adv), ADV_TILE, 0, st>>>(b);
     else k_link_tail<256, false><<<nblk, 256, 0, st>>>(b);
     OPAL_HIP(hipGetLastError());

@@ -47,7 +47,7 @@ struct PeerArgs {
     int head_only;         // halo-only exchange (yee.rs:358-409 on its own): header + halo, no leavers
     int pack_halo;         // the halo is taken from the grid rows (HaloSrc) instead of the send message
     HaloSrc halo;
-    unsigned *err;         // device word: bit 0 = a neighbour's message never came
+    unsigned *err;         // device word: bit 0 = a neighbour's message never came; the word behind it: the senders' ticket
 };
 
 #ifdef __HIPCC__
@@ -108,6 +108,64 @@ __device__ inline void peer_send(const PeerArgs &a)
         for (int side = 0; side < 2; side++)
             if (a.send[side])  // release: everything stored above is visible before the sequence number is
                 __hip_atomic_store(reinterpret_cast<unsigned *>(a.dst[side]), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The same send shared among the workgroups of a launch (the tail of a linked step at a cut a front is crossing: megabytes of
+// leavers per step, which one workgroup moves at a few tens of GB/s).  peer_send_head: header and halo of both messages, and
+// the row blocks of the species slots in `rows_of` (bit s = slot s: those no other workgroup takes).  peer_send_rows: the row
+// blocks of ONE species slot of ONE message, every `of`-th block starting at block `part`.  peer_publish: called by every
+// sending workgroup after its stores (contains a barrier); the one that draws the last of `senders` tickets knows every
+// share is out and stores the sequence numbers.  No workgroup waits for another of its own launch.
+__device__ inline void peer_send_rows(const PeerArgs &a, int side, unsigned slot, unsigned part, unsigned of)
+{
+    const char *msg = a.send[side];
+    if (!msg || a.head_only) return;
+    unsigned c = reinterpret_cast<const unsigned *>(msg)[LINK_H_COUNT + slot];
+    c = c < a.cap[side] ? c : a.cap[side];
+    const unsigned blocks = (c + LINK_ROWS - 1) / LINK_ROWS, wpb = a.layout.blk / 8;
+    for (unsigned b = part; b < blocks; b += of) {
+        const size_t off = (LINK_HEAD_BYTES + ((size_t)b * a.layout.nslots + slot) * a.layout.blk) / 8;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg) + off;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES) + off;
+        for (unsigned i = threadIdx.x; i < wpb; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__device__ inline void peer_send_head(const PeerArgs &a, unsigned rows_of)
+{
+    constexpr unsigned HEAD_WORDS = (unsigned)(LINK_HEAD_BYTES / 8), HEADER_WORDS = (unsigned)(LINK_HEADER_BYTES / 8);
+    for (int side = 0; side < 2; side++) {
+        const char *msg = a.send[side];
+        if (!msg || threadIdx.x >= HEAD_WORDS) continue;
+        const unsigned i = threadIdx.x;
+        unsigned long long v;
+        if (a.pack_halo && i >= HEADER_WORDS)
+            v = (unsigned long long)__double_as_longlong(halo_value(a.halo, side, (int)(i - HEADER_WORDS)));
+        else
+            v = reinterpret_cast<const unsigned long long *>(msg)[i];
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES) + i, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int side = 0; side < 2; side++)
+        for (unsigned s = 0; s < a.layout.nslots; s++)
+            if (rows_of & (1u << s)) peer_send_rows(a, side, s, 0, 1);
+}
+// (returns true in thread 0 of the workgroup that drew the last ticket: every sender has read the send messages by then)
+__device__ inline bool peer_publish(const PeerArgs &a, unsigned *ticket, unsigned senders)
+{
+    bool last = false;
+    __syncthreads();  // (every wave waits for its stores before it arrives)
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == senders - 1) {
+            last = true;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch: stream order)
+            for (int side = 0; side < 2; side++)
+                if (a.send[side])
+                    __hip_atomic_store(reinterpret_cast<unsigned *>(a.dst[side]), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    return last;
 }
 
 // Called by every thread of a workgroup that is about to read what the neighbours sent.  Contains a barrier.

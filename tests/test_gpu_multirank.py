@@ -143,6 +143,17 @@ def test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, fused, nx
     assert sum(len(g["e_w"]) for g in got) == nx * npc
 
 
+@pytest.mark.parametrize("world,nx,mode", [(2, 64, "sim"), (3, 768, "sim"), (3, 768, "sim_es")])
+def test_tail_shared_among_workgroups_gives_the_same_world(oracle, tmp_path, monkeypatch, world, nx, mode):
+    """Where the bound says many particles stand near a cut, the tail kernel of the linked step shares sending and
+    unpacking among 8 workgroups per species and side, a ticket deciding who publishes the message (particles.hip:
+    k_link_tail, peer_device.hpp: peer_send_head / _rows / peer_publish).  Forced on from the first exchange here: the
+    same worlds as test_sim_fused_step_one_exchange_per_step must come out, against the oracle's."""
+    monkeypatch.setenv("OPAL_TEST_LINK", "peer")
+    monkeypatch.setenv("OPAL_TAIL_PARTS_AT", "1")
+    test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, world, 1, nx, mode, "peer")
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_decomposed_thin_plasma_is_ballistic(tmp_path, world, link_kind):
     """A plasma too thin to act on itself, cut into 2 and 3 subdomains, 700 steps under the adaptive re-binning policy:
@@ -223,6 +234,9 @@ def test_a_link_grows_instead_of_overflowing(oracle, tmp_path, monkeypatch):
     # density near the cuts)
     gap = 10
     monkeypatch.setenv("OPAL_TEST_GROW_GAP", str(gap))
+    # ... and the tail kernel shares sending and unpacking among 8 workgroups per species and side as soon as the bound
+    # says a few hundred particles stand near the cut (default: 65 536, the laser-plasma cuts)
+    monkeypatch.setenv("OPAL_TAIL_PARTS_AT", "256")
     _launch("_gloo_hip_worker.py", world, ["grow", tmp_path, nx, npc, steps, 1])
     nxs, offs = o.design_unbalanced(world, nx, dx)
     rng = np.random.default_rng(9)
