@@ -882,7 +882,12 @@ def main():
         sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
     else:
         wkey = f"two_stream:{nx}x{npc}"
-        sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
+        text = YAML.format(nx=nx, npc=npc)
+        if os.environ.get("OPAL_BENCH_HOT"):  # diagnostic: a hot plasma (u_th = that many mc) -- thousands of leavers per cut and step
+            u = os.environ["OPAL_BENCH_HOT"]
+            text = text.replace("ux: drift_u * (1.0 + 0.001 * nrand) * (2.0 * floor(urand - 0.5) + 1.0)", f"ux: {u} * nrand") \
+                       .replace("uy: 0.0", f"uy: {u} * nrand").replace("uz: 0.0", f"uz: {u} * nrand")
+        sim = oa.Simulation(yaml_text=text, rank=rank, numtasks=world, link=link, stream=stream)
     sim._bench_link = link
     sim.set_fused(not args.unfused)
     if args.self_exchange and world == 1:
