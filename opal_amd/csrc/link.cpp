@@ -343,6 +343,8 @@ int opal_link_create_layout(opal_link_t **out, int rank, int size, int device_bu
     OPAL_HIP(hipHostMalloc((void **)&l->h_bounds, sizeof(LinkBounds) * LINK_RING, hipHostMallocMapped | hipHostMallocCoherent));
     memset((void *)l->h_bounds, 0, sizeof(LinkBounds) * LINK_RING);
     OPAL_HIP(hipHostGetDevicePointer((void **)&l->d_bounds, (void *)l->h_bounds, 0));
+    OPAL_HIP(hipMalloc((void **)&l->d_tail_words, 8 * sizeof(unsigned long long)));
+    OPAL_HIP(hipMemset(l->d_tail_words, 0, 8 * sizeof(unsigned long long)));
     char **dev[4] = {&l->d_send_left, &l->d_send_right, &l->d_recv_left, &l->d_recv_right};
     for (auto d : dev) {
         OPAL_HIP(hipMalloc((void **)d, l->nbytes));
@@ -371,6 +373,7 @@ int opal_link_free(opal_link_t *l)
         hipHostFree(l->h_send_left); hipHostFree(l->h_send_right); hipHostFree(l->h_recv_left); hipHostFree(l->h_recv_right);
     }
     if (l->h_bounds) hipHostFree((void *)l->h_bounds);
+    if (l->d_tail_words) hipFree(l->d_tail_words);
     delete l;
     return OPAL_OK;
 }

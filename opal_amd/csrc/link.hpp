@@ -84,6 +84,7 @@ struct opal_link {
     char *h_send_left, *h_send_right, *h_recv_left, *h_recv_right;  // host staging when device_buffers == 0
     // message sizes that follow the particles (link.cpp): bounds of the last LINK_RING exchanges, written by the device
     opal::LinkBounds *h_bounds, *d_bounds;  // the same mapped pinned memory, host and device view
+    unsigned long long *d_tail_words;       // 8 device words: where the workgroups that share an unpack agree on its first slot
     unsigned xseq;           // whole-message exchanges so far
     unsigned ring_mask[opal::LINK_RING];  // which species' pushes counted into exchange e's headers, at e % LINK_RING (link_plan)
     unsigned send_cap[2];    // slots (a multiple of 64) the next exchange ships per species: left / right edge

@@ -1195,10 +1195,11 @@ struct UnpackBatch {
     unsigned seq;
     int zone_at;                                   // header word of this exchange's zone counts (link_h_zone)
     int parts;      // workgroups per (species, side): 1, or TAIL_PARTS where a front may be crossing (unpack_arrivals)
+    unsigned long long *first_slot;  // parts > 1: one word per (species, side), (exchange << 32) | first slot of its arrivals
 };
 constexpr int TAIL_PARTS = 8;
 
-__device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigned of);
+__device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigned of, unsigned long long *first_slot, unsigned seq);
 
 template <int NT, bool ADV>
 __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
@@ -1273,11 +1274,15 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
         if (ADV && b.has_adv) advance_edges(b.adv, s_adv);  // the cells synchronize wrote, and their stencil neighbours
         return;
     }
-    if (b.n) unpack_one(b.a[pair >> 1], (int)(pair & 1u), part, parts);
+    if (b.n) unpack_one(b.a[pair >> 1], (int)(pair & 1u), part, parts, b.first_slot ? b.first_slot + pair : nullptr, b.peer.seq);
 }
 
-// arrivals [first, first + count) of one species through one side: share `part` of `of` (whole row blocks each)
-__device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigned of)
+// arrivals of one species through one side: share `part` of `of` (whole row blocks each).  The shares of one (species, side)
+// land in ONE run of slots, in message order -- the re-binning's windows and the arrival chunks' tiles count on arrivals
+// from one neighbour standing together (interleaved by whichever workgroup came first, the same arrivals cost the counting
+// sort 65 % more) --: share 0 reserves the run and publishes its first slot with the exchange number; the others wait for
+// that word (a launch of a few dozen workgroups, all resident; bounded like every wait here).
+__device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigned of, unsigned long long *first_slot, unsigned seq)
 {
     __shared__ unsigned s_base;
     const char *msg = a.recv[side];
@@ -1291,17 +1296,36 @@ __device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigne
     const unsigned first = part * per;
     if (first >= total) return;
     const unsigned count = total - first < per ? total - first : per;
-    if (threadIdx.x == 0) s_base = atomicAdd(&a.ctr->n_slots, count);
+    if (threadIdx.x == 0) {
+        if (of == 1) {
+            s_base = atomicAdd(&a.ctr->n_slots, total);
+        } else if (part == 0) {
+            s_base = atomicAdd(&a.ctr->n_slots, total);
+            __hip_atomic_store(first_slot, ((unsigned long long)seq << 32) | s_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const long long t0 = wall_clock64();
+            unsigned long long v;
+            while (((v = __hip_atomic_load(first_slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
+                if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+                    atomicOr(&a.ctr->err, 16);
+                    v = (unsigned long long)a.pop_cap;  // (past the end: this share is dropped, the error ends the run)
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_base = (unsigned)v;
+        }
+    }
     __syncthreads();
     unsigned base = s_base;
-    if (base + count > a.pop_cap) {
-        if (threadIdx.x == 0) {
+    if (base + total > a.pop_cap || base >= a.pop_cap) {
+        if (threadIdx.x == 0 && part == 0) {
             atomicOr(&a.ctr->err, 16);
-            atomicSub(&a.ctr->n_slots, count);
+            atomicSub(&a.ctr->n_slots, total);
         }
         return;
     }
-    base -= first;  // (slot of arrival k is base + k below)
+    // (slot of arrival k is base + k below)
     for (unsigned k = first + threadIdx.x; k < first + count; k += blockDim.x) {
         a.cell[base + k] = *link_cell(msg, a.layout, a.slot, k) + (side == 1 ? a.my_size : 0);
 #pragma unroll
@@ -1903,6 +1927,7 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
     // links (bound ~25 000 slots, ~30 leavers a step) keep the single workgroups.
     static const unsigned parts_at = getenv("OPAL_TAIL_PARTS_AT") ? (unsigned)atoi(getenv("OPAL_TAIL_PARTS_AT")) : 65536u;  // (tests)
     b.parts = (peer_exchange && std::max(link->plan_cap[0], link->plan_cap[1]) >= parts_at) ? TAIL_PARTS : 1;
+    b.first_slot = b.parts > 1 ? link->d_tail_words : nullptr;
     const unsigned nblk = (b.n ? 2 * b.n * b.parts : 1) + b.has_sync;
     if (b.has_adv) k_link_tail<ADV_TILE, true><<<nblk + grid_interior_tiles(b.adv), ADV_TILE, 0, st>>>(b);
     else k_link_tail<256, false><<<nblk, 256, 0, st>>>(b);
