@@ -391,3 +391,29 @@ def test_bench_prices_each_kernel_form_with_its_own_bytes():
     assert bench.bytes_model({}, 5, 5, False) is None
     # the hash that guards profiles/traffic.json does not move with comments or white space
     assert len(bench.src_sha()) == 16
+
+
+def test_native_launcher_without_a_gpu_fails_loudly_and_at_once(tmp_path):
+    """`opal_amd/bin/opal_amd [-n N] input.yaml` (main.cpp: the reference's `mpirun -n N opal input.yaml`) has no CPU
+    fallback: where no GPU is visible every rank says so, the launcher ends the others and leaves with a non-zero status --
+    nobody waits in a socket for a rank that has gone.  Also its usage line (main.rs:56-59)."""
+    import subprocess
+    exe = os.path.join(ROOT, "opal_amd", "bin", "opal_amd")
+    if not os.path.exists(exe):
+        pytest.skip("opal_amd/bin/opal_amd is built by __graft_entry__.build()")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is visible: tests/test_gpu_multirank.py runs the launcher for real")
+    except ImportError:
+        pass
+    yml = tmp_path / "in.yaml"
+    yml.write_text("---\ncontrol:\n nx: 64\n")
+    for n in (1, 3):
+        res = subprocess.run([exe] + (["-n", str(n)] if n > 1 else []) + [str(yml)], stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, timeout=60)
+        assert res.returncode != 0
+        assert "no HIP device visible" in res.stdout.decode()
+    res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+    assert res.returncode != 0 and "Usage: opal_amd [-n ranks] input-file" in res.stdout.decode()
+
