@@ -71,8 +71,8 @@ int link_begin(opal_link_t *l, hipStream_t st, unsigned species_mask)
 // LINK_ZONE pushes of s earlier at the most, within LINK_ZONE cells of that edge ON EITHER SIDE of it (it may have
 // crossed into this subdomain meanwhile and be on its way back): it was counted by this subdomain's push (`mine`) or by
 // the neighbour's (`theirs`) -- the pushes count the particles that stay within the zone AND the leavers through that
-// edge (a leaver of exchange e arrives after the receiver's push has counted, and stands within a cell of the cut).  So need(s) = mine + theirs of the most recent exchange e_s <= X - LINK_ZONE that counted
-// s -- between e_s and X the species is pushed at most LINK_ZONE times, whatever mix of per-species and combined
+// edge (a leaver of exchange e arrives after the receiver's push has counted, and stands within a cell of the cut).
+// So need(s) = mine + theirs of the most recent exchange e_s <= X - LINK_ZONE that counted s -- between e_s and X the species is pushed at most LINK_ZONE times, whatever mix of per-species and combined
 // exchanges the caller makes (the ring remembers which species each exchange counted).  Photons born since the count
 // (photon emission: links with >= 12 fields) come from electrons that were within the same LINK_ZONE cells, one photon
 // per electron and step at most: need(photons) += LINK_ZONE x need(electrons).  Stimulated emission (15 fields) has
