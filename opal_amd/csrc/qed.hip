@@ -74,10 +74,20 @@ struct Fit {
     }
 };
 
-// first row whose column `col` is >= v (rows are increasing in both columns), pwmci.rs:99-102,116-119
+// first row whose column `col` is >= v, pwmci.rs:99-102,116-119.  The reference scans from the first row; the same row is
+// found here by bisection over the rows [0, len - 4), which are non-decreasing in both columns in every table
+// (tests/test_qed_oracle.py::test_table_prefixes_are_monotone), and a scan of the last four, where the tabulated ln cdf is
+// rounding noise about zero: 5 dependent loads instead of up to 31-41 (round 4: k_radiate is a chain of these look-ups
+// per emitter and was 21 % of the GPU time of the colliding-beams step).
 __device__ inline int first_row_not_below(double v, Table t, int len, int col)
 {
-    int i = 0;
+    int lo = 0, hi = len - 4;  // the answer is in [lo, hi] if it is below len - 4
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v > t[mid][col]) lo = mid + 1;
+        else hi = mid;
+    }
+    int i = lo;
     while (i < len && v > t[i][col]) i++;
     return i;
 }

@@ -434,3 +434,24 @@ def test_golden_sample_vectors_are_what_the_generator_writes(tmp_path, monkeypat
     monkeypatch.setattr(mod, "HERE", str(tmp_path))
     mod.main()
     assert open(tmp_path / "qed_sample_reference_tables.json").read() == open(os.path.join(here, "qed_sample_reference_tables.json")).read()
+
+
+def test_table_prefixes_are_monotone():
+    """The device finds "the first row not below v" (pwmci.rs:99-102, 116-119) by bisection over all but the last four rows
+    of a table and a scan of those (opal_amd/csrc/qed.hip: first_row_not_below): the same row as the reference's scan from
+    the first row provided the rows before the last four are non-decreasing in both columns.  They are, in all 74 tables
+    (the tail rows of 17 of them are rounding noise about ln cdf = 0 and are not)."""
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opal_amd", "csrc", "qed_tables.inc")).read()
+    blocks = re.findall(r"\{\s*((?:\{\s*[-+0-9.eE]+\s*,\s*[-+0-9.eE]+\s*\}\s*,?\s*){20,})\}", text)
+    assert len(blocks) == 74
+    noisy = 0
+    for b in blocks:
+        rows = [(float(a), float(c)) for a, c in re.findall(r"\{\s*([-+0-9.eE]+)\s*,\s*([-+0-9.eE]+)\s*\}", b)]
+        assert len(rows) in (31, 41)
+        for col in (0, 1):
+            v = [r[col] for r in rows]
+            assert all(v[i + 1] >= v[i] for i in range(len(v) - 5)), (len(rows), col)
+            noisy += any(v[i + 1] < v[i] for i in range(len(v) - 1))
+    assert noisy == 17
+
