@@ -440,7 +440,14 @@ __device__ void radiate_one(const RadiateArgs &a, size_t i, int role)
     }
     if (a.max_formation_length >= 0.0) keep = keep && formation_length < a.max_formation_length;
     if (!keep) return;
-    unsigned slot = atomicAdd(&a.pctr->n_slots, 1u);
+    // One atomic per wave for the photons' slots (tens of thousands of photons a step all bump ONE counter: lane by lane that
+    // was most of this kernel's time): the lanes that keep their photon are counted, the first of them reserves the run.
+    const unsigned long long keepers = __ballot(1);
+    const int lane = (int)(threadIdx.x & 63u), first = __ffsll((long long)keepers) - 1;
+    unsigned base = 0;
+    if (lane == first) base = atomicAdd(&a.pctr->n_slots, (unsigned)__popcll(keepers));
+    base = __shfl(base, first);
+    unsigned slot = base + (unsigned)__popcll(keepers & ((1ull << lane) - 1ull));
     if (slot >= a.pcap) {  // cannot happen: the host sized the photon arrays for every emitter
         atomicSub(&a.pctr->n_slots, 1u);
         atomicAdd(&a.pctr->n_lost, 1u);
