@@ -245,50 +245,6 @@ __device__ bool quantum_sample(double chi, double gamma, double rand1, double ra
     return true;
 }
 
-// The same sample computed by TWO lanes (role 0 / 1, lanes 2k and 2k + 1 of a wave, both called with the same arguments):
-// the sampler interpolates between two tabulated cdfs twice -- ln u between chi-tables i and i + 1, y between delta-tables
-// j and j + 1 -- and each of the four inversions is a Brent iteration of thousands of dependent f64 instructions.  A wave
-// of emitters is alone on its SIMD (a few emitters per thousand electrons), so that chain IS the kernel's duration: each
-// lane of a pair inverts one table of each stage and the two exchange results.  Every number is computed by the same
-// instructions as in quantum_sample: the result is identical, bit for bit.
-__device__ bool quantum_sample_paired(double chi, double gamma, double rand1, double rand2, double rand3, int role, Sample &out)
-{
-    double ln_chi = log(chi);
-    if (ln_chi <= QED_LN_CHI_MIN) {
-        out = classical_sample(chi, gamma, rand1, rand2, rand3);
-        out.omega_mc2 = out.omega_mc2 * gamma / (gamma + out.omega_mc2);
-        return true;
-    }
-    double index = (ln_chi - QED_LN_CHI_MIN) / QED_LN_CHI_STEP;
-    double fl = floor(index);
-    double weight = index - fl;
-    if (!(fl < 40.0)) return false;
-    int i = (int)fl;
-    double ln_rand = log(rand1);
-    const double mine = quantum_ln_u(QED_QUANTUM_CDF[i + role], ln_rand);
-    const double theirs = __shfl_xor(mine, 1);
-    double u = exp((1.0 - weight) * (role ? theirs : mine) + weight * (role ? mine : theirs));
-
-    double beta = 2.0 * u / (3.0 * chi);
-    double delta = (1.0 + (1.0 + u) * (1.0 + u)) * pow(beta, -2.0 / 3.0) / (1.0 + u);
-    index = (log(delta) - QED_LN_DELTA_MIN) / QED_LN_DELTA_STEP;
-    fl = floor(index);
-    weight = index - fl;
-    double y;
-    if (!(fl < 30.0)) {  // delta > 100 (or not a number): the delta -> infinity table, one inversion (both lanes make it)
-        y = from_linear_cdf_table(0.0, beta, rand2, QED_Y_INFINITE_DELTA_CDF[0]);
-    } else {
-        int j = max((int)fl, 0);
-        double y0 = pow(delta, -1.5);
-        const double y_mine = from_linear_cdf_table(y0, beta, rand2, QED_Y_CDF[j + role]);
-        const double y_theirs = __shfl_xor(y_mine, 1);
-        y = (1.0 - weight) * (role ? y_theirs : y_mine) + weight * (role ? y_mine : y_theirs);
-    }
-    double z = fmax(y / beta, 1.0);
-    out = {gamma * u / (1.0 + u), polar_angle(gamma, z), 2.0 * M_PI * rand3};
-    return true;
-}
-
 // vec3.rs:115-138
 __device__ inline V3 normalize(V3 a) { return (1.0 / sqrt(dot(a, a))) * a; }
 __device__ inline V3 orthogonal(V3 a)
@@ -378,7 +334,7 @@ __global__ __launch_bounds__(256) void k_list_emitters(const int *__restrict__ c
         if (hits & (1u << it)) list[at++] = (unsigned)(chunk0 + (size_t)it * 256 + threadIdx.x);
 }
 
-__device__ void radiate_one(const RadiateArgs &a, size_t i, int role);
+__device__ void radiate_one(const RadiateArgs &a, size_t i);
 
 // Pass 2: Electron::radiate + the filters of emit_radiation, one listed emitter per thread
 __global__ __launch_bounds__(256) void k_radiate(RadiateArgs a)
@@ -386,9 +342,7 @@ __global__ __launch_bounds__(256) void k_radiate(RadiateArgs a)
     // the list length is read from the device: the host may not know it (asynchronous mode), so the grid is
     // sized for the most it can be and strides over the list
     const unsigned n_list = a.ectr->n_emit;
-    // (two lanes per emitter: quantum_sample_paired)
-    for (unsigned e = (blockIdx.x * blockDim.x + threadIdx.x) >> 1; e < n_list; e += (gridDim.x * blockDim.x) >> 1)
-        radiate_one(a, a.list[e], (int)(threadIdx.x & 1u));
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n_list; e += gridDim.x * blockDim.x) radiate_one(a, a.list[e]);
 }
 
 // electron.rs:219-240: the photon's momentum at polar angle theta around the electron's direction from the sampled
@@ -406,22 +360,20 @@ __device__ inline V3 radiate_core(V3 &u, double chi, double gamma, const Sample 
     return k;
 }
 
-__device__ void radiate_one(const RadiateArgs &a, size_t i, int role)
+__device__ void radiate_one(const RadiateArgs &a, size_t i)
 {
 
     unsigned long long id;
     memcpy(&id, &a.id[i], sizeof id);
     double rnd[4];
     emission_randoms(a.seed, id, a.step, rnd);
+    a.tau[i] = -log(1.0 - rnd[0]);  // Exp1, electron.rs:211
+
     V3 u = {a.ux[i], a.uy[i], a.uz[i]};
     const double chi = a.chi[i];
     const double gamma = sqrt(1.0 + dot(u, u));  // the reference keeps gamma in the struct (same value up to rounding)
     Sample smp;
-    // (both lanes of the pair have read the electron before either writes it: they stay together to the end of the sampler)
-    const bool ok = quantum_sample_paired(chi, gamma, rnd[1], rnd[2], rnd[3], role, smp);
-    if (role) return;  // the even lane of the pair finishes the event
-    a.tau[i] = -log(1.0 - rnd[0]);  // Exp1, electron.rs:211
-    if (!ok) {
+    if (!quantum_sample(chi, gamma, rnd[1], rnd[2], rnd[3], smp)) {
         atomicOr(&a.ectr->err, 32);  // photon_emission.rs:143-144: chi >= 100 is unimplemented!() there
         return;
     }
