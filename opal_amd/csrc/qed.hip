@@ -41,7 +41,9 @@ struct QedCdf {
 // stops on a 1e-6 bracket and branches on comparisons of residuals, so a fused multiply-add can return a
 // different iterate than the reference's (Rust never fuses).  Unfused, the device differs from the CPU
 // restatement only by the last-ulp differences of log/exp/pow/acos, and tests/test_gpu_qed.py holds the
-// golden vectors of tests/golden/qed_sample_reference_tables.json to 1e-12.  k_radiate is 64 us of a step.
+// golden vectors of tests/golden/qed_sample_reference_tables.json to 1e-12.  k_radiate is ~70 us of a colliding-beams step
+// at its peak (1e5-3e5 emitters): VALU-bound -- 17.5e6 wave-instructions per launch over 1024 SIMDs (round 4's counters),
+// not a latency chain: two lanes per emitter, each inverting one table of each interpolation stage, changed nothing.
 #pragma clang fp contract(off)
 
 constexpr int RECURSION_LIMIT = 32;      // pwmci.rs:3
