@@ -21,10 +21,16 @@ region (`bytes_model`; the library reports the form of each launch, opal_prof_fo
 `algorithmic_GBps_over_whole_step` <= 8000.  The kernel's mean duration is measured with HIP events on the
 simulation's stream around a 1-in-5 sample of its launches in the timed region; `traffic` is the PMC-measured HBM bytes
 per launch from profiles/traffic.json, used only if that entry was taken for this workload, this kernel instantiation
-and these kernel sources.  At N = 1 the line also carries configs[1] (`secondary`) and configs[3]'s physics inside the
-laser-plasma interaction (`laser_plasma_interaction`), measured the same way in the same process.  At N > 1 the line
-carries `laser_plasma_interaction` for configs[3] as named (1e8 particles, `balance: true`) on the same N GPUs, run after
-the two-stream measurement is complete and under a deadline, so that nothing in it can cost the line.
+and these kernel sources: `roofline.frac` prices a launch with the form's ALGORITHMIC bytes, `roofline.frac_physical` with the
+bytes that crossed the HBM interface (an attribute no lane of a wave changed is not written back: fewer than 80).  A `--steps`
+below 200 is followed by a second timed region of 200 steps (`steps_long`).  At N = 1 the line also carries configs[1]
+(`secondary`), configs[3]'s physics inside the laser-plasma interaction (`laser_plasma_interaction`) and configs[4]
+(`colliding_beams`: examples/colliding_beams.yaml's physics with photon emission through the collision, electrons + photons
+pushed, each kernel priced with its own bytes), measured the same way in the same process.  At N > 1 the line carries
+`laser_plasma_interaction` for configs[3] as named (1e8 particles, `balance: true`) and `colliding_beams` on the same N GPUs,
+run after the two-stream measurement is complete and each under a deadline, so that nothing in them can cost the line;
+`config.gpus_seen` / `config.ranks` say which cards took part (host, HIP ordinal, PCI bus id, link kind) whatever the
+transport, `per_rank` what each rank did (its own clock, particles, push time, re-binnings, its link's room and growths).
 
 `python bench.py --gpus N` needs no launcher: with WORLD_SIZE unset the parent -- which never touches a
 GPU -- starts N ranks of itself as child processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on
