@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -970,17 +971,35 @@ int opal_sim_run(opal_sim_t *s)
         if (int rc = write_pop(s, s->photons, "photon", s->photon_output, i)) return rc;
         return write_energies(s, i);
     };
+    // PrettyDuration, setup.rs:404-419; ettc, setup.rs:372-378
+    auto pretty = [](double seconds) {
+        unsigned long long t = (unsigned long long)seconds;
+        const unsigned long long sec = t % 60, min = (t / 60) % 60, hr = (t / 3600) % 24, d = t / 86400;
+        char buf[64];
+        if (d > 0) snprintf(buf, sizeof buf, "%llud %02llu:%02llu:%02llu", d, hr, min, sec);
+        else snprintf(buf, sizeof buf, "%02llu:%02llu:%02llu", hr, min, sec);
+        return std::string(buf);
+    };
+    const auto runtime = std::chrono::steady_clock::now();  // main.rs:215
+    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - runtime).count(); };
     for (size_t i = 0; i < s->n_outputs; i++) {
         if (int rc = write_all(i)) return rc;
-        if (s->rank == 0) {
-            printf("Output %4zu at t = %s...\n", i, simulation_time(s->t).c_str());
+        if (s->rank == 0) {  // main.rs:224-234
+            if (i > 0) {
+                const double rt = elapsed(), done = (double)(i * s->steps_bt_output), total = (double)(s->n_outputs * s->steps_bt_output);
+                printf("Output %4zu at t = %s, RT = %s, ETTC = %s...\n", i, simulation_time(s->t).c_str(), pretty(rt).c_str(),
+                       pretty(rt * (total - done) / done).c_str());
+            } else {
+                printf("Output %4zu at t = %s...\n", i, simulation_time(s->t).c_str());
+            }
             fflush(stdout);
         }
         if (int rc = opal_sim_step(s, s->steps_bt_output)) return rc;
         if (int rc = opal_sim_sync(s)) return rc;
     }
     if (int rc = write_all(s->n_outputs)) return rc;
-    if (s->rank == 0) printf("Output %4zu at t = %s\n", s->n_outputs, simulation_time(s->t).c_str());
+    if (s->rank == 0)  // main.rs:278-283
+        printf("Output %4zu at t = %s, RT = %s\n", s->n_outputs, simulation_time(s->t).c_str(), pretty(elapsed()).c_str());
     return OPAL_OK;
 }
 
