@@ -82,6 +82,23 @@ int link_begin(opal_link_t *l, hipStream_t st, unsigned species_mask)
 // and files every LINK_PEER_EVERY-th exchange: the same argument with an entry up to LINK_PEER_ZONE exchanges old (a
 // caller that exchanges species by species over such a link finds entries for the species of those exchanges only; the
 // others reserve the link's capacity).
+size_t link_room_for(const opal_link_t *l, size_t slots)
+{
+    size_t want = slots + slots / 4, cap2 = 1024;
+    while (cap2 < want) cap2 *= 2;
+    if (l->peer) {
+        // An edge's two mailboxes are one IPC-shared allocation, and one of 2 GiB or more could not be mapped by
+        // the neighbour (hipIpcOpenMemHandle never returned for 2.5 GB where 1.26 GB had taken milliseconds:
+        // round 4, two processes on one MI355X).  An edge stops growing below that; a bound beyond it -- the bound
+        // counts what COULD cross, newborn photons of every electron near the cut included -- is then not
+        // covered by room, and a real overflow would be the error it always was.
+        const size_t per_slot = (size_t)l->layout.nslots * l->layout.blk / LINK_ROWS;
+        const size_t most = ((((size_t)1 << 31) - 65536) / 2 - LINK_HEAD_BYTES) / per_slot;
+        while (cap2 > most) cap2 /= 2;
+    }
+    return cap2;
+}
+
 int link_plan(opal_link_t *l, unsigned species_mask)
 {
     unsigned full[2] = {(unsigned)l->cap_side[0], (unsigned)l->cap_side[1]};
@@ -156,18 +173,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
             // particle/mod.rs:308-354).  The other end of the edge reads the same numbers for the same exchange and
             // grows to the same capacity; a pile-up that moves on leaves the room behind (no shrinking: the memory is
             // what the densest moment of the run needed at this cut).
-            size_t want = (size_t)slots[side] + slots[side] / 4, cap2 = 1024;
-            while (cap2 < want) cap2 *= 2;
-            if (l->peer) {
-                // An edge's two mailboxes are one IPC-shared allocation, and one of 2 GiB or more could not be mapped by
-                // the neighbour (hipIpcOpenMemHandle never returned for 2.5 GB where 1.26 GB had taken milliseconds:
-                // round 4, two processes on one MI355X).  An edge stops growing below that; a bound beyond it -- the bound
-                // counts what COULD cross, newborn photons of every electron near the cut included -- is then not
-                // covered by room, and a real overflow would be the error it always was.
-                const size_t per_slot = (size_t)l->layout.nslots * l->layout.blk / LINK_ROWS;
-                const size_t most = ((((size_t)1 << 31) - 65536) / 2 - LINK_HEAD_BYTES) / per_slot;
-                while (cap2 > most) cap2 /= 2;
-            }
+            const size_t cap2 = link_room_for(l, slots[side]);
             if (cap2 > full[side]) grow_to[side] = cap2;
         }
     }

@@ -123,6 +123,9 @@ void link_peer_free(opal_link_t *l);
 // (peer.hip).  Both ends of an edge call it for the same exchange with the same capacity (link_plan decides from numbers
 // both hold).  Drains the device.
 int link_grow(opal_link_t *l, const size_t new_cap[2]);  // (0: that edge stays as it is)
+// the capacity an edge that must hold `slots` particles per species grows to (a power of two with a quarter to spare; a
+// peer link's stays below what its neighbour can map)
+size_t link_room_for(const opal_link_t *l, size_t slots);
 int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state);
 int link_peer_grow_finish(opal_link_t *l, int side, void *state);
 // OPAL_ERR_LINK if a wait for a neighbour's message has ever timed out on this link (peer links; OPAL_OK for the others).

@@ -337,8 +337,8 @@ int sim_setup(opal_sim_t *s)
         if (int rc = load_species(s, "ions", "ni", OPAL_ION, ipc, rng, &s->ions)) return rc;
         if (int rc = opal_pop_set_charge_state(s->ions, z, z, a)) return rc;  // main.rs:142-147
     }
+    size_t ppc = 0;
     if (s->photon_emission || s->photon_absorption) {  // main.rs:153-170
-        size_t ppc;
         if (!in.read_usize("photons", "npc", ppc, ce)) return config_fail(ce);
         if (!in.read_strings("photons", "output", s->photon_output, ce)) return config_fail(ce);
         if (ppc > 0) {
@@ -352,6 +352,56 @@ int sim_setup(opal_sim_t *s)
         // main.rs:53); the build's counter-based generator takes one key for the whole run, so that a
         // particle's draws do not depend on which subdomain it is in.
         s->emission_seed = 0x6f70616c5f616d64ull;
+    }
+    // A link that grows sizes each edge by the particles that stood near the cut a few exchanges earlier (link.cpp) -- history
+    // the first exchanges do not have.  What the loader put near each cut is known without any: npc particles in every cell
+    // whose density is positive (mod.rs:178-182), on this side and on the neighbour's, from the input file alone -- every rank
+    // evaluates the same expressions at the same cell centres and so arrives at its neighbour's number too.  An edge with
+    // less room than that grows here, before the first step; from then on the zone counts carry the bound.
+    if (s->link && s->link->growable) {
+        const int zone = link_is_peer(s->link) ? LINK_PEER_ZONE : LINK_ZONE;
+        struct Sp { const char *section, *key; size_t npc; };
+        std::vector<Sp> species;
+        if (s->electrons) species.push_back({"electrons", "ne", epc});
+        if (s->ions) species.push_back({"ions", "ni", ipc});
+        if (s->photons && ppc > 0) species.push_back({"photons", "nph", ppc});
+        size_t need[2] = {0, 0};
+        const int nt = s->numtasks;
+        const int nb[2] = {(s->rank - 1 + nt) % nt, (s->rank + 1) % nt};
+        const bool linked[2] = {opal_grid_to_left(s->grid) >= 0, opal_grid_to_right(s->grid) >= 0};
+        size_t electrons_near[2] = {0, 0};
+        for (const Sp &sp : species) {
+            std::function<double(const double *)> n;
+            if (!in.func(sp.section, sp.key, {"x"}, n, ce)) return config_fail(ce);
+            auto populated = [&](int r, long c0, long c1) {  // cells [c0, c1) of subdomain r that the loader fills
+                size_t k = 0;
+                const double x0 = s->xmin + offs[(size_t)r];
+                for (long c = std::max(c0, 0L); c < std::min(c1, (long)nxs[(size_t)r]); c++) {
+                    double x = x0 + ((double)c + 0.5) * s->dx;
+                    if (n(&x) * s->dx > 0.0) k++;
+                }
+                return k;
+            };
+            for (int side = 0; side < 2; side++) {
+                if (!linked[side]) continue;
+                const long mine_n = (long)nxs[(size_t)s->rank], theirs_n = (long)nxs[(size_t)nb[side]];
+                size_t cells = side == 0 ? populated(s->rank, 0, zone) + populated(nb[0], theirs_n - zone, theirs_n)
+                                         : populated(s->rank, mine_n - zone, mine_n) + populated(nb[1], 0, zone);
+                size_t count = cells * sp.npc;
+                if (sp.section[0] == 'e') electrons_near[side] = count;
+                need[side] = std::max(need[side], count);
+            }
+        }
+        if (s->photons && s->link->nfields >= 12 && s->link->nfields < 15)  // photons born of those electrons (link_plan)
+            for (int side = 0; side < 2; side++) need[side] = std::max(need[side], (size_t)zone * electrons_near[side]);
+        size_t grow_to[2] = {0, 0};
+        for (int side = 0; side < 2; side++) {
+            if (!need[side]) continue;
+            size_t slots = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+            if (slots > s->link->cap_side[side]) grow_to[side] = link_room_for(s->link, slots);
+        }
+        if (grow_to[0] || grow_to[1])
+            if (int rc = link_grow(s->link, grow_to)) return rc;
     }
     s->t = s->tstart;
     s->total_steps = (size_t)((s->tend - s->tstart) / s->dt);  // main.rs:186 (`as usize` truncates)

@@ -255,8 +255,12 @@ def main():
         for name, p in (("e", sim.electrons), ("i", sim.ions)):
             for k, v in p.soa().items():
                 init[f"init_{name}_{k}"] = v
+        if link is not None and hasattr(link, "growth"):
+            init["link_growth_at_start"] = np.array(link.growth())
         sim.step(steps)
         sim.sync()
+        if link is not None and hasattr(link, "growth"):
+            init["link_growth"] = np.array(link.growth())
         dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
         if link is not None and fused and nx >= 512 and mode != "sim_thin" and not peer:
             # (not before the first re-binning: until then a chunk is 8 x 256 slots, half of such a small population)

@@ -273,6 +273,37 @@ def test_a_link_grows_instead_of_overflowing(oracle, tmp_path, monkeypatch):
         _launch("_gloo_hip_worker.py", world, ["grow", tmp_path / "nogrow", nx, npc, steps, 1])
 
 
+def test_an_input_file_sizes_the_edges_it_starts_with(oracle, tmp_path, monkeypatch):
+    """Growth goes by the particles counted near a cut a few exchanges earlier; the first exchanges of a run have no such
+    history.  A Simulation knows what the loader put there -- npc particles in every cell of positive density (mod.rs:178-182),
+    on both sides of each cut, from the input file -- and grows an edge that is too small for it before the first step
+    (sim.cpp: sim_setup).  A link with room for 64 under a plasma that sends ~100 per step and species through each cut, each way, from
+    the very first step: the oracle world's run must come out; with growth off, the overflow error."""
+    monkeypatch.setenv("OPAL_TEST_LINK", "peer")
+    monkeypatch.setenv("OPAL_TEST_LINK_CAP", "64")
+    world, nx, npc, steps = 2, 64, 1024, 15
+    o = oracle
+    dx = 1.0e-8
+    dt = 0.95 * dx / C
+    _launch("_gloo_hip_worker.py", world, ["sim", tmp_path, nx, npc, steps, 1])
+    got = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    st_e = [tuple(g[f"init_e_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
+    st_i = [tuple(g[f"init_i_{k}"] for k in ("cell", "x", "ux", "uy", "uz", "w")) for g in got]
+    grids, pes, pis = _oracle_world(o, world, nx, dx, dt, st_e, st_i, steps)
+    for r in range(world):
+        cl, cr, grows = [int(v) for v in got[r]["link_growth_at_start"]]
+        assert grows >= 1 and cl >= 2 * 8 * npc and cr >= 2 * 8 * npc, (cl, cr, grows)  # 8 cells (LINK_PEER_ZONE) either side
+        assert tuple(got[r]["link_growth"]) == (cl, cr, grows)                      # ... and nothing more was needed later
+        assert len(got[r]["e_w"]) == len(pes[r]) and len(got[r]["i_w"]) == len(pis[r])
+        for k in COMPS:
+            ref = grids[r].raw(k)
+            assert np.max(np.abs(got[r][k] - ref)) / max(np.max(np.abs(ref)), 1e-300) < 1e-9, (r, k)
+    monkeypatch.setenv("OPAL_LINK_NO_GROWTH", "1")
+    (tmp_path / "nogrow").mkdir()
+    with pytest.raises(AssertionError, match="leaver buffer overflow"):
+        _launch("_gloo_hip_worker.py", world, ["sim", tmp_path / "nogrow", nx, npc, steps, 1])
+
+
 @pytest.mark.parametrize("world,deposit", [(2, 0), (3, 0), (2, 1)])
 def test_photon_emission_across_subdomains(oracle, tmp_path, world, deposit, link_kind):
     """Config C5's physics decomposed: electrons carry their optical depths and ids across the cuts, photons
