@@ -52,7 +52,7 @@ __global__ __launch_bounds__(FT) void k_advance(AdvArgs a)
 
 __global__ void k_publish_only(PublishBatch pub) { publish_counters(pub); }
 
-constexpr int ADV_LDS = 2 * 5 * (ADV_EDGE + 2 * ADV_HALO);  // doubles: the synchronize workgroup's two edge tiles
+constexpr int ADV_LDS = 2 * 6 * (ADV_EDGE + 2 * ADV_HALO);  // doubles: the synchronize workgroup's two edge tiles (six components)
 static_assert(ADV_LDS >= 5 * (ADV_TILE + 2 * ADV_HALO), "an interior tile fits the same array");
 
 // synchronize + advance in ONE launch: workgroup 0 runs synchronize and then advances the cells it touched (and their
@@ -63,8 +63,7 @@ __global__ __launch_bounds__(ADV_TILE) void k_sync_advance(SyncArgs sa, AdvArgs 
     // (the policy's counters leave from the last workgroup: off the synchronize workgroup's longer chain where there is another)
     if (pub.n && blockIdx.x == gridDim.x - 1) publish_counters(pub);
     if (blockIdx.x == 0) {
-        synchronize_body(sa);
-        advance_edges(a, lds);
+        sync_advance_edges(sa, a, lds);
     } else {
         advance_interior(a, (int)blockIdx.x - 1, lds);
     }

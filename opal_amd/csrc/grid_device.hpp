@@ -72,25 +72,17 @@ constexpr int ADV_HALO = 2;  // halo cells recomputed on each side of a tile
 // (5 x (T + 4) doubles), runs the three sub-steps there and writes its tile to the other field buffer.  The array
 // ends follow the reference loops: B is not advanced in the last cell, cell 0 gets the Silver-Mueller update.
 // Contains workgroup barriers: every thread of the workgroup must call it (groups with nothing to do pass e <= s).
+// The three sub-steps and the write-out, for a tile that is in LDS already (rows of T + 4 doubles).  Bx: the tile's row of
+// it, or null = taken from the source buffer as it is.
 template <int T>
-__device__ inline void advance_tile(const AdvArgs &a, int s, int e, int t, double *lds)
+__device__ inline void advance_tile_steps(const AdvArgs &a, int s, int e, int t, double *Ex, double *Ey, double *Ez, double *By,
+                                          double *Bz, const double *Bx)
 {
     constexpr int FH = ADV_HALO, FW = T + 2 * FH;
-    double *Ex = lds, *Ey = lds + FW, *Ez = lds + 2 * FW, *By = lds + 3 * FW, *Bz = lds + 4 * FW;
     const size_t lenp = a.lenp;
     const int len = a.len;
     const double dt = a.dt, dx = a.dx;
     const bool work = e > s;
-    if (work)
-        for (int k = t; k < FW; k += T) {
-            int i = s - FH + k;
-            bool in = i >= 0 && i < len;
-            Ex[k] = in ? a.src[0 * lenp + i] : 0.0;
-            Ey[k] = in ? a.src[1 * lenp + i] : 0.0;
-            Ez[k] = in ? a.src[2 * lenp + i] : 0.0;
-            By[k] = in ? a.src[4 * lenp + i] : 0.0;
-            Bz[k] = in ? a.src[5 * lenp + i] : 0.0;
-        }
     // (the currents the E step needs are requested now, so that their latency overlaps the B half step)
     double jx0 = 0.0, jy0 = 0.0, jz0 = 0.0, jx1 = 0.0, jy1 = 0.0, jz1 = 0.0;
     {
@@ -141,7 +133,7 @@ __device__ inline void advance_tile(const AdvArgs &a, int s, int e, int t, doubl
             a.dst[0 * lenp + i] = Ex[k];
             a.dst[1 * lenp + i] = Ey[k];
             a.dst[2 * lenp + i] = Ez[k];
-            a.dst[3 * lenp + i] = a.src[3 * lenp + i];  // Bx: "nothing happens to Bx in 1D" (yee.rs:844)
+            a.dst[3 * lenp + i] = Bx ? Bx[k] : a.src[3 * lenp + i];  // "nothing happens to Bx in 1D" (yee.rs:844)
             a.dst[4 * lenp + i] = by;
             a.dst[5 * lenp + i] = bz;
             // YeeGrid::clear (yee.rs:543-549) for the next step, done on the spare current buffer: nobody
@@ -154,16 +146,27 @@ __device__ inline void advance_tile(const AdvArgs &a, int s, int e, int t, doubl
     }
 }
 
-// what the workgroup that runs synchronize (1024 threads) does next: the two ends of the grid, half its threads each
-__device__ inline void advance_edges(const AdvArgs &a, double *lds /* 2 x 5 x (ADV_EDGE + 4) doubles */)
+template <int T>
+__device__ inline void advance_tile(const AdvArgs &a, int s, int e, int t, double *lds)
 {
-    const int half = threadIdx.x >> 9, t = threadIdx.x & (ADV_EDGE - 1);
-    const int s = half ? a.len - a.edge_right : 0;
-    const int e = half ? a.len : a.edge_left;
-    __syncthreads();  // synchronize's writes are done
-    advance_tile<ADV_EDGE>(a, s, e, t, lds + half * 5 * (ADV_EDGE + 2 * ADV_HALO));
+    constexpr int FH = ADV_HALO, FW = T + 2 * FH;
+    double *Ex = lds, *Ey = lds + FW, *Ez = lds + 2 * FW, *By = lds + 3 * FW, *Bz = lds + 4 * FW;
+    const size_t lenp = a.lenp;
+    const int len = a.len;
+    if (e > s)
+        for (int k = t; k < FW; k += T) {
+            int i = s - FH + k;
+            bool in = i >= 0 && i < len;
+            Ex[k] = in ? a.src[0 * lenp + i] : 0.0;
+            Ey[k] = in ? a.src[1 * lenp + i] : 0.0;
+            Ez[k] = in ? a.src[2 * lenp + i] : 0.0;
+            By[k] = in ? a.src[4 * lenp + i] : 0.0;
+            Bz[k] = in ? a.src[5 * lenp + i] : 0.0;
+        }
+    advance_tile_steps<T>(a, s, e, t, Ex, Ey, Ez, By, Bz, nullptr);  // (begins with a barrier)
 }
-// ... and an interior workgroup (ADV_TILE threads): tile number `tile` between the edges
+
+// an interior workgroup (ADV_TILE threads): tile number `tile` between the edges (the edges: sync_advance_edges below)
 __device__ inline void advance_interior(const AdvArgs &a, int tile, double *lds /* 5 x (ADV_TILE + 4) doubles */)
 {
     advance_tile<ADV_TILE>(a, a.edge_left + tile * ADV_TILE, a.len - a.edge_right, threadIdx.x, lds);
@@ -247,6 +250,115 @@ __device__ inline void synchronize_body(const SyncArgs &a)
             a.eb[5 * a.lenp + start + i] = -a.eb[5 * a.lenp + start - i];
         }
     }
+}
+
+// synchronize followed by the field solve of the cells it touches, by ONE workgroup of 1024 threads that does both
+// (k_sync_advance's first workgroup, k_link_tail's): the same results as synchronize_body + advance_edges, with what
+// synchronize does to E and B done in LDS.  Those values exist for one purpose -- the field solve that follows reads them
+// and writes the OTHER field buffer -- so they need never reach memory; what synchronize adds to the currents and the
+// charge density does (write_data reads them).  The workgroup's chain becomes: the neighbours' halo and both edge tiles
+// (one round trip to memory), the currents' halo cells (written, then read by the E step: a second), the solve -- where
+// synchronize_body + advance_edges went four times (halo, overlay, absorber read-modify-write, tiles).
+__device__ inline void sync_advance_edges(const SyncArgs &sa, const AdvArgs &a, double *lds /* 2 x 6 x (ADV_EDGE + 4) doubles */)
+{
+    constexpr int T = ADV_EDGE, FH = ADV_HALO, FW = T + 2 * FH;
+    const int tid = threadIdx.x, half = tid >> 9, t = tid & (T - 1);
+    const int s_of[2] = {0, a.len - a.edge_right};
+    const int s = s_of[half], e = half ? a.len : a.edge_left;
+    const size_t lenp = a.lenp;
+    const int len = a.len;
+    // (i) what the neighbours sent -- or, alone on a periodic domain, this grid's own other end: yee.rs:424-452
+    int side = tid / HALO_DOUBLES, r = tid % HALO_DOUBLES;
+    int k = r / HALO_COMPS, comp = r % HALO_COMPS;
+    bool active = false;
+    double v = 0.0;
+    if (tid < 2 * HALO_DOUBLES) {
+        if (sa.self_periodic) {
+            int src = side == 0 ? len - HALO_CELLS + k : k;
+            v = comp == 0 ? sa.jr[3 * lenp + src]
+                : comp < 4 ? sa.jr[(size_t)(comp - 1) * lenp + src]
+                           : sa.eb[(size_t)(comp - 4) * lenp + src];
+            active = true;
+        } else {
+            const double *recv = side == 0 ? sa.recv_left : sa.recv_right;
+            if (recv) {
+                v = recv[r];
+                active = true;
+            }
+        }
+    }
+    // this half's tile of E and B (all six: synchronize's overlay, absorber and mirror act on Bx too) as memory has them
+    double *tile = lds + half * 6 * FW;
+    if (e > s)
+        for (int q = t; q < FW; q += T) {
+            int i = s - FH + q;
+            bool in = i >= 0 && i < len;
+#pragma unroll
+            for (int c = 0; c < 6; c++) tile[c * FW + q] = in ? a.src[(size_t)c * lenp + i] : 0.0;
+        }
+    __syncthreads();  // every value a lane adds below was read before anybody writes; the tiles are there
+    // Where cell i stands in the tiles: in one of them, or -- within two cells of where they meet on a grid too short to
+    // have an interior -- in both (each tile carries a two-cell halo): both copies hold the same value and get the same
+    // treatment.
+    const int e_of[2] = {a.edge_left, len};
+    auto in_tiles = [&](int i, auto &&f) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int q = i - s_of[h] + FH;
+            if (e_of[h] > s_of[h] && q >= 0 && q < FW) f(lds + h * 6 * FW + q);
+        }
+    };
+    if (active) {
+        int cellidx = side == 0 ? k : len - HALO_CELLS + k;
+        bool ghost = side == 0 ? (k < GHOST_SIZE) : (k >= GHOST_SIZE);
+        if (comp == 0) sa.jr[3 * lenp + cellidx] += v;                               // Cell::overlay, yee.rs:97-113
+        else if (comp < 4) sa.jr[(size_t)(comp - 1) * lenp + cellidx] += v;
+        else if (ghost) in_tiles(cellidx, [&](double *cell) { cell[(comp - 4) * FW] = v; });  // Cell::overlay_ghost
+    }
+    // (ii) laser, yee.rs:456-462 (a laser boundary has no neighbour on that side: the cell is nobody's ghost)
+    if (sa.left_bdy == OPAL_BDY_LASER && tid == 0)
+        in_tiles(sa.L - 2, [&](double *cell) {
+            cell[1 * FW] += sa.laser_y;
+            cell[2 * FW] += sa.laser_z;
+        });
+    // (iii) absorbing layer, yee.rs:464-479 / conducting wall, :480-495 (likewise: no neighbour on that side)
+    if (sa.right_bdy == OPAL_BDY_ABSORBING) {
+        int first = len - sa.R + 1;
+        for (int i = first + tid; i < len; i += blockDim.x) {
+            double f = sa.damp[i - first];
+            bool zero = i >= len - 2;
+            in_tiles(i, [&](double *cell) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double w = f * cell[c * FW];
+                    cell[c * FW] = zero ? 0.0 : w;
+                }
+            });
+        }
+    } else if (sa.right_bdy == OPAL_BDY_CONDUCTING) {
+        // (the wall's R = 4 cells and the R - 1 below it that they mirror lie in the right tile proper, which is at least
+        // 8 cells long, and outside the left tile's halo)
+        double *right = lds + 6 * FW;
+        int q0 = len - sa.R - s_of[1] + FH;  // the wall's cell in the tile
+        // every source is at or below the wall's cell, every destination above it: the wall's own cell first
+        if (tid == 0) {
+            right[0 * FW + q0] = 0.0;
+            right[4 * FW + q0] = 0.0;
+            right[5 * FW + q0] = 0.0;
+        }
+        __syncthreads();
+        if (tid >= 1 && tid < sa.R) {
+            int i = tid;
+            right[0 * FW + q0 + i] = -right[0 * FW + q0 - i];
+            right[1 * FW + q0 + i] = right[1 * FW + q0 + 1 - i];
+            right[2 * FW + q0 + i] = right[2 * FW + q0 + 1 - i];
+            right[3 * FW + q0 + i] = right[3 * FW + q0 + 1 - i];
+            right[4 * FW + q0 + i] = -right[4 * FW + q0 - i];
+            right[5 * FW + q0 + i] = -right[5 * FW + q0 - i];
+        }
+    }
+    __syncthreads();  // the currents' halo cells are written: the E step's loads below see them
+    advance_tile_steps<T>(a, s, e, t, tile, tile + FW, tile + 2 * FW, tile + 4 * FW, tile + 5 * FW, tile + 3 * FW);
 }
 #endif
 }  // namespace opal

@@ -1344,7 +1344,7 @@ template <int NT, bool ADV>
 __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
 {
     static_assert(!ADV || NT == ADV_TILE, "the field solve's workgroups are ADV_TILE threads");
-    __shared__ double s_adv[ADV ? 2 * 5 * (ADV_EDGE + 2 * ADV_HALO) : 1];
+    __shared__ double s_adv[ADV ? 2 * 6 * (ADV_EDGE + 2 * ADV_HALO) : 1];
     const unsigned parts = (unsigned)b.parts;
     const unsigned n_unpack = b.n ? 2u * (unsigned)b.n * parts : 1u;
     if (ADV && blockIdx.x > n_unpack) {
@@ -1409,8 +1409,10 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
         }
     }
     if (blockIdx.x >= n_unpack) {  // (only launched when has_sync)
-        synchronize_body(b.sync);
-        if (ADV && b.has_adv) advance_edges(b.adv, s_adv);  // the cells synchronize wrote, and their stencil neighbours
+        // (with the field solve in this launch: synchronize and the solve of the cells it touches, and of their stencil
+        // neighbours, as one -- grid_device.hpp)
+        if (ADV && b.has_adv) sync_advance_edges(b.sync, b.adv, s_adv);
+        else synchronize_body(b.sync);
         return;
     }
     if (b.n) unpack_one(b.a[pair >> 1], (int)(pair & 1u), part, parts, b.first_slot ? b.first_slot + pair : nullptr, b.peer.seq);
