@@ -430,6 +430,93 @@ def cpu_baseline(oa, cells, npc, target_seconds=14.0):
     }
 
 
+LIVE_TRAFFIC = {}  # "<workload_key>|<kernel instantiation>" -> what measure_traffic_live() found on THIS box, in THIS run
+
+
+def measure_traffic_live(argv, deadline_s=150.0):
+    """HBM bytes per launch of the push kernels, measured on the box this run is on, before the run itself touches the
+    GPU: two child processes, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, as
+    MI355X_MICROARCH.md prescribes; the program after `--` is python3 itself), each a 5-step run of this very command
+    with the side blocks off.  Counters cannot be read from inside the process, and a constant from profiles/ says
+    nothing about the box the driver landed on -- boxes differ by a few per cent in clock, not in bytes, which is the
+    point of measuring it: `roofline.traffic` then comes from the same silicon as `ms_per_step`.
+    Returns a note for the line; fills LIVE_TRAFFIC.  Every failure (no rocprofv3, a refused profiler, a time-out) is a
+    note and nothing else: bench.py then falls back to profiles/traffic.json, labelled as such."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return "live PMC passes skipped: no rocprofv3 on this box"
+    drop_with_value = {"--steps", "--warmup", "--gpus"}
+    child_args, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in drop_with_value:
+            skip = True
+            continue
+        if a.split("=")[0] in drop_with_value:
+            continue
+        child_args.append(a)
+    child_args += ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-laser-plasma",
+                   "--no-colliding-beams", "--no-live-traffic"]
+    push = re.compile(r"k_push(?:_pair)?<[^>]*>")
+    tmp = tempfile.mkdtemp(prefix="opal_pmc_")
+    env = dict(os.environ, TMPDIR=tmp, OPAL_BENCH_PMC_CHILD="1")
+    found, lines = {}, {}
+    t0 = time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--kernel-include-regex", "k_push", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "c",
+                   "--", sys.executable, os.path.abspath(__file__)] + child_args
+            left = deadline_s - (time.time() - t0)
+            if left < 20.0:
+                return f"live PMC passes gave up: {counter} pass not started, {deadline_s:.0f} s budget spent"
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=left)
+            if r.returncode != 0:
+                return f"live PMC passes failed: the {counter} pass exited with status {r.returncode}"
+            for ln in reversed(r.stdout.decode(errors="replace").strip().splitlines()):
+                if ln.startswith("{"):
+                    lines[counter] = json.loads(ln)
+                    break
+            path = None
+            for root, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(root, f)
+            if path is None or counter not in lines:
+                return f"live PMC passes failed: the {counter} pass left no counter file"
+            acc = {}
+            for row in csv.DictReader(open(path)):
+                m = push.search(row["Kernel_Name"])
+                if m and row["Counter_Name"] == counter:
+                    acc.setdefault(m.group(0), []).append(float(row["Counter_Value"]))
+            found[counter] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    except subprocess.TimeoutExpired:
+        return f"live PMC passes gave up: a pass ran into the {deadline_s:.0f} s budget"
+    except Exception as e:  # a profiler that is not allowed here, a changed file layout ...: never the run's problem
+        return f"live PMC passes failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    cfg = lines["FETCH_SIZE"]["config"]
+    wkey, n = cfg["workload_key"], cfg["particles_total"]
+    for k in sorted(set(found["FETCH_SIZE"]) & set(found["WRITE_SIZE"])):
+        # KiB; gfx950: FETCH_SIZE counts half of a coalesced streaming read, WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM)
+        rd = 2.0 * found["FETCH_SIZE"][k][0] * 1024.0
+        wr = found["WRITE_SIZE"][k][0] * 1024.0
+        LIVE_TRAFFIC[f"{wkey}|{k}"] = {"hbm_bytes_per_particle_update": (rd + wr) / n, "read": rd / n, "write": wr / n,
+                                       "launches": [found["FETCH_SIZE"][k][1], found["WRITE_SIZE"][k][1]]}
+    return (f"live PMC passes: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two 5-step runs of this command on this box "
+            f"before the timed run ({time.time() - t0:.0f} s): " +
+            "; ".join(f"{k.split('|')[1]} {v['hbm_bytes_per_particle_update']:.1f} B/update" for k, v in sorted(LIVE_TRAFFIC.items())))
+
+
 def launch_ranks(n, argv):
     """Parent of a self-launched N-rank run.  Makes no GPU call (imports neither torch nor the library)."""
     import socket
@@ -499,7 +586,17 @@ def main():
     ap.add_argument("--self-exchange", action="store_true",
                     help="N=1 rehearsal of the multi-GPU step: the lone periodic subdomain sends its halo and leavers "
                          "to itself through RCCL (pack kernels, RCCL send/recv, unpack) instead of wrapping in place")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic on this box (N = 1)")
     args = ap.parse_args()
+
+    # roofline.traffic from THIS box: two short child runs under rocprofv3's counters, before this process touches the GPU
+    live_note = None
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_live_traffic and not under_profiler
+            and not os.environ.get("OPAL_BENCH_PMC_CHILD") and not args.unfused and not args.self_exchange):
+        live_note = measure_traffic_live(sys.argv[1:])
+        print("[bench] " + live_note, file=sys.stderr)
 
     if args.no_elision:
         args.elision, args.no_default_path = "off", True
@@ -718,7 +815,24 @@ def main():
             tj = json.load(open(tpath)).get(f"{workload_key}|{roof['kernel']}") if os.path.exists(tpath) else None
         except Exception:
             tj = None
-        if tj is None:
+        live = LIVE_TRAFFIC.get(f"{workload_key}|{roof['kernel']}")
+        if live is not None:
+            # measured minutes ago on this very box (measure_traffic_live): the committed constant is only the cross-check
+            roof["traffic"] = live["hbm_bytes_per_particle_update"] * per_launch
+            roof["traffic_source"] = ("measured by this run on this box: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate "
+                                      f"5-step passes of this command before the timed run ({live['launches'][0]} / "
+                                      f"{live['launches'][1]} launches of this kernel counted; FETCH_SIZE doubled as the gfx950 guide prescribes)")
+            roof["traffic_bytes_per_update"] = live["hbm_bytes_per_particle_update"]
+            roof["traffic_read_write_bytes_per_update"] = [live["read"], live["write"]]
+            if tj is not None and tj.get("src_sha") == src_sha():
+                roof["traffic_committed_bytes_per_update"] = tj["hbm_bytes_per_particle_update"]  # (profiles/traffic.json)
+            roof["traffic_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 if launches else None
+            roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS if launches else None
+            roof["frac_physical"] = roof["frac_traffic"]
+            roof["traffic_note"] = ("bytes that crossed the HBM interface per launch; below the algorithmic bytes where the "
+                                    "write-back of attributes no lane of a wave changed (uy, uz, most cell indices in an "
+                                    "electrostatic run) is skipped")
+        elif tj is None:
             roof["traffic_note"] = f"no PMC entry for {workload_key}|{roof['kernel']} in profiles/traffic.json"
         elif tj.get("src_sha") != src_sha():
             roof["traffic_note"] = (f"profiles/traffic.json entry for {workload_key}|{roof['kernel']} is stale (kernel "
@@ -981,6 +1095,7 @@ def main():
                 "gpus_seen": gpus_seen,
                 "ranks": ranks_seen,
                 "frac_of_hbm_roofline_whole_step": m["frac_of_hbm_roofline_whole_step"],
+                "traffic_live": live_note,
             },
             "roofline": m["roofline"],
         }

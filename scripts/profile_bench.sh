@@ -11,7 +11,7 @@ shift
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--no-cpu-baseline --no-secondary $*"
+ARGS="--no-cpu-baseline --no-secondary --no-live-traffic $*"
 echo "$ARGS" > $O/args.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/bench_under_kt.json 2> $O/kt.log
 echo "kernel-trace done"

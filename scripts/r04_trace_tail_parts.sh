@@ -7,7 +7,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 for at in 2000000000 1; do
-  OPAL_BENCH_HOT=1.0 OPAL_TAIL_PARTS_AT=$at OPAL_BENCH_LINK=peer rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$at -o kt -- python3 $R/bench.py --self-exchange --cells 512 --npc 20000 --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --no-default-path > $O/bench_$at.json 2> $O/log_$at.txt
+  OPAL_BENCH_HOT=1.0 OPAL_TAIL_PARTS_AT=$at OPAL_BENCH_LINK=peer rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$at -o kt -- python3 $R/bench.py --self-exchange --cells 512 --npc 20000 --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --no-default-path --no-live-traffic > $O/bench_$at.json 2> $O/log_$at.txt
   echo "== OPAL_TAIL_PARTS_AT=$at" >> $O/summary.txt
   python3 - $O/kt_$at >> $O/summary.txt <<'PY'
 import csv, glob, sys

@@ -8,7 +8,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 for LINK in peer rccl; do
-  OPAL_BENCH_LINK=$LINK rocprofv3 --kernel-trace --output-format csv -d $O/$LINK -o kt -- python3 $R/bench.py --self-exchange --elision on --cells 4096 --npc 1526 --no-cpu-baseline --no-secondary --steps 400 --warmup 20 > $O/bench_$LINK.json 2> $O/$LINK.log
+  OPAL_BENCH_LINK=$LINK rocprofv3 --kernel-trace --output-format csv -d $O/$LINK -o kt -- python3 $R/bench.py --self-exchange --elision on --cells 4096 --npc 1526 --no-cpu-baseline --no-secondary --no-live-traffic --steps 400 --warmup 20 > $O/bench_$LINK.json 2> $O/$LINK.log
   python3 $R/scripts/step_timeline.py $O/$LINK 2 20 > $O/timeline_$LINK.txt
   rm -rf $O/$LINK
 done
