@@ -20,8 +20,11 @@ streams uy/uz nor the uniform weight, and gives the same bits) is measured besid
 region (`bytes_model`; the library reports the form of each launch, opal_prof_forms), so `frac` <= 1 by construction and
 `algorithmic_GBps_over_whole_step` <= 8000.  The kernel's mean duration is measured with HIP events on the
 simulation's stream around a 1-in-5 sample of its launches in the timed region; `traffic` is the PMC-measured HBM bytes
-per launch from profiles/traffic.json, used only if that entry was taken for this workload, this kernel instantiation
-and these kernel sources: `roofline.frac` prices a launch with the form's ALGORITHMIC bytes, `roofline.frac_physical` with the
+per launch -- measured ON THE BOX THE RUN IS ON at N = 1: before this process touches the GPU it runs two 5-step child
+copies of its own command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (measure_traffic_live, ~30 s; the
+top level's kernel and `default_path`'s); for the other blocks, or where the passes cannot run (`config.traffic_live` says
+why), the constant from profiles/traffic.json, used only if that entry was taken for this workload, this kernel instantiation
+and these kernel sources.  `roofline.frac` prices a launch with the form's ALGORITHMIC bytes, `roofline.frac_physical` with the
 bytes that crossed the HBM interface (an attribute no lane of a wave changed is not written back: fewer than 80).  A `--steps`
 below 200 is followed by a second timed region of 200 steps (`steps_long`).  At N = 1 the line also carries configs[1]
 (`secondary`), configs[3]'s physics inside the laser-plasma interaction (`laser_plasma_interaction`) and configs[4]
