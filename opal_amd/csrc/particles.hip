@@ -91,6 +91,7 @@ int pop_max_ppt(const opal_pop_t *p)
 }
 enum { EDGE_WRAP = 0, EDGE_DELETE = 1, EDGE_SEND = 2 };
 
+constexpr int ROTATE_BELOW = 96;  // steps between two re-binnings (two-stream: hundreds; the laser-plasma electrons: ~20, its ions: ~55)
 struct PushArgs {
     int *cell;
     double *x, *ux, *uy, *uz;
@@ -118,6 +119,7 @@ struct PushArgs {
     // the rest uniform chunks of BLOCK x ppt slots from ctr->n_sorted on.  n_tab = 0: uniform chunks throughout.
     const unsigned *tab_slot;
     unsigned n_tab;
+    int rotate;  // the waves of a workgroup start a quarter of their chunk apart (push_body: slot_of)
     int tail_sides;  // 2: the chunks behind the sorted slots are each taken by two workgroups (see push_body)
     int w_uniform;  // every slot's weight is w0 unless ctr->w_mixed says otherwise (opal_pop::w_uniform)
     double w0;
@@ -459,7 +461,22 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         sl.prev = (MODE == MODE_DEPOSIT) ? ldk(cp.prev, kk) : 0.0;
         return sl;
     };
-    unsigned k = tid;
+    // The order of the loop below: iteration p of a thread takes slot_of(p).  In a chunk of the table the four waves start
+    // a quarter of the chunk apart (and wrap round), so that the FIRST slots -- which place the tile -- are 64 from each
+    // quarter.  A re-binning leaves the particles of a cell in the order its workgroups got there, which follows the slots
+    // they came from: those that moved up into the cell first, those that moved down last.  The first 256 slots of a chunk
+    // are therefore its up-movers, and a tile centred on them loses the down-movers at its low end a few steps early
+    // (laser-plasma run: cell - tile base = 2 at the first misses; looking at both ends of every chunk re-binned 135 times
+    // per 2000 steps instead of 141, scripts/r04_ab_lib_variants_lp.sh).  No load is added: the sample is the first iteration.
+    // (Only for a population whose re-binnings come in quick succession -- a hot one, build_args: four runs of 64 slots a
+    // quarter of the chunk apart instead of 256 consecutive ones cost the two-stream contract run 1 % and gave it nothing.)
+    const int rot = (tabled && a.rotate) ? __builtin_amdgcn_readfirstlane(tid >> 6) * (iters >> 2) : 0;  // wave-uniform (a scalar); < iters
+    auto slot_of = [&](int p) {
+        int q = p + rot;
+        q -= q >= iters ? iters : 0;
+        return (unsigned)q * BLOCK + (unsigned)tid;
+    };
+    unsigned k = slot_of(0);
     Slot s_n = fetch(min(k, last));
     bool have_n = k < nloc;
     int c_n = have_n ? s_n.c : DEAD_CELL;
@@ -574,8 +591,8 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         const int c_mem = c;
         const double xi = s_n.x, wt = s_n.w, prev = s_n.prev;
         const V3 u = {s_n.ux, s_n.uy, s_n.uz};
-        k += BLOCK;
         if (p + 1 < iters) {  // block-uniform; one slot per lane in flight (two measured 1.5 % slower)
+            k = slot_of(p + 1);
             s_n = fetch(min(k, last));
             have_n = k < nloc;
         }
@@ -622,7 +639,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         // the same side either way, or as DEAD_CELL if it has just left through that end)
         for (int p = 0; p < iters; p++) {
             if (!(pending & (1u << p))) continue;
-            const int c = cp.cell[(unsigned)p * BLOCK + tid];
+            const int c = cp.cell[slot_of(p)];
             if (c == DEAD_CELL || (c >= (a.size >> 1)) != (my_half == 1)) pending &= ~(1u << p);
         }
     }
@@ -636,7 +653,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         if (pending) {
             for (int p = 0; p < iters; p++) {
                 if (!(pending & (1u << p))) continue;
-                unsigned kc = (unsigned)p * BLOCK + tid;
+                unsigned kc = slot_of(p);
                 V3 u = {cp.ux[kc], cp.uy[kc], cp.uz[kc]};
                 double prev = (MODE == MODE_DEPOSIT) ? cp.prev[kc] : 0.0;
                 const int cm = cp.cell[kc];
@@ -687,7 +704,7 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
             __syncthreads();
             unsigned at = s_base[0] + before + incl - mine;
             for (int p = 0; p < iters; p++)
-                if (emit_mask & (1u << p)) a.emit_list[at++] = (unsigned)(chunk0 + (size_t)p * BLOCK + tid);
+                if (emit_mask & (1u << p)) a.emit_list[at++] = (unsigned)(chunk0 + slot_of(p));
         }
     }
 
@@ -1777,6 +1794,8 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     a.dbg = p->d_dbg;
     a.tab_slot = p->d_tab_slot;
     a.n_tab = p->n_tab;
+    // a population re-binned again within ROTATE_BELOW steps is hot: its chunks' first slots are not a fair sample (push_body)
+    a.rotate = p->last_interval > 0 && p->last_interval < ROTATE_BELOW;
     const size_t behind = p->n_upper > p->n_sorted ? p->n_upper - p->n_sorted : 0;  // appended since the re-binning
     // arrivals from both neighbours behind a sorted population: two workgroups per chunk of them (push_body)
     // (safe while no arrival can have reached the middle of the subdomain: less than a cell per step since the last
@@ -2206,6 +2225,7 @@ int do_sort(opal_pop_t *p, const opal_grid_t *g, bool wait)
         p->preempt_at = std::max(4, p->last_onset - 1);
     p->miss_onset = 0;
     p->last_onset = p->last_trigger = 0;
+    p->last_interval = p->steps_since_sort;
     p->steps_since_sort = 0;
     p->emit_list_valid = false;  // slots moved
     p->sorted_exact = true;
@@ -2535,6 +2555,7 @@ int opal_pop_upload_soa(opal_pop_t *p, size_t n, const int32_t *cell, const doub
     p->miss_onset = p->last_onset = p->last_trigger = p->preempt_at = 0;
     p->added_since_snapshot = 0;
     p->steps_since_sort = 0;
+    p->last_interval = 0;
     p->emit_list_valid = false;
     p->sorted_exact = false;
     p->dead_cost = 0.0;
