@@ -512,3 +512,43 @@ def test_extras_survive_rebinning(oa, oracle):
     for k in ("chi", "work", "y", "z"):
         scale = np.max(np.abs(rex[k]))
         assert np.max(np.abs(ex[k][order] - rex[k][rorder])) <= 1e-10 * scale, k
+
+
+def test_rebinning_of_a_nearly_ordered_population_keeps_every_particle_whole(oa):
+    """The re-binning as a run meets it (particles.hip: k_sort_hist, k_sort_scan, k_sort_scatter_staged): slots sorted for a
+    cell their particle has since drifted up to 13 cells from (a wave holds ~20 distinct cells: counts and ranks in the LDS
+    window, the scatter staged through LDS), cold cells that fill whole chunks (every lane of a wave in ONE cell: the wave's
+    shared increment), cells thousands of particles deep, a few hundred far-away cells (wrapped particles: outside the window,
+    straight to their slot), prev_x and the emission state (tau, id) carried.  Every particle must come out with all of its
+    attributes, in cell order."""
+    nx, dx = 4096, 1.0e-8
+    dt = 0.95 * dx / C
+    rng = np.random.default_rng(123)
+    g = oa.Grid.single(nx, 0.0, dx)
+    hot_home = np.repeat(np.arange(1000, 2000, dtype=np.int64), 60)                  # 60 000 hot particles
+    hot = hot_home + rng.integers(-13, 14, len(hot_home))
+    cold = np.repeat(np.arange(2500, 2600, dtype=np.int64), 300)                     # 30 000 cold ones: 300 per cell
+    deep = np.repeat(np.array([3000, 3001], dtype=np.int64), 5000)                   # two cells 5000 deep (several chunks each)
+    cell = np.concatenate([hot, cold, deep])
+    far = rng.choice(len(cell), 300, replace=False)
+    cell[far] = rng.integers(0, nx, 300)                                             # strays anywhere
+    n = len(cell)
+    x = rng.random(n)
+    u = rng.standard_normal((3, n))
+    w = 1.0e3 * (1.0 + np.arange(n) * 1e-9)
+    p = oa.Population(oa.ELECTRON, n + 4096)
+    p.track_extras(2)
+    p.upload(cell.astype(np.int32), x, u[0], u[1], u[2], w, dx, dt)
+    tau = rng.random(n)
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(7919)) ^ np.uint64(0xABCDEF)
+    p.set_emission_state(tau, ids)
+    before = p.soa(prev_x=True)
+    p.sort(g)
+    after = p.soa(prev_x=True)
+    t_after, i_after = p.emission_state()
+    assert len(after["w"]) == n and np.all(np.diff(after["cell"]) >= 0)
+    assert np.array_equal(np.bincount(after["cell"], minlength=nx), np.bincount(cell, minlength=nx))
+    order = np.argsort(after["w"], kind="stable")
+    for k in ("cell", "x", "ux", "uy", "uz", "w", "prev_x"):
+        assert np.array_equal(after[k][order], before[k]), k   # (uploaded in w order: `before` is already by identity)
+    assert np.array_equal(t_after[order], tau) and np.array_equal(i_after[order], ids)
