@@ -31,3 +31,20 @@ for a, b in steps[-nshow:]:
     for i in range(a, b):
         s, e, n = rows[i]
         print(f"    {(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f}  {n}")
+# gaps between the launches of a step, over the last 400 steps: where the GPU waits for its next kernel
+import collections
+gaps = collections.defaultdict(list)
+for idx, (a, b) in enumerate(steps[-400:]):
+    for i in range(a, b):
+        nxt = rows[i + 1]
+        gaps[f"{rows[i][2][:24]} -> {nxt[2][:24]}"].append(((nxt[0] - rows[i][1]) / 1e3, idx))
+print("  gaps between consecutive kernels over the last 400 steps (us): mean, median, p90, share of steps with a gap > 2 us; mean gap by step index mod 4")
+for k, v in sorted(gaps.items()):
+    g = sorted(x for x, _ in v)
+    by = [0.0] * 4
+    cnt = [0] * 4
+    for x, i in v:
+        by[i % 4] += x
+        cnt[i % 4] += 1
+    print(f"    {k:52s} {sum(g) / len(g):6.2f} {g[len(g) // 2]:6.2f} {g[int(0.9 * len(g))]:6.2f}  {sum(1 for x in g if x > 2.0) / len(g):5.2f}   "
+          + " ".join(f"{by[m] / max(cnt[m], 1):5.2f}" for m in range(4)))
