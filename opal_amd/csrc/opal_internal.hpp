@@ -170,6 +170,7 @@ struct opal_pop {
     unsigned int n_tab, n_sorted;
     bool sorted_count_pending; // the snapshot in flight (upper_event) carries the slot count a re-binning left: it is n_sorted
     unsigned int count_cells;  // d_count holds the cell ends of this many cells (set by a re-binning)
+    size_t added_since_pub;    // room reserved for arrivals since the policy's last publication was asked for (policy_step)
     int last_interval;         // steps between the last two re-binnings (0: none yet): short = a hot population (particles.hip: ROTATE_BELOW)
     bool want_host_maps;       // keep h_cell_end / h_tab_slot current (the overlapped step's edge / bulk split reads them):
                                // re-binnings then wait for the device

@@ -2014,6 +2014,7 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     p->sorted_exact = false;
     p->n_upper += incoming;
     p->added_since_snapshot += incoming;
+    p->added_since_pub += incoming;
     return OPAL_OK;
 }
 
@@ -2095,8 +2096,12 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
     if (zero_counts) link->counts_clean = true;
     // (only once the reservations since the last snapshot add up to a few per cent of the population: a
     // snapshot is a small copy on the stream, not worth having every step)
+    // (Not at all for a population under the adaptive re-binning policy: the counters that policy has published every other
+    // step -- by the very kernel launched above, into mapped host memory -- include the slot count, and policy_step takes the
+    // bound down with it.  The copy, its event and the packets round them cost the linked step ~2 us a step: round 4's trace.)
     for (int i = 0; i < npops; i++)
-        if (pops[i] && pops[i]->added_since_snapshot > pops[i]->n_upper / 32)
+        if (pops[i] && pops[i]->added_since_snapshot > pops[i]->n_upper / 32 &&
+            !(pops[i]->sort_interval < 0 && pops[i]->species != OPAL_PHOTON))
             if (int rc = opal::pop_snapshot_upper(pops[i], 0)) return rc;
     return OPAL_OK;
 }
@@ -2303,6 +2308,7 @@ int ask_publication(opal_pop_t *p)
     if (p->ctr_pending) return OPAL_OK;
     p->pub_seq++;
     p->ctr_pending = true;
+    p->added_since_pub = 0;  // (whatever is reserved from here on may or may not be in the slot count this publication carries)
     PublishBatch one{};
     PublishBatch &b = g_publish_scope ? g_publish_scope->b : one;
     if (g_publish_scope) {
@@ -2404,6 +2410,13 @@ int policy_step(opal_pop_t *p, bool &sort_now)
         fresh = true;
         p->h_ctr_seen = p->h_pub->c;
         p->ctr_pending = false;
+    }
+    if (fresh && p->species != OPAL_PHOTON) {
+        // the slot count of a check ago, and what has been reserved for arrivals since that publication was asked for: a
+        // bound on the slots in use now (arrivals are all that is ever appended to electrons and ions; a re-binning in
+        // between would have withdrawn the publication: sort_end)
+        const size_t bound = (size_t)p->h_ctr_seen.n_slots + p->added_since_pub;
+        if (bound < p->n_upper) p->n_upper = bound;
     }
     if (int rc = ask_publication(p)) return rc;
     if (!fresh) return OPAL_OK;
