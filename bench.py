@@ -481,10 +481,22 @@ def measure_traffic_live(argv, deadline_s=150.0):
             left = deadline_s - (time.time() - t0)
             if left < 20.0:
                 return f"live PMC passes gave up: {counter} pass not started, {deadline_s:.0f} s budget spent"
-            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=left)
-            if r.returncode != 0:
-                return f"live PMC passes failed: the {counter} pass exited with status {r.returncode}"
-            for ln in reversed(r.stdout.decode(errors="replace").strip().splitlines()):
+            # (its own process group: a pass that runs out of time is ended with everything it started -- the profiler AND
+            # the copy of this program under it, which would otherwise keep the card busy beside the timed run)
+            proc = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                stdout, _ = proc.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)  # exactly the group started above
+                except ProcessLookupError:
+                    pass
+                proc.wait()
+                raise
+            if proc.returncode != 0:
+                return f"live PMC passes failed: the {counter} pass exited with status {proc.returncode}"
+            for ln in reversed(stdout.decode(errors="replace").strip().splitlines()):
                 if ln.startswith("{"):
                     lines[counter] = json.loads(ln)
                     break
