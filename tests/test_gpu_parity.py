@@ -7,6 +7,7 @@ divisions by dt, dx and gamma, and summation order); N-step field parity 1e-9 ov
 (north_star asks 1e-6).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -552,3 +553,15 @@ def test_rebinning_of_a_nearly_ordered_population_keeps_every_particle_whole(oa)
     for k in ("cell", "x", "ux", "uy", "uz", "w", "prev_x"):
         assert np.array_equal(after[k][order], before[k]), k   # (uploaded in w order: `before` is already by identity)
     assert np.array_equal(t_after[order], tau) and np.array_equal(i_after[order], ids)
+
+
+def test_rebinning_with_the_scatter_straight_to_the_output(oa):
+    """OPAL_SORT_STAGED=0 keeps round 3's scatter (every lane stores to the run of its own cell) as the other leg of the A/B
+    in profiles/r04_ab/ab_sort_staged.txt; the switch is read once per process, so the same test runs in a child."""
+    import subprocess
+    import sys
+    env = dict(os.environ, OPAL_SORT_STAGED="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "nearly_ordered or without_changing_the_population or extras_survive"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
