@@ -244,6 +244,12 @@ def lp_link_capacity(npc):
     return int(os.environ.get("OPAL_BENCH_LP_CAPACITY") or max(4096, 20 * npc))
 
 
+def lp_fixed_capacity(npc):
+    """... and the room of a laser-plasma link that cannot grow (torch.distributed's: its buffers are torch tensors): the
+    worst pile-up measured at a cut, as rounds 2-3 sized every link."""
+    return int(os.environ.get("OPAL_BENCH_LP_CAPACITY") or max(65536, 128 * npc))
+
+
 def src_sha():
     """Hash of the kernel sources the PMC traffic figures were taken with (profiles/traffic.json records it):
     the code of the push and field kernels with comments and white space taken out."""
@@ -512,7 +518,9 @@ def measure_traffic_live(argv, deadline_s=150.0):
                 m = push.search(row["Kernel_Name"])
                 if m and row["Counter_Name"] == counter:
                     acc.setdefault(m.group(0), []).append(float(row["Counter_Value"]))
-            found[counter] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+            # (only the launches of the child's timed steps: the last 5 of each instantiation -- its pre-heat and warm-up
+            # launches run on arrays the loader has just written and alternate forms)
+            found[counter] = {k: (sum(v[-5:]) / len(v[-5:]), len(v[-5:])) for k, v in acc.items()}
     except subprocess.TimeoutExpired:
         return f"live PMC passes gave up: a pass ran into the {deadline_s:.0f} s budget"
     except Exception as e:  # a profiler that is not allowed here, a changed file layout ...: never the run's problem
@@ -525,7 +533,9 @@ def measure_traffic_live(argv, deadline_s=150.0):
         # KiB; gfx950: FETCH_SIZE counts half of a coalesced streaming read, WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM)
         rd = 2.0 * found["FETCH_SIZE"][k][0] * 1024.0
         wr = found["WRITE_SIZE"][k][0] * 1024.0
-        LIVE_TRAFFIC[f"{wkey}|{k}"] = {"hbm_bytes_per_particle_update": (rd + wr) / n, "read": rd / n, "write": wr / n,
+        # a single-species launch (k_push<species, ...>) covers one of the two equal species of the workload
+        n_cov = n / 2 if k.startswith("k_push<") else n
+        LIVE_TRAFFIC[f"{wkey}|{k}"] = {"hbm_bytes_per_particle_update": (rd + wr) / n_cov, "read": rd / n_cov, "write": wr / n_cov,
                                        "launches": [found["FETCH_SIZE"][k][1], found["WRITE_SIZE"][k][1]]}
     return (f"live PMC passes: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two 5-step runs of this command on this box "
             f"before the timed run ({time.time() - t0:.0f} s): " +
@@ -680,7 +690,8 @@ def main():
         order = {"peer": ("peer", "rccl", "torch"), "rccl": ("rccl", "torch"), "torch": ("torch",), "gloo": ("torch",)}[link_kind]
         link, link_kind = make_link(rank, world, link_device, link_capacity, stream=torch.cuda.current_stream().cuda_stream,
                                     to_left=not (lp_open and rank == 0), to_right=not (lp_open and rank == world - 1),
-                                    prefer=order, log=lambda m: print(m.replace("[opal_amd]", "[bench]"), file=sys.stderr))
+                                    prefer=order, log=lambda m: print(m.replace("[opal_amd]", "[bench]"), file=sys.stderr),
+                                    fixed_capacity=lp_fixed_capacity(npc) if lp_open else None)
         if link_kind == "rccl" and os.environ.get("OPAL_BENCH_FIXED"):  # diagnostic: ship all slots every step
             link.set_bounded(False)
     red_dev = "cuda" if backend == "nccl" else "cpu"
@@ -841,6 +852,11 @@ def main():
             roof["traffic_read_write_bytes_per_update"] = [live["read"], live["write"]]
             if tj is not None and tj.get("src_sha") == src_sha():
                 roof["traffic_committed_bytes_per_update"] = tj["hbm_bytes_per_particle_update"]  # (profiles/traffic.json)
+                rel = abs(live["hbm_bytes_per_particle_update"] / tj["hbm_bytes_per_particle_update"] - 1.0)
+                if rel > 0.03:
+                    roof["traffic_disagreement"] = (f"live and committed bytes per update differ by {100 * rel:.1f} %: the live "
+                                                    f"figure is used (same box as ms_per_step), the committed one is "
+                                                    f"{tj.get('source')}")
             roof["traffic_GBps"] = roof["traffic"] / (avg_ms * 1e-3) / 1e9 if launches else None
             roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS if launches else None
             roof["frac_physical"] = roof["frac_traffic"]
@@ -1200,7 +1216,7 @@ def main():
             nonlocal link
             link = None
             link3, kind3 = make_link(rank, world, link_device, lp_link_capacity(lp_npc), stream=stream, to_left=rank != 0,
-                                     to_right=rank != world - 1, prefer=order,
+                                     to_right=rank != world - 1, prefer=order, fixed_capacity=lp_fixed_capacity(lp_npc),
                                      log=lambda m_: print(m_.replace("[opal_amd]", "[bench]"), file=sys.stderr))
             if os.environ.get("OPAL_BENCH_LP_FAIL_RANK") == str(rank):  # (rehearsing the failure path)
                 raise RuntimeError("failure requested through OPAL_BENCH_LP_FAIL_RANK")

@@ -45,13 +45,16 @@ def main(argv):
             except oa.OpalError:
                 pass  # (the run itself will report a malformed section)
         cap = int(os.environ.get("OPAL_LINK_CAPACITY", str(max(4096, 20 * npc))))
+        # ... and a link that cannot grow (torch.distributed's, whose buffers are torch tensors) for the worst pile-up at a cut
+        # measured so far (hole boring: 47 x / 93 x the initial density in a cell), as rounds 2-3 sized every link
+        fixed = int(os.environ.get("OPAL_LINK_CAPACITY", str(max(65536, 128 * npc))))
         stream = torch.cuda.current_stream().cuda_stream
         open_ends = cfg.contains("laser")  # laser + absorbing boundaries: the first and last subdomain have one neighbour
         want = os.environ.get("OPAL_LINK")
         link, kind = make_link(rank, world, device if backend == "nccl" else torch.device("cpu"), cap, stream=stream,
                                photon_emission=emission, photon_absorption=absorption,
                                to_left=not (open_ends and rank == 0), to_right=not (open_ends and rank == world - 1),
-                               prefer=(want,) if want else ("peer", "rccl", "torch"))
+                               prefer=(want,) if want else ("peer", "rccl", "torch"), fixed_capacity=fixed)
         if rank == 0:
             print(f"Neighbour exchange: {kind}")
     try:

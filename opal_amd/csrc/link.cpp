@@ -111,7 +111,11 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     // and reserving the link's whole capacity every step would have a link sized for a pile-up (128 cells' worth of
     // particles) blow the host's bound on the slots in use up by millions per step.
     const bool sizes_messages = l->bounded && l->exchange2 && !link_is_peer(l);
-    if ((!sizes_messages && !link_is_peer(l)) || !l->h_bounds || l->nfields >= 15) return OPAL_OK;
+    // (a link that carries stimulated emission -- 15 fields -- ships every slot: several photons may copy themselves off one
+    // electron, so the count below is no bound for it.  It is still the best estimate of what stands near the cut, and an
+    // edge of such a link grows by it like any other instead of staying at its creation size through a pile-up.)
+    const bool every_slot = l->nfields >= 15;
+    if ((!sizes_messages && !link_is_peer(l) && !(every_slot && l->growable)) || !l->h_bounds) return OPAL_OK;
     if (X < (unsigned)LINK_ZONE) return OPAL_OK;
     unsigned need[2] = {0, 0};
     // (a peer link files every LINK_PEER_EVERY-th exchange only and counts LINK_PEER_ZONE cells: see link.hpp)
@@ -187,8 +191,8 @@ int link_plan(opal_link_t *l, unsigned species_mask)
         full[1] = (unsigned)l->cap_side[1];
     }
     for (int side = 0; side < 2; side++) {
-        l->plan_cap[side] = slots[side] < full[side] ? slots[side] : full[side];
-        l->send_cap[side] = sizes_messages ? l->plan_cap[side] : full[side];
+        l->plan_cap[side] = (slots[side] < full[side] && !every_slot) ? slots[side] : full[side];
+        l->send_cap[side] = (sizes_messages && !every_slot) ? l->plan_cap[side] : full[side];
     }
     return OPAL_OK;
 }
@@ -208,41 +212,62 @@ int link_grow(opal_link_t *l, const size_t new_cap_in[2])
                   "(opal_link_set_buffers)", new_cap[0] > new_cap[1] ? new_cap[0] : new_cap[1]);
         return OPAL_ERR_CAPACITY;
     }
+    if (l->peer && !link_is_peer(l)) {
+        // (the mailboxes of an unconnected peer link keep their creation stride, and opal_link_peer_connect takes the
+        // neighbours' offsets from it: buffers grown here would outrun them)
+        set_error("link: a peer link grows only once it is connected (opal_link_peer_connect)");
+        return OPAL_ERR_LINK;
+    }
     OPAL_HIP(hipDeviceSynchronize());  // nothing in flight reads or writes the buffers about to go
     void *state[2] = {nullptr, nullptr};
-    if (l->peer)  // every record is on its way before anybody waits for one (peer.hip)
-        for (int side = 0; side < 2; side++)
-            if (new_cap[side])
-                if (int rc = link_peer_grow_begin(l, side, new_cap[side], &state[side])) return rc;
-    for (int side = 0; side < 2; side++) {
-        if (!new_cap[side]) continue;
-        const size_t nb = link_prefix_bytes(l, (unsigned)new_cap[side]);
-        char **dev[2] = {side == 0 ? &l->d_send_left : &l->d_send_right, side == 0 ? &l->d_recv_left : &l->d_recv_right};
-        for (auto d : dev) {
-            char *fresh = nullptr;
-            OPAL_HIP(hipMalloc((void **)&fresh, nb));
-            OPAL_HIP(hipMemset(fresh, 0, nb));
-            // (the header of a send message carries the zone counts of the exchange before: kept)
-            OPAL_HIP(hipMemcpy(fresh, *d, LINK_HEAD_BYTES, hipMemcpyDeviceToDevice));
-            OPAL_HIP(hipFree(*d));
-            *d = fresh;
-        }
-        if (!l->device_buffers) {
-            char **host[2] = {side == 0 ? &l->h_send_left : &l->h_send_right, side == 0 ? &l->h_recv_left : &l->h_recv_right};
-            for (auto h : host) {
-                OPAL_HIP(hipHostFree(*h));
-                OPAL_HIP(hipHostMalloc((void **)h, nb));
-                memset(*h, 0, nb);
+    // whatever fails from here on, the mailboxes allocated for edges that did not finish growing are let go
+    auto body = [&]() -> int {
+        if (l->peer)  // every record is on its way before anybody waits for one (peer.hip)
+            for (int side = 0; side < 2; side++)
+                if (new_cap[side])
+                    if (int rc = link_peer_grow_begin(l, side, new_cap[side], &state[side])) return rc;
+        for (int side = 0; side < 2; side++) {
+            if (!new_cap[side]) continue;
+            const size_t nb = link_prefix_bytes(l, (unsigned)new_cap[side]);
+            char **dev[2] = {side == 0 ? &l->d_send_left : &l->d_send_right, side == 0 ? &l->d_recv_left : &l->d_recv_right};
+            for (auto d : dev) {
+                char *fresh = nullptr;
+                OPAL_HIP(hipMalloc((void **)&fresh, nb));
+                hipError_t e = hipMemset(fresh, 0, nb);
+                // (the header of a send message carries the zone counts of the exchange before: kept)
+                if (e == hipSuccess) e = hipMemcpy(fresh, *d, LINK_HEAD_BYTES, hipMemcpyDeviceToDevice);
+                if (e != hipSuccess) {
+                    hipFree(fresh);
+                    OPAL_HIP(e);
+                }
+                OPAL_HIP(hipFree(*d));
+                *d = fresh;
             }
+            if (!l->device_buffers) {
+                char **host[2] = {side == 0 ? &l->h_send_left : &l->h_send_right, side == 0 ? &l->h_recv_left : &l->h_recv_right};
+                for (auto h : host) {
+                    OPAL_HIP(hipHostFree(*h));
+                    *h = nullptr;
+                    OPAL_HIP(hipHostMalloc((void **)h, nb));
+                    memset(*h, 0, nb);
+                }
+            }
+            if (l->peer) {
+                void *st = state[side];
+                state[side] = nullptr;  // (link_peer_grow_finish owns it from here, success or not)
+                if (int rc = link_peer_grow_finish(l, side, st)) return rc;
+            }
+            l->cap_side[side] = new_cap[side];
+            l->nbytes_side[side] = nb;
+            l->grows++;
         }
-        if (l->peer)
-            if (int rc = link_peer_grow_finish(l, side, state[side])) return rc;
-        l->cap_side[side] = new_cap[side];
-        l->nbytes_side[side] = nb;
-        l->grows++;
-    }
+        return OPAL_OK;
+    };
+    const int rc = body();
+    for (int side = 0; side < 2; side++)
+        if (state[side]) link_peer_grow_abort(l, state[side]);
     l->nbytes = l->nbytes_side[0] > l->nbytes_side[1] ? l->nbytes_side[0] : l->nbytes_side[1];
-    return OPAL_OK;
+    return rc;
 }
 
 // whether exchanges may be issued on `st` rather than on the stream the link was created with: host-staged

@@ -127,7 +127,8 @@ int link_grow(opal_link_t *l, const size_t new_cap[2]);  // (0: that edge stays 
 // peer link's stays below what its neighbour can map)
 size_t link_room_for(const opal_link_t *l, size_t slots);
 int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state);
-int link_peer_grow_finish(opal_link_t *l, int side, void *state);
+int link_peer_grow_finish(opal_link_t *l, int side, void *state);  // (releases `state` whatever it returns)
+void link_peer_grow_abort(opal_link_t *l, void *state);            // a growth begun that will not be finished
 // OPAL_ERR_LINK if a wait for a neighbour's message has ever timed out on this link (peer links; OPAL_OK for the others).
 // Synchronises with the link's stream: called where the host waits for the device anyway.
 int link_peer_check(opal_link_t *l);

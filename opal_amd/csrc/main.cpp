@@ -228,7 +228,8 @@ bool make_link(Comm &c, void *stream, size_t cap, int slots, int fields, bool to
     if (allowed("socket")) {
         opal_link_t *l = nullptr;
         bool mine_ok = opal_link_create_layout(&l, c.rank, c.size, 0, cap, slots, fields, cb_exchange, &c, stream) == OPAL_OK &&
-                       opal_link_set_exchange2(l, cb_exchange2) == OPAL_OK;
+                       opal_link_set_exchange2(l, cb_exchange2) == OPAL_OK &&
+                       opal_link_set_growth(l, getenv("OPAL_LINK_NO_GROWTH") ? 0 : 1) == OPAL_OK;  // (its buffers are the library's: link_grow)
         if (!mine_ok) why = opal_last_error();
         if (all_agree(c, mine_ok)) {
             out.link = l;

@@ -272,7 +272,11 @@ int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state)
 {
     *state = nullptr;
     opal_peer *p = l->peer;
-    if (!p || !p->connected) return OPAL_OK;  // (not connected yet: opal_link_peer_connect takes the capacities as they are)
+    if (!p) return OPAL_OK;
+    if (!p->connected) {  // (link_grow refuses before it gets here)
+        set_error("peer link: not connected (opal_link_peer_connect)");
+        return OPAL_ERR_LINK;
+    }
     OPAL_HIP(hipDeviceSynchronize());
     PeerGrowth *gr = new PeerGrowth();
     gr->stride = peer_stride(l, new_cap);
@@ -283,10 +287,10 @@ int link_peer_grow_begin(opal_link_t *l, int side, size_t new_cap, void **state)
         delete gr;
         return hip_fail(e, "allocating larger peer mailboxes");
     }
+    *state = gr;  // (from here the caller lets it go if anything fails: link_peer_grow_abort)
     OPAL_HIP(hipMemset(gr->fresh, 0, bytes));
     OPAL_HIP(hipDeviceSynchronize());
     gr->gen = ++p->gen[side];
-    *state = gr;
     if (p->self[side]) return OPAL_OK;
     PeerCtl mine;
     memset(&mine, 0, sizeof mine);
@@ -323,25 +327,33 @@ int link_peer_grow_finish(opal_link_t *l, int side, void *state)
     PeerCtl theirs;
     const auto t0 = std::chrono::steady_clock::now();
     if (getenv("OPAL_LINK_DEBUG")) fprintf(stderr, "[link] rank %d side %d: waiting for the neighbour's record %u\n", l->rank, side, gr->gen);
+    auto give_up = [&](int rc) {  // (the fresh mailboxes were exported but never used: nobody holds a mapping of them)
+        link_peer_grow_abort(l, gr);
+        return rc;
+    };
     for (;;) {
-        OPAL_HIP(hipMemcpy(&theirs, p->box_mem[side], sizeof theirs, hipMemcpyDeviceToHost));
+        hipError_t e = hipMemcpy(&theirs, p->box_mem[side], sizeof theirs, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return give_up(hip_fail(e, "reading the neighbour's growth record"));
         if (theirs.gen == gr->gen) break;
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
             set_error("peer link: the neighbour on side %d never sent the handle of its larger mailboxes (growth %u to %zu "
                       "particles per species)", side, gr->gen, gr->cap);
-            return OPAL_ERR_LINK;
+            return give_up(OPAL_ERR_LINK);
         }
         usleep(200);
     }
     if (theirs.cap != (unsigned)gr->cap) {
         set_error("peer link: the two ends of edge %d disagree on its new capacity (%zu here, %u there)", side, gr->cap, theirs.cap);
-        return OPAL_ERR_LINK;
+        return give_up(OPAL_ERR_LINK);
     }
     hipIpcMemHandle_t h;
     memcpy(&h, theirs.handle, sizeof h);
     void *map = nullptr;
     if (getenv("OPAL_LINK_DEBUG")) fprintf(stderr, "[link] rank %d side %d: record %u here, mapping\n", l->rank, side, gr->gen);
-    OPAL_HIP(hipIpcOpenMemHandle(&map, h, hipIpcMemLazyEnablePeerAccess));
+    {
+        hipError_t e = hipIpcOpenMemHandle(&map, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return give_up(hip_fail(e, "hipIpcOpenMemHandle(the neighbour's larger mailboxes)"));
+    }
     // the mapping of the neighbour's old mailboxes is shared by both sides when both neighbours are one subdomain
     void *old = p->mapped[side];
     p->mapped[side] = map;
@@ -352,6 +364,14 @@ int link_peer_grow_finish(opal_link_t *l, int side, void *state)
     p->stride[side] = gr->stride;
     delete gr;
     return OPAL_OK;
+}
+
+void link_peer_grow_abort(opal_link_t *l, void *state)
+{
+    PeerGrowth *gr = static_cast<PeerGrowth *>(state);
+    if (!gr) return;
+    if (gr->fresh) hipFree(gr->fresh);
+    delete gr;
 }
 
 }  // namespace opal

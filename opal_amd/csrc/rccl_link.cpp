@@ -11,6 +11,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "link.hpp"
@@ -159,6 +160,9 @@ int opal_link_create_rccl(opal_link_t **out, int rank, int size, size_t particle
     (*out)->user_free = rccl_free;
     (*out)->exchange2 = rccl_exchange2;  // one size per edge: messages follow the particles (link.cpp)
     (*out)->set_stream = [](void *user, hipStream_t s) { static_cast<RcclState *>(user)->stream = s; };
+    // the buffers are the library's own and RCCL is handed their addresses at every call: an edge can grow (link_grow) when
+    // more particles stand near it than it has room for, exactly as a peer link's does
+    (*out)->growable = !getenv("OPAL_LINK_NO_GROWTH");
     return OPAL_OK;
 }
 

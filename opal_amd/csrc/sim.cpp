@@ -1035,7 +1035,9 @@ int opal_sim_run(opal_sim_t *s)
     for (size_t i = 0; i < s->n_outputs; i++) {
         if (int rc = write_all(i)) return rc;
         if (s->rank == 0) {  // main.rs:224-234
-            if (i > 0) {
+            // (total_steps < n_outputs leaves steps_bt_output, and so `done`, at zero: the reference panics in
+            // Duration::from_secs_f64 on the NaN; here the line goes out without an estimate)
+            if (i > 0 && s->steps_bt_output > 0) {
                 const double rt = elapsed(), done = (double)(i * s->steps_bt_output), total = (double)(s->n_outputs * s->steps_bt_output);
                 printf("Output %4zu at t = %s, RT = %s, ETTC = %s...\n", i, simulation_time(s->t).c_str(), pretty(rt).c_str(),
                        pretty(rt * (total - done) / done).c_str());

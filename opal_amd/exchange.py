@@ -287,12 +287,16 @@ class PeerLink:
 
 
 def make_link(rank, world, device, particle_capacity, stream=None, photon_emission=False, photon_absorption=False,
-              to_left=True, to_right=True, prefer=("peer", "rccl", "torch"), log=None):
+              to_left=True, to_right=True, prefer=("peer", "rccl", "torch"), log=None, fixed_capacity=None):
     """The neighbour transport of a decomposed run on one node, best first: peer-mapped mailboxes written by the step's
     own kernels; the library's own RCCL send/recv; torch.distributed P2P.  Collective: every subdomain calls it, and all
     of them end up with the same kind (a kind is kept only if it came up on EVERY subdomain: the mailboxes are tried
     with a few halo exchanges first).  Returns (link, kind).  With a CPU `device` (ranks sharing a card in a rehearsal)
     the fallback is the host-staged torch.distributed link.
+
+    particle_capacity is the room a link that can GROW is created with (peer mailboxes, the library's RCCL link: link.cpp,
+    link_grow); fixed_capacity (default: the same) is what a link gets whose buffers belong to torch and therefore stay as
+    they are created (TorchLink): callers pass the worst pile-up they provide for.
 
     The handles and the yes/no votes travel over a gloo group of their own when the default group is RCCL's."""
     device = torch.device(device)
@@ -333,7 +337,7 @@ def make_link(rank, world, device, particle_capacity, stream=None, photon_emissi
             elif kind == "rccl" and device.type == "cuda":
                 link = RcclLink(rank, world, device, **kw)
             elif kind == "torch" or device.type != "cuda":
-                link = TorchLink(rank, world, device, **kw)
+                link = TorchLink(rank, world, device, **dict(kw, particle_capacity=max(particle_capacity, fixed_capacity or 0)))
                 kind = "torch" if device.type == "cuda" else "gloo"
         except Exception as e:  # noqa: BLE001
             err, link = str(e), None
