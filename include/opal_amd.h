@@ -419,6 +419,31 @@ int opal_sim_set_fused(opal_sim_t *s, int fused);
  * it is there for links whose latency is larger than that. */
 int opal_sim_set_overlap(opal_sim_t *s, int on);
 size_t opal_sim_overlapped_steps(const opal_sim_t *s); /* how many steps so far ran that way (diagnostic) */
+/* Cuts that follow the plasma (opt-in).  The reference partitions the domain once, at t = 0, by the electrons' initial
+ * density (GridDesign::balanced, grid/mod.rs:157-206, called from main.rs:103-110); a laser that piles the plasma up or a
+ * beam that crosses the domain then leaves most particles on one or two subdomains.  With every > 0, every `every`-th
+ * step of opal_sim_step the subdomains all-reduce their particle loads (opal_sim_set_collectives' allreduce) and, when
+ * max / mean exceeds `threshold` (>= 1), move the cuts by the reference's own partition rule applied to the particles
+ * where they stand now -- each cut by `max_shift` cells at the most (0: 64), never out of the two subdomains it separates,
+ * every subdomain keeping opal_grid_min_size() cells (yee.rs:783-785).  The cells that change hands travel with everything
+ * in them: particles as leavers through the link (mod.rs:291-293, 366-368), grid columns through the all-reduce; the
+ * subdomain sizes the grid rows are gathered by follow (yee.rs:749-779).  every = 0 (default): the reference's partition,
+ * made once.  Results do not depend on where the cuts are (only the deposit's summation order does).
+ * opal_sim_recut_now: one check + re-cut at once, whatever the threshold (collective; for callers that step by hand).
+ * opal_sim_recut_stats: checks and re-cuts so far, max / mean at the last check and the worst since the previous call
+ * (0: never checked), and the subdomains' present sizes (numtasks entries; any pointer may be null). */
+int opal_sim_set_recut(opal_sim_t *s, size_t every, double threshold, size_t max_shift);
+int opal_sim_recut_now(opal_sim_t *s);
+int opal_sim_recut_stats(opal_sim_t *s, size_t *checks, size_t *recuts, double *imbalance_last, double *imbalance_worst,
+                         size_t *nx_of_every_subdomain);
+/* The plan of a re-cut, pure host arithmetic (no device): cuts[0 .. numtasks] are the first global cell of every
+ * subdomain and one past the last; cost[c] the load of global cell c, most[c] the particle count of its fullest species
+ * (null: cost); edge_room[i - 1] the particles per species cut i may move (null or negative: any number).  new_cuts gets
+ * the partition of grid/mod.rs:170-176 on `cost`, held to the limits above; imbalance_* = max / mean of the subdomains'
+ * cost before and after (may be null). */
+int opal_recut_plan(int numtasks, const size_t *cuts, const double *cost, const double *most, size_t min_size,
+                    size_t max_shift, const double *edge_room, size_t *new_cuts, double *imbalance_before,
+                    double *imbalance_after);
 /* A HIP stream of the library's own runtime, for hosts that have none to hand in (several subdomains inside one
  * process, one stream each: tests/_inproc_world.py).  Every `hip_stream` argument of this header takes it. */
 int opal_stream_create(void **out);

@@ -102,11 +102,18 @@ class Grid:
             self.h = h
         else:
             self.h = C.c_void_p(_handle)
-        self.size = self._lib.opal_grid_size(self.h)
-        self.len = self._lib.opal_grid_len(self.h)
         self.left_bdy_size = self._lib.opal_grid_left_bdy_size(self.h)
         self.right_bdy_size = self._lib.opal_grid_right_bdy_size(self.h)
         self.dx = self._lib.opal_grid_dx(self.h)
+
+    # (asked of the library each time: a Simulation's grid changes size when its cuts move, Simulation.set_recut)
+    @property
+    def size(self):
+        return self._lib.opal_grid_size(self.h)
+
+    @property
+    def len(self):
+        return self._lib.opal_grid_len(self.h)
 
     @classmethod
     def single(cls, nx, xmin, dx, left=BDY_INTERNAL, right=BDY_INTERNAL, stream=None):
@@ -508,6 +515,24 @@ class Simulation:
     def set_fused(self, fused):
         _check(self._lib.opal_sim_set_fused(self.h, 1 if fused else 0))
 
+    def set_recut(self, every, threshold=1.1, max_shift=64):
+        """Cuts that follow the plasma (opal_sim_set_recut): every `every` steps the subdomains compare their particle
+        loads and, above `threshold` (max / mean), move their cuts by up to max_shift cells.  every = 0: the reference's
+        partition, made once at t = 0 (grid/mod.rs:157-206)."""
+        _check(self._lib.opal_sim_set_recut(self.h, int(every), float(threshold), int(max_shift)))
+
+    def recut_now(self):
+        """One check + re-cut at once, whatever the threshold (collective)."""
+        _check(self._lib.opal_sim_recut_now(self.h))
+
+    def recut_stats(self, numtasks):
+        """dict: checks, recuts, imbalance (max / mean at the last check; 0.0: never checked), imbalance_worst (since the
+        previous call), sizes (interior cells of every subdomain now)."""
+        a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_double(), C.c_double()
+        nx = (C.c_size_t * numtasks)()
+        _check(self._lib.opal_sim_recut_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), nx))
+        return {"checks": a.value, "recuts": b.value, "imbalance": c.value, "imbalance_worst": d.value, "sizes": list(nx)}
+
     @property
     def t(self):
         return self._lib.opal_sim_time(self.h)
@@ -532,6 +557,21 @@ class Simulation:
         f, e, i = C.c_double(), C.c_double(), C.c_double()
         _check(self._lib.opal_sim_energies(self.h, C.byref(f), C.byref(e), C.byref(i)))
         return f.value, e.value, i.value
+
+
+def recut_plan(cuts, cost, most=None, min_size=8, max_shift=64, edge_room=None):
+    """opal_recut_plan: (new cuts, imbalance before, imbalance after); host arithmetic only (no GPU)."""
+    cuts = np.ascontiguousarray(cuts, dtype=np.uint64)
+    n = len(cuts) - 1
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    assert len(cost) == int(cuts[-1])
+    most = None if most is None else np.ascontiguousarray(most, dtype=np.float64)
+    room = None if edge_room is None else np.ascontiguousarray(edge_room, dtype=np.float64)
+    out = np.zeros(n + 1, dtype=np.uint64)
+    a, b = C.c_double(), C.c_double()
+    _check(_lib.load().opal_recut_plan(n, _ptr(cuts), _ptr(cost), _ptr(most) if most is not None else None, min_size, max_shift,
+                                       _ptr(room) if room is not None else None, _ptr(out), C.byref(a), C.byref(b)))
+    return out.astype(np.int64), a.value, b.value
 
 
 class Config:

@@ -239,6 +239,75 @@ int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const d
     return OPAL_OK;
 }
 
+// A subdomain whose cuts have moved (sim.cpp: sim_recut): `size` interior cells from `offset` on, boundary regions as they
+// were (yee.rs:278-292 goes by rank and boundary kind, which do not change), and the 10 rows rho jx jy jz Ex Ey Ez Bx By Bz of
+// the new array -- `rows`, host memory, new_len doubles each -- as the state.  The handle stays the one the caller holds.
+int grid_recut(opal_grid_t *g, size_t size, double offset, const double *rows)
+{
+    if (size < (size_t)(2 * GHOST_SIZE) || size > (size_t)1 << 28) {
+        set_error("grid_recut: subdomain of %zu cells (min %d)", size, 2 * GHOST_SIZE);
+        return OPAL_ERR_ARG;
+    }
+    OPAL_HIP(hipStreamSynchronize(g->stream));
+    const size_t len = size + (size_t)g->L + (size_t)g->R, lenp = (len + 63) / 64 * 64, nb = sizeof(double) * lenp;
+    double *eb[2] = {nullptr, nullptr}, *jb[2] = {nullptr, nullptr}, *pin = nullptr;
+    auto drop = [&]() {
+        for (int k = 0; k < 2; k++) {
+            if (eb[k]) hipFree(eb[k]);
+            if (jb[k]) hipFree(jb[k]);
+        }
+        if (pin) hipHostFree(pin);
+    };
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+        e = hipMalloc(&eb[k], 6 * nb);
+        if (e == hipSuccess) e = hipMalloc(&jb[k], 4 * nb);
+        if (e == hipSuccess) e = hipMemsetAsync(eb[k], 0, 6 * nb, g->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(jb[k], 0, 4 * nb, g->stream);
+    }
+    if (e == hipSuccess) e = hipHostMalloc(&pin, sizeof(double) * 11 * lenp);
+    if (e != hipSuccess) {
+        drop();
+        return hip_fail(e, "grid_recut: allocating the re-cut subdomain's rows");
+    }
+    // (rows are staged through the new pinned scratch: the caller's are pageable)
+    memcpy(pin, rows, sizeof(double) * 10 * len);
+    const size_t lb = sizeof(double) * len;
+    e = hipMemcpyAsync(jb[0] + 3 * lenp, pin, lb, hipMemcpyHostToDevice, g->stream);  // rho
+    for (int c = 0; c < 3 && e == hipSuccess; c++) e = hipMemcpyAsync(jb[0] + (size_t)c * lenp, pin + (size_t)(1 + c) * len, lb, hipMemcpyHostToDevice, g->stream);
+    for (int c = 0; c < 6 && e == hipSuccess; c++) e = hipMemcpyAsync(eb[0] + (size_t)c * lenp, pin + (size_t)(4 + c) * len, lb, hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e != hipSuccess) {
+        drop();
+        return hip_fail(e, "grid_recut: uploading the re-cut subdomain's rows");
+    }
+    hipFree(g->d_eb[0]); hipFree(g->d_eb[1]); hipFree(g->d_jb[0]); hipFree(g->d_jb[1]);
+    hipHostFree(g->h_pin);
+    g->d_eb[0] = eb[0]; g->d_eb[1] = eb[1]; g->d_jb[0] = jb[0]; g->d_jb[1] = jb[1];
+    g->h_pin = pin;
+    g->cur = 0;
+    g->jcur = 0;
+    g->j_spare_zero = true;
+    g->size = size;
+    g->len = len;
+    g->lenp = lenp;
+    g->offset = offset;
+    // a transverse field that came with the new cells ends the electrostatic launches here too (opal_grid_set_raw)
+    for (int c = 5; c < 10; c++)
+        for (size_t i = 0; i < len; i++)
+            if (rows[(size_t)c * len + i] != 0.0) *g->h_esflag = 1;
+    if (g->right_bdy == OPAL_BDY_ABSORBING) {
+        // yee.rs:465-468 with the new offset: the same cells, the same factors up to the rounding of cell_x
+        double xmin_b = g->cell_x(g->size + (size_t)g->L);
+        double xmax_b = g->cell_x(g->size + (size_t)g->L + (size_t)g->R - 1);
+        double sigma_max = 10.0 / ((double)g->R);
+        for (size_t i = g->len - (size_t)g->R + 1, k = 0; i < g->len; i++, k++)
+            g->damp_host[k] = 1.0 - sigma_max * (g->cell_x(i) - xmin_b) / (xmax_b - xmin_b);
+        OPAL_HIP(hipMemcpy(g->d_damp, g->damp_host.data(), sizeof(double) * g->damp_host.size(), hipMemcpyHostToDevice));
+    }
+    return OPAL_OK;
+}
+
 int grid_check_err(const opal_grid_t *g)
 {
     int err = 0;
@@ -544,3 +613,8 @@ int opal_grid_synchronize(opal_grid_t *g, opal_link_t *link, opal_fn2 laser_y, o
 }
 
 }  // extern "C"
+
+namespace opal {
+// all rows of the subdomain on the host (pinned scratch of the grid): [comp * lenp + i], comp = OPAL_X .. OPAL_BZ
+const double *grid_fetch_rows(const opal_grid_t *g) { return grid_fetch(g) == OPAL_OK ? g->h_pin : nullptr; }
+}

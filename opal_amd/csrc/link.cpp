@@ -116,7 +116,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     // edge of such a link grows by it like any other instead of staying at its creation size through a pile-up.)
     const bool every_slot = l->nfields >= 15;
     if ((!sizes_messages && !link_is_peer(l) && !(every_slot && l->growable)) || !l->h_bounds) return OPAL_OK;
-    if (X < (unsigned)LINK_ZONE) return OPAL_OK;
+    if (X < (unsigned)LINK_ZONE && !l->hold_on) return OPAL_OK;
     unsigned need[2] = {0, 0};
     // (a peer link files every LINK_PEER_EVERY-th exchange only and counts LINK_PEER_ZONE cells: see link.hpp)
     const bool peer = link_is_peer(l);
@@ -126,6 +126,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
         unsigned e = X - LINK_ZONE;
         if (peer) e -= e % LINK_PEER_EVERY;
         for (;; e -= peer ? LINK_PEER_EVERY : 1) {
+            if (l->hold_on && e < l->hold_from) break;  // counted near where the cuts were before they moved
             // overwritten since (or about to be).  (An old entry is as good as a recent one for a called transport: the
             // exchanges after it that did not count the species did not push it either, so at most LINK_ZONE pushes of
             // it lie between the entry and X.  A peer link skips entries whatever they counted, so age itself bounds.)
@@ -154,17 +155,24 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     };
     const LinkBounds *be = nullptr;
     const bool qed = l->nfields >= 12 && l->nslots >= 3;
-    if (qed && (species_mask & 4u))
-        if (int rc = entry_of(0, &be)) return rc;
-    for (int sp = 0; sp < l->nslots; sp++) {
-        if (!(species_mask & (1u << sp))) continue;
-        const LinkBounds *b;
-        if (int rc = entry_of(sp, &b)) return rc;
-        if (!b || (sp == 2 && qed && !be)) return OPAL_OK;  // no history to go by: every slot
-        for (int side = 0; side < 2; side++) {
-            unsigned n = b->mine[side][sp] + b->theirs[side][sp];
-            if (sp == 2 && qed) n += zone_cells * (be->mine[side][0] + be->theirs[side][0]);
-            need[side] = need[side] > n ? need[side] : n;
+    const bool held = l->hold_on && X - l->hold_from < zone_cells;  // (X >= hold_from: xseq only grows)
+    if (held) {
+        // the cuts moved fewer than zone_cells exchanges ago: what stood near them then (link_hold)
+        need[0] = l->hold_need[0];
+        need[1] = l->hold_need[1];
+    } else {
+        if (qed && (species_mask & 4u))
+            if (int rc = entry_of(0, &be)) return rc;
+        for (int sp = 0; sp < l->nslots; sp++) {
+            if (!(species_mask & (1u << sp))) continue;
+            const LinkBounds *b;
+            if (int rc = entry_of(sp, &b)) return rc;
+            if (!b || (sp == 2 && qed && !be)) return OPAL_OK;  // no history to go by: every slot
+            for (int side = 0; side < 2; side++) {
+                unsigned n = b->mine[side][sp] + b->theirs[side][sp];
+                if (sp == 2 && qed) n += zone_cells * (be->mine[side][0] + be->theirs[side][0]);
+                need[side] = need[side] > n ? need[side] : n;
+            }
         }
     }
     unsigned slots[2];
@@ -196,6 +204,16 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     }
     return OPAL_OK;
 }
+
+void link_hold(opal_link_t *l, const unsigned need[2])
+{
+    l->hold_on = true;
+    l->hold_from = l->xseq;
+    l->hold_need[0] = need[0];
+    l->hold_need[1] = need[1];
+}
+
+int link_zone_cells(const opal_link_t *l) { return link_is_peer(l) ? LINK_PEER_ZONE : LINK_ZONE; }
 
 int link_grow(opal_link_t *l, const size_t new_cap_in[2])
 {

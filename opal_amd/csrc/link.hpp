@@ -92,6 +92,12 @@ struct opal_link {
                              // what the populations reserve room for (a peer link ships whatever leaves, up to `cap`)
     bool bounded;            // sizes follow the bounds (needs exchange2); else every exchange ships all `cap` slots
     size_t last_bytes[2];    // what the last whole-message exchange moved per edge (diagnostic)
+    // After the cuts have moved (sim.cpp: sim_recut) the ring's entries count particles near where the cuts WERE.  Until
+    // exchanges made with the new cuts have filed theirs, the bound is what stood within the zone of each new cut when it
+    // was made (hold_need, from the histogram the re-cut was planned with): exchange hold_from + j comes j + 1 pushes after
+    // the re-cut, so that count covers j < zone; entries of exchanges before hold_from are never used again.
+    bool hold_on;
+    unsigned hold_from, hold_need[2];
     // peer-mapped mailboxes (peer.hip, peer_device.hpp): the kernels of the step move the messages themselves
     struct opal_peer *peer;  // null for transports that are called (RCCL, torch.distributed, host callbacks)
 };
@@ -132,4 +138,8 @@ void link_peer_grow_abort(opal_link_t *l, void *state);            // a growth b
 // OPAL_ERR_LINK if a wait for a neighbour's message has ever timed out on this link (peer links; OPAL_OK for the others).
 // Synchronises with the link's stream: called where the host waits for the device anyway.
 int link_peer_check(opal_link_t *l);
+// the cuts have just moved: need[side] particles per species stand within the zone of the left / right cut now (see hold_on)
+void link_hold(opal_link_t *l, const unsigned need[2]);
+// cells either side of a cut within which the pushes count particles into the message headers (what link_plan's bound covers)
+int link_zone_cells(const opal_link_t *l);
 }  // namespace opal

@@ -1529,6 +1529,68 @@ __global__ void k_pack_extras(PackExtrasArgs a)
     }
 }
 
+// A re-cut of the decomposition (sim.cpp: sim_recut): the cells this subdomain hands to its neighbours change hands with
+// everything in them.  Particles in the first `give_left` cells (the last cells, from `first_right` on) are packed into the
+// link's send messages exactly as a push packs its leavers -- cell index in the receiver's frame: negative for the left
+// neighbour, which adds its new size (mod.rs:366-368), from zero for the right one (mod.rs:291-293), all attributes, prev_x
+// and the extras the link carries -- and their slots vacated; everybody else's cell index moves to the new frame.
+struct RecutPackArgs {
+    int *cell;
+    const double *f[5];
+    const double *prev;
+    const double *ex[NEX];
+    unsigned n;          // slots in use
+    int give_left;       // cells [0, give_left) go to the left neighbour
+    int first_right;     // cells [first_right, size) go to the right neighbour
+    int delta;           // a stayer's cell index changes by this much: cells taken over on the left minus cells given away there
+    char *send[2];
+    unsigned cap[2];
+    LinkLayout layout;
+    int slot;
+    unsigned nextra;
+    PopCounters *ctr;
+};
+__global__ __launch_bounds__(256) void k_recut_pack(RecutPackArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned n_wave_aligned = (a.n + 63u) & ~63u;
+    int err = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_wave_aligned; i += gridDim.x * blockDim.x) {
+        const int c = i < a.n ? a.cell[i] : DEAD_CELL;
+        int side = -1;
+        if (c != DEAD_CELL) {
+            if (c < a.give_left) side = 0;
+            else if (c >= a.first_right) side = 1;
+            else if (a.delta) a.cell[i] = c + a.delta;
+        }
+        for (int sd = 0; sd < 2; sd++) {  // (wave-uniform loop: one reservation per wave and side)
+            const unsigned long long m = __ballot(side == sd);
+            if (!m) continue;
+            unsigned base = 0;
+            const int lead = __ffsll((long long)m) - 1;
+            if (lane == lead) base = atomicAdd(reinterpret_cast<unsigned *>(a.send[sd]) + LINK_H_COUNT + a.slot, (unsigned)__popcll(m));
+            base = __shfl(base, lead);
+            if (side != sd) continue;
+            const unsigned k = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            a.cell[i] = DEAD_CELL;
+            if (k >= a.cap[sd]) {
+                err |= 8;
+                continue;
+            }
+            char *msg = a.send[sd];
+            *link_cell(msg, a.layout, a.slot, k) = sd == 0 ? c - a.give_left : c - a.first_right;
+#pragma unroll
+            for (int q = 0; q < 5; q++) *link_field(msg, a.layout, a.slot, q, k) = a.f[q][i];
+            *link_field(msg, a.layout, a.slot, 5, k) = a.prev ? a.prev[i] : 0.0;
+            for (int q = 0; q < NEX; q++)
+                if (q < (int)a.nextra) *link_field(msg, a.layout, a.slot, 6 + q, k) = a.ex[q] ? a.ex[q][i] : 0.0;
+        }
+        const unsigned long long gone = __ballot(side >= 0);
+        if (gone && lane == 0) atomicAdd(&a.ctr->n_dead, (unsigned)__popcll(gone));
+    }
+    if (err) atomicOr(&a.ctr->err, err);
+}
+
 int check_pop(const opal_pop_t *p)
 {
     if (!p) {
@@ -3113,6 +3175,79 @@ int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *
     for (int i = 0; i < npops && i < 4; i++)
         if (pops[i] && sort_now[i])
             if (int rc = do_sort(pops[i], g, false)) return rc;
+    return OPAL_OK;
+}
+
+// ---- a re-cut of the decomposition (sim.cpp: sim_recut), the populations' part
+// live particles of `p` (drains its stream)
+int pop_live_count(opal_pop_t *p, size_t *n)
+{
+    if (int rc = fetch_counters(p)) return rc;
+    *n = (size_t)p->h_ctr->n_slots - std::min(p->h_ctr->n_slots, p->h_ctr->n_dead);
+    return OPAL_OK;
+}
+// Re-bins `p` exactly and waits: *cell_end[c] is then one past the last slot of cell c, c < g->size (null: no particles)
+int pop_cell_ends(opal_pop_t *p, const opal_grid_t *g, const unsigned **cell_end)
+{
+    *cell_end = nullptr;
+    if (p->upper_pending)
+        if (int rc = pop_tighten_upper(p)) return rc;
+    if (p->n_upper == 0) return OPAL_OK;
+    if (int rc = do_sort(p, g, true)) return rc;
+    if (p->n_cell_end == g->size) *cell_end = p->h_cell_end;
+    return OPAL_OK;
+}
+// packs what the cells given away hold into the link's send messages (after link_begin) and moves the stayers' cell
+// indices to the new frame; `size` is the subdomain's size BEFORE the re-cut
+int pops_recut_pack(opal_pop_t *const *pops, int npops, opal_link_t *link, size_t size, int give_left, int give_right, int delta)
+{
+    for (int i = 0; i < npops; i++) {
+        opal_pop_t *p = pops[i];
+        if (!p || p->n_upper == 0) continue;
+        if (p->species >= link->nslots) {
+            set_error("this link's messages have no room for species %d (see opal_link_set_layout)", p->species);
+            return OPAL_ERR_LINK;
+        }
+        RecutPackArgs a;
+        memset(&a, 0, sizeof a);
+        const int k = p->cur;
+        a.cell = p->d_cell[k];
+        a.f[0] = p->d_x[k]; a.f[1] = p->d_ux[k]; a.f[2] = p->d_uy[k]; a.f[3] = p->d_uz[k]; a.f[4] = p->d_w[k];
+        a.prev = p->prev_valid ? p->d_prev_x : nullptr;
+        for (int q = 0; q < NEX; q++) a.ex[q] = p->extras ? p->d_ex[q] : nullptr;
+        a.n = (unsigned)p->n_upper;
+        a.give_left = give_left;
+        a.first_right = (int)size - give_right;
+        a.delta = delta;
+        for (int side = 0; side < 2; side++) {
+            a.send[side] = link_send(link, side);
+            a.cap[side] = link->send_cap[side];
+        }
+        a.layout = link->layout;
+        a.slot = p->species;
+        a.nextra = link->nfields > 6 ? (unsigned)(link->nfields - 6) : 0u;
+        a.ctr = p->d_ctr;
+        const unsigned nblk = (unsigned)std::min<size_t>((p->n_upper + 255) / 256, 8192);
+        k_recut_pack<<<nblk, 256, 0, p->stream>>>(a);
+        OPAL_HIP(hipGetLastError());
+        p->sorted_exact = false;
+        p->emit_list_valid = false;
+        p->n_cell_end = 0;  // the host's cell map is of the old frame
+    }
+    return OPAL_OK;
+}
+// the arrivals (the exchange has been made), then every population in exact order on the re-cut grid `g`
+int pops_recut_finish(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g)
+{
+    if (int rc = unpack_arrivals(pops, npops, link, g, true)) return rc;
+    for (int i = 0; i < npops; i++) {
+        opal_pop_t *p = pops[i];
+        if (!p) continue;
+        const int interval = p->last_interval;  // (what the policy knows of the population's temperature is not the re-cut's doing)
+        if (int rc = do_sort(p, g, true)) return rc;
+        p->last_interval = interval;
+        if (int rc = check_pop_err(p)) return rc;
+    }
     return OPAL_OK;
 }
 }

@@ -9,6 +9,7 @@
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -41,6 +42,13 @@ bool pops_plan_split(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, const op
 int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link, opal_grid_t *g, double dt, bool edges,
                               hipStream_t on);
 int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz);
+// a re-cut of the decomposition (sim_recut): the pieces in particles.hip and grid.hip
+int pop_live_count(opal_pop_t *p, size_t *n);
+int pop_cell_ends(opal_pop_t *p, const opal_grid_t *g, const unsigned **cell_end);
+int pops_recut_pack(opal_pop_t *const *pops, int npops, opal_link_t *link, size_t size, int give_left, int give_right, int delta);
+int pops_recut_finish(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
+int grid_recut(opal_grid_t *g, size_t size, double offset, const double *rows);
+const double *grid_fetch_rows(const opal_grid_t *g);
 }
 
 namespace {
@@ -175,7 +183,14 @@ struct opal_sim {
     size_t n_overlapped = 0;  // steps that took the overlapped path (diagnostic)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_edges = nullptr, ev_comm = nullptr;
-    std::vector<size_t> nxs;  // interior cells of every subdomain (GridDesign)
+    std::vector<size_t> nxs;  // interior cells of every subdomain (GridDesign; moves with the cuts: sim_recut)
+    // cuts that follow the plasma (opal_sim_set_recut; 0 = the reference's partition, made once at t = 0)
+    size_t recut_every = 0, recut_max_shift = 64, recut_max_particles = (size_t)1 << 24;
+    double recut_threshold = 1.10;
+    size_t recut_checks = 0, recuts = 0;
+    double imbalance_seen = 0.0;    // max / mean of the subdomains' particle cost at the last check (0: never checked)
+    double imbalance_worst = 0.0;   // ... the worst seen at any check since opal_sim_recut_stats was last asked
+    std::vector<size_t> cuts;       // first global cell of every subdomain, and one past the last one's
     opal_allreduce_fn allreduce = nullptr;
     opal_gather_fn gather = nullptr;
     void *coll_user = nullptr;
@@ -316,6 +331,8 @@ int sim_setup(opal_sim_t *s)
                                  s->stream))
         return rc;
     s->nxs = nxs;
+    s->cuts.assign((size_t)s->numtasks + 1, 0);
+    for (int r = 0; r < s->numtasks; r++) s->cuts[(size_t)r + 1] = s->cuts[(size_t)r] + nxs[(size_t)r];
 
     Rng rng;
     rng.seed((uint64_t)s->rank);  // main.rs:53
@@ -640,6 +657,203 @@ static int ensure_comm_stream(opal_sim_t *s)
     return OPAL_OK;
 }
 
+// Cuts that follow the plasma.  The reference balances the decomposition once, on the electrons' initial density
+// (grid/mod.rs:157-206, main.rs:103-110), and so does this driver by default; with opal_sim_set_recut the same partition
+// rule is applied again every few steps to the particles where they stand (recut.cpp), and what changes hands travels the
+// way leavers do.  Collective: every subdomain enters it at the same step.
+//   A. the subdomains' particle costs, all-reduced (one small message); below the threshold nothing else happens.
+//   B. every population re-binned exactly (its cell ends ARE the per-cell histogram), the per-species histograms of the
+//      whole domain all-reduced, the new cuts planned -- the same on every subdomain, from the same numbers.
+//   C. edges whose messages are too small for what crosses them grow (both ends know the count); the particles in the
+//      cells given away are packed as leavers with their cell index in the receiver's frame (mod.rs:291-293, 366-368)
+//      and exchanged through the link; the grid's columns that change hands (and the four ghost columns beyond) go
+//      through one more all-reduce of a window only their old owner fills; the grid is rebuilt in place, the arrivals
+//      appended, every population re-binned on the new grid; the link's bound is re-seeded with what stands near the new
+//      cuts (link_hold).  nxs / offsets follow, so {i}_grid.dat still gathers in rank order (yee.rs:749-779).
+// Nothing of the physics depends on where the cuts are (tests/test_gpu_recut.py: a re-cutting world equals the static
+// oracle world), only the summation order of the deposit does.
+static int sim_recut(opal_sim_t *s, bool force)
+{
+    const int N = s->numtasks, rank = s->rank;
+    if (N < 2) return OPAL_OK;
+    if (!s->link || !s->allreduce) {
+        set_error("a re-cut of %d subdomains needs a link and opal_sim_set_collectives (the all-reduce its plan is made from)", N);
+        return OPAL_ERR_ARG;
+    }
+    opal_grid_t *g = s->grid;
+    opal_link_t *link = s->link;
+    hipStream_t st = (hipStream_t)s->stream;
+    opal_pop_t *pops[3] = {s->electrons, s->ions, s->photons};
+    if (s->photons && link->nslots < 3) pops[2] = nullptr;  // (photons that never cross a cut: nothing of theirs is moved)
+    // what a particle of each species costs a step, in units of the general push's 80 bytes (photons: 36 read, 12 written)
+    const double weight[3] = {1.0, 1.0, 0.5};
+    auto reduce = [&](double *v, size_t n) -> int {
+        if (s->allreduce(s->coll_user, v, n, 0)) {
+            set_error("re-cut: the caller's allreduce failed");
+            return OPAL_ERR_LINK;
+        }
+        return OPAL_OK;
+    };
+    const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
+    // ---- A
+    std::vector<double> v(2 * (size_t)N, 0.0);
+    for (int sp = 0; sp < 3; sp++)
+        if (pops[sp]) {
+            size_t live = 0;
+            if (int rc = pop_live_count(pops[sp], &live)) return rc;
+            v[(size_t)rank] += weight[sp] * (double)live;
+        }
+    if (to_right && rank + 1 < N) {
+        // particles per species the cut on my right can move at once: what the edge has room for, or can grow to
+        double room = (double)link->cap_side[1];
+        if (link->growable && !link->external) room = (double)link_room_for(link, ((size_t)1 << 31) / 5 * 4);
+        v[(size_t)N + (size_t)rank] = room;
+    }
+    if (int rc = reduce(v.data(), v.size())) return rc;
+    double total = 0.0, worst = 0.0;
+    for (int r = 0; r < N; r++) {
+        total += v[(size_t)r];
+        worst = std::max(worst, v[(size_t)r]);
+    }
+    s->recut_checks++;
+    s->imbalance_seen = total > 0.0 ? worst * (double)N / total : 1.0;
+    s->imbalance_worst = std::max(s->imbalance_worst, s->imbalance_seen);
+    if (!force && s->imbalance_seen < s->recut_threshold) return OPAL_OK;
+    // ---- B
+    const size_t ncells = s->cuts[(size_t)N], size = g->size;
+    std::vector<double> hist(3 * ncells, 0.0);
+    for (int sp = 0; sp < 3; sp++) {
+        if (!pops[sp]) continue;
+        const unsigned *ce = nullptr;
+        if (int rc = pop_cell_ends(pops[sp], g, &ce)) return rc;
+        if (!ce) continue;
+        double *h = hist.data() + (size_t)sp * ncells + s->cuts[(size_t)rank];
+        for (size_t c = 0; c < size; c++) h[c] = (double)(ce[c] - (c ? ce[c - 1] : 0u));
+    }
+    if (int rc = reduce(hist.data(), hist.size())) return rc;
+    std::vector<double> cost(ncells), most(ncells);
+    for (size_t c = 0; c < ncells; c++) {
+        const double e = hist[c], i = hist[ncells + c], ph = hist[2 * ncells + c];
+        cost[c] = weight[0] * e + weight[1] * i + weight[2] * ph;
+        most[c] = std::max(e, std::max(i, ph));
+    }
+    std::vector<double> room((size_t)N - 1);
+    for (int i = 1; i < N; i++)
+        room[(size_t)i - 1] = std::max(0.0, std::min(v[(size_t)N + (size_t)i - 1] - 2.0 * LINK_SLACK, (double)s->recut_max_particles));
+    std::vector<size_t> cuts(s->cuts), fresh((size_t)N + 1);
+    double before = 0.0, after = 0.0;
+    if (int rc = opal_recut_plan(N, cuts.data(), cost.data(), most.data(), opal_grid_min_size(), s->recut_max_shift, room.data(),
+                                 fresh.data(), &before, &after))
+        return rc;
+    if (fresh == cuts || (!force && !(after < before - 0.01))) return OPAL_OK;  // nothing to gain
+    // ---- C
+    const size_t oldL = cuts[(size_t)rank], oldR = cuts[(size_t)rank + 1], newL = fresh[(size_t)rank], newR = fresh[(size_t)rank + 1];
+    const size_t new_size = newR - newL;
+    const int give_left = newL > oldL ? (int)(newL - oldL) : 0, take_left = oldL > newL ? (int)(oldL - newL) : 0;
+    const int give_right = oldR > newR ? (int)(oldR - newR) : 0;
+    auto most_in = [&](size_t a, size_t b) {  // particles of the fullest species in the global cells [a, b) (a bound on any one species')
+        double n = 0.0;
+        for (size_t c = a; c < b && c < ncells; c++) n += most[c];
+        return n;
+    };
+    unsigned ship[2] = {0, 0};  // slots per species this re-cut's messages carry through my left / right edge
+    size_t grow_to[2] = {0, 0};
+    const size_t moved[2] = {(size_t)most_in(std::min(oldL, newL), std::max(oldL, newL)), (size_t)most_in(std::min(oldR, newR), std::max(oldR, newR))};
+    for (int side = 0; side < 2; side++) {
+        if (!(side == 0 ? to_left : to_right)) continue;
+        const size_t slots = (moved[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+        ship[side] = (unsigned)slots;
+        if (slots > link->cap_side[side]) grow_to[side] = link_room_for(link, slots);
+    }
+    if (grow_to[0] || grow_to[1]) {
+        if (!link->growable) {
+            set_error("re-cut: an edge would have to grow, but this link does not (opal_link_set_growth)");
+            return OPAL_ERR_CAPACITY;
+        }
+        if (int rc = link_grow(link, grow_to)) return rc;
+    }
+    if (int rc = link_begin(link, st, 0)) return rc;  // (species mask 0: this exchange's zone counts are nobody's bound)
+    for (int side = 0; side < 2; side++) {
+        // both ends of an edge ship, and reserve room for, what the histogram says can cross it -- not the edge's whole room
+        const unsigned cap = (unsigned)link->cap_side[side];
+        link->plan_cap[side] = std::min(cap, std::max(ship[side], (unsigned)LINK_ROWS));
+        link->send_cap[side] = link_is_peer(link) ? cap : link->plan_cap[side];
+    }
+    if (int rc = pops_recut_pack(pops, 3, link, size, give_left, give_right, take_left - give_left)) return rc;
+    // the grid's columns: a window per moved cut -- the cells that change hands and the four beyond them, which become the
+    // receiver's ghost cells -- filled by their old owner, all-reduced (every other subdomain adds zeros)
+    const double *old_rows = grid_fetch_rows(g);
+    if (!old_rows) return OPAL_ERR_HIP;
+    const size_t old_lenp = g->lenp, old_len = g->len;
+    const int L = g->L;
+    struct Window { size_t a, b, at; int owner; };
+    const size_t ghost = opal_grid_min_size() / 2;  // yee.rs:239: four ghost cells (the minimum subdomain is two ghost layers)
+    std::vector<Window> win;
+    size_t wtotal = 0;
+    for (int i = 1; i < N; i++) {
+        const size_t o = cuts[(size_t)i], n = fresh[(size_t)i];
+        if (n == o) continue;
+        Window w = n > o ? Window{o, n + ghost, wtotal, i} : Window{n - ghost, o, wtotal, i - 1};
+        wtotal += 10 * (w.b - w.a);
+        win.push_back(w);
+    }
+    std::vector<double> wbuf(wtotal, 0.0);
+    for (const Window &w : win)
+        if (w.owner == rank)
+            for (int comp = 0; comp < 10; comp++)
+                for (size_t c = w.a; c < w.b; c++)
+                    wbuf[w.at + (size_t)comp * (w.b - w.a) + (c - w.a)] = old_rows[(size_t)(comp + 1) * old_lenp + (c - oldL) + (size_t)L];
+    if (wtotal)
+        if (int rc = reduce(wbuf.data(), wbuf.size())) return rc;
+    const size_t new_len = new_size + (size_t)g->L + (size_t)g->R;
+    std::vector<double> rows(10 * new_len, 0.0);
+    for (size_t j = 0; j < new_len; j++) {
+        const long gc = (long)newL + (long)j - (long)L;  // global cell of array index j (outside [newL, newR): ghost / boundary cells)
+        const Window *from = nullptr;
+        for (const Window &w : win)
+            if (w.owner != rank && gc >= (long)w.a && gc < (long)w.b) from = &w;
+        const long jo = gc - (long)oldL + (long)L;  // where my old array held that cell
+        for (int comp = 0; comp < 10; comp++) {
+            double val = 0.0;
+            if (from) val = wbuf[from->at + (size_t)comp * (from->b - from->a) + ((size_t)gc - from->a)];
+            else if (jo >= 0 && jo < (long)old_len) val = old_rows[(size_t)(comp + 1) * old_lenp + (size_t)jo];
+            rows[(size_t)comp * new_len + j] = val;
+        }
+    }
+    if (int rc = grid_recut(g, new_size, (double)newL * s->dx, rows.data())) return rc;
+    if (int rc = link_exchange_particles(link, to_left, to_right, st)) return rc;
+    if (int rc = pops_recut_finish(pops, 3, link, g)) return rc;
+    // what stands within the zone of my new cuts, on both sides: the link's bound until exchanges made with these cuts have
+    // filed their own counts (link_hold); photons born meanwhile come from the electrons there (link_plan)
+    {
+        const size_t zone = (size_t)link_zone_cells(link);
+        unsigned need[2] = {0, 0};
+        const size_t at[2] = {newL, newR};
+        for (int side = 0; side < 2; side++) {
+            if (!(side == 0 ? to_left : to_right)) continue;
+            // (a periodic wrap: the cut at 0 is the cut at ncells)
+            double n = 0.0, ne = 0.0;
+            for (long c = (long)at[side] - (long)zone; c < (long)at[side] + (long)zone; c++) {
+                const size_t cc = (size_t)((c % (long)ncells + (long)ncells) % (long)ncells);
+                n += most[cc];
+                ne += hist[cc];
+            }
+            if (link->nfields >= 12 && link->nslots >= 3) n += (double)zone * ne;
+            need[side] = (unsigned)std::min(n, 4.0e9);
+        }
+        link_hold(link, need);
+    }
+    s->cuts = fresh;
+    for (int r = 0; r < N; r++) s->nxs[(size_t)r] = fresh[(size_t)r + 1] - fresh[(size_t)r];
+    s->recuts++;
+    if (getenv("OPAL_RECUT_DEBUG") && rank == 0) {
+        fprintf(stderr, "[recut] step %zu: imbalance %.3f -> %.3f (planned), sizes", s->step_index, before, after);
+        for (int r = 0; r < N; r++) fprintf(stderr, " %zu", s->nxs[(size_t)r]);
+        fprintf(stderr, "\n");
+    }
+    return OPAL_OK;
+}
+
 // main.rs:238-267
 int opal_sim_step(opal_sim_t *s, size_t n)
 {
@@ -685,6 +899,9 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         ~RhoGuard() { g->want_rho = true; }
     } rho_guard{s->grid};
     for (size_t k = 0; k < n; k++) {
+        // cuts that follow the plasma (off unless asked for: opal_sim_set_recut): between two steps, where nothing is in flight
+        if (s->recut_every && s->numtasks > 1 && s->step_index && s->step_index % s->recut_every == 0)
+            if (int rc = sim_recut(s, false)) return rc;
         s->grid->want_rho = k + 1 == n;
         if (linked && !(s->fused && s->current_deposition && !qed)) {
             // The reference's operator order across subdomains (main.rs:240-267) with the leavers of every
@@ -1081,6 +1298,46 @@ int opal_sim_set_overlap(opal_sim_t *s, int on)
     return OPAL_OK;
 }
 size_t opal_sim_overlapped_steps(const opal_sim_t *s) { return s ? s->n_overlapped : 0; }
+
+int opal_sim_set_recut(opal_sim_t *s, size_t every, double threshold, size_t max_shift)
+{
+    if (!s || (every && !(threshold >= 1.0))) {
+        set_error("opal_sim_set_recut: bad arguments (threshold is max / mean of the subdomains' load: >= 1)");
+        return OPAL_ERR_ARG;
+    }
+    s->recut_every = every;
+    if (every) {
+        s->recut_threshold = threshold;
+        s->recut_max_shift = max_shift ? max_shift : 64;
+    }
+    return OPAL_OK;
+}
+
+int opal_sim_recut_now(opal_sim_t *s)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    return sim_recut(s, true);
+}
+
+int opal_sim_recut_stats(opal_sim_t *s, size_t *checks, size_t *recuts, double *imbalance_last, double *imbalance_worst,
+                         size_t *nx_of_every_subdomain)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    if (checks) *checks = s->recut_checks;
+    if (recuts) *recuts = s->recuts;
+    if (imbalance_last) *imbalance_last = s->imbalance_seen;
+    if (imbalance_worst) *imbalance_worst = s->imbalance_worst;
+    s->imbalance_worst = 0.0;
+    if (nx_of_every_subdomain)
+        for (size_t r = 0; r < s->nxs.size(); r++) nx_of_every_subdomain[r] = s->nxs[r];
+    return OPAL_OK;
+}
 
 // -------------------------------------------------------------------- config
 struct opal_config {

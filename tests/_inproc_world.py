@@ -84,6 +84,53 @@ class InProcLink:
             return 1
 
 
+class InProcCollectives:
+    """opal_sim_set_collectives for the threads of `world`: all-reduce and gather-to-rank-0 as rendezvous (what
+    exchange.TorchCollectives does between processes).  Pass as Simulation(collectives=...)."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank = world, rank
+        if not hasattr(world, "coll"):
+            world.coll = [None] * world.n
+        self.allreduce_cb = _lib.ALLREDUCE_FN(self._allreduce)
+        self.gather_cb = _lib.GATHER_FN(self._gather)
+
+    def _allreduce(self, user, values, n, op):
+        try:
+            w = self.world
+            mine = np.ctypeslib.as_array(values, shape=(n,))
+            w.coll[self.rank] = mine.copy()
+            w.barrier.wait()
+            parts = np.stack(w.coll)  # rank order: every subdomain reduces in the same order and gets the same bits
+            out = parts.sum(axis=0) if op == 0 else parts.min(axis=0) if op == 1 else parts.max(axis=0)
+            w.barrier.wait()
+            mine[:] = out
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            self.world.barrier.abort()
+            return 1
+
+    def _gather(self, user, local, n_local, out, counts, numtasks):
+        try:
+            w = self.world
+            w.coll[self.rank] = np.ctypeslib.as_array(local, shape=(n_local,)).copy() if n_local else np.zeros(0)
+            w.barrier.wait()
+            if self.rank == 0:
+                cnt = [counts[r] for r in range(numtasks)]
+                dst = np.ctypeslib.as_array(out, shape=(sum(cnt),))
+                at = 0
+                for r in range(numtasks):
+                    dst[at:at + cnt[r]] = w.coll[r][:cnt[r]]
+                    at += cnt[r]
+            w.barrier.wait()
+            return 0
+        except Exception:
+            traceback.print_exc(file=sys.stderr)
+            self.world.barrier.abort()
+            return 1
+
+
 def run_world(n, body, timeout=600.0):
     """Runs body(rank, world) -> result on n threads; returns the results in rank order, or raises the first error."""
     world = World(n)

@@ -482,6 +482,39 @@ def test_native_launcher_matches_the_python_one(tmp_path, world, transport):
     shutil.rmtree(a)
 
 
+def test_called_transports_grow_too(tmp_path):
+    """Every transport whose buffers are the library's grows an edge that is too small (link.cpp: link_plan / link_grow), not
+    the peer mailboxes alone: the native launcher's host-staged link (the fallback of GPUs that cannot map each other; RCCL's
+    takes the same path) created with room for 64 leavers under a plasma that sends ~100 per step, species and cut.  The
+    run must give the files of the same run over the mailboxes; with growth off it ends in the overflow error."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _gloo_hip_worker import YAML
+    exe = os.path.join(ROOT, "opal_amd", "bin", "opal_amd")
+    assert os.path.exists(exe), "opal_amd/bin/opal_amd is built by __graft_entry__.build()"
+    text = YAML.format(nx=64, npc=1024).replace("end: 1.0e-12", "end: 15.5 * 0.95e-8 / c")
+    outs = {}
+    for kind, extra in (("socket", {}), ("peer", {}), ("nogrow", {"OPAL_LINK_NO_GROWTH": "1"})):
+        d = tmp_path / kind
+        d.mkdir()
+        (d / "hot.yaml").write_text(text)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OPAL_LINK="peer" if kind == "peer" else "socket",
+                   OPAL_LINK_CAPACITY="64", **extra)
+        res = subprocess.run([exe, "-n", "2", str(d / "hot.yaml")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                             timeout=300)
+        outs[kind] = (res.returncode, res.stdout.decode())
+    assert outs["socket"][0] == 0, outs["socket"][1][-3000:]
+    assert "host-staged messages" in outs["socket"][1]
+    assert outs["peer"][0] == 0, outs["peer"][1][-3000:]
+    assert outs["nogrow"][0] != 0 and "leaver buffer overflow" in outs["nogrow"][1], outs["nogrow"][1][-3000:]
+    for i in range(3):
+        ra, rb = np.loadtxt(tmp_path / "socket" / f"{i}_grid.dat"), np.loadtxt(tmp_path / "peer" / f"{i}_grid.dat")
+        assert ra.shape == rb.shape == (64, 11)
+        for c in range(1, 11):
+            scale = max(np.max(np.abs(rb[:, c])), 1e-300)
+            assert np.max(np.abs(ra[:, c] - rb[:, c])) <= 1e-9 * scale, (i, c)
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_launcher_runs_an_input_file(tmp_path, world):
     """`python -m opal_amd input.yaml`, alone and as 2 ranks (gloo rehearsal of the torchrun + RCCL launch):
