@@ -745,7 +745,10 @@ static int sim_recut(opal_sim_t *s, bool force)
     if (int rc = opal_recut_plan(N, cuts.data(), cost.data(), most.data(), opal_grid_min_size(), s->recut_max_shift, room.data(),
                                  fresh.data(), &before, &after))
         return rc;
-    if (fresh == cuts || (!force && !(after < before - 0.01))) return OPAL_OK;  // nothing to gain
+    // (No test of `after` against `before`: a cut that cannot reach its place in one go -- max_shift, its edge's room -- may
+    // leave its neighbour with more than it had for a check or two; every cut only ever moves towards the place the rule
+    // gives it, so the partition converges all the same, and holding out for an immediate gain would pin it where it is.)
+    if (fresh == cuts) return OPAL_OK;
     // ---- C
     const size_t oldL = cuts[(size_t)rank], oldR = cuts[(size_t)rank + 1], newL = fresh[(size_t)rank], newR = fresh[(size_t)rank + 1];
     const size_t new_size = newR - newL;

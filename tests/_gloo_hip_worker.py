@@ -97,6 +97,20 @@ constants:
 """
 
 
+def maybe_recut(sim, world):
+    """OPAL_TEST_RECUT=every,threshold,max_shift: the run moves its cuts (Simulation.set_recut)"""
+    spec = os.environ.get("OPAL_TEST_RECUT")
+    if spec and world > 1:
+        every, threshold, max_shift = spec.split(",")
+        sim.set_recut(int(every), float(threshold), int(max_shift))
+
+
+def recut_report(sim, world):
+    st = sim.recut_stats(world)
+    return {"sizes": np.array(st["sizes"]), "recuts": st["recuts"], "checks": st["checks"], "size": sim.grid.size,
+            "L": sim.grid.left_bdy_size}
+
+
 def dump(outdir, rank, g, pe, pi, extra=None):
     out = {k: g.raw(k) for k in ("Ex", "Ey", "Ez", "By", "Bz", "jx", "jy", "jz", "rho")}
     for name, p in (("e", pe), ("i", pi)):
@@ -179,8 +193,11 @@ def main():
         for k, v in sim.photons.soa().items():
             out[f"init_ph_{k}"] = v
         nsteps = sim.total_steps if steps <= 0 else steps
+        out["init_size"] = sim.grid.size
+        maybe_recut(sim, world)
         sim.step(nsteps)
         sim.sync()
+        out.update(recut_report(sim, world))
         tau, ids = sim.electrons.emission_state()
         for k, v in sim.electrons.soa().items():
             out[f"e_{k}"] = v
@@ -195,9 +212,28 @@ def main():
         out["Ey"] = sim.grid.raw("Ey")
         out["t"] = sim.t
         # leavers of all three species in one message; with deposition a second, halo-only one
-        if not peer:
+        if not peer and not os.environ.get("OPAL_TEST_RECUT"):
             assert link.calls == nsteps * (2 if deposit else 1), (link.calls, nsteps)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    elif mode == "recut":
+        # a slab that fills part of a periodic domain cut into equal subdomains: the inner cuts move onto it
+        from test_gpu_recut import NONUNIFORM
+        sim = oa.Simulation(yaml_text=NONUNIFORM, rank=rank, numtasks=world, link=link)
+        sim.set_fused(bool(fused))
+        init = {"init_size": sim.grid.size}
+        for name, p in (("e", sim.electrons), ("i", sim.ions)):
+            for k, v in p.soa().items():
+                init[f"init_{name}_{k}"] = v
+        maybe_recut(sim, world)
+        sim.step(steps)
+        sim.sync()
+        init.update(recut_report(sim, world))
+        init["dt"] = sim.dt
+        if link is not None and hasattr(link, "growth"):
+            init["link_growth"] = np.array(link.growth())
+        dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
+        if link is not None and peer:
+            link.status()  # (raises if a wait for a neighbour's message ever timed out)
     elif mode == "run":
         # the whole of main(): outputs included (grid rows gathered, energies and histograms reduced)
         sim = oa.Simulation(yaml_text=YAML.format(nx=nx, npc=npc).replace("n_outputs: 2", "n_outputs: 3")
@@ -208,7 +244,9 @@ def main():
             for k, v in p.soa().items():
                 init[f"init_{name}_{k}"] = v
         init["steps"] = sim.total_steps
+        maybe_recut(sim, world)
         sim.run()
+        init.update(recut_report(sim, world))
         dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)
     elif mode == "ops":
         nxs, offs = oa.design_unbalanced(world, nx, dx)

@@ -482,6 +482,76 @@ def test_native_launcher_matches_the_python_one(tmp_path, world, transport):
     shutil.rmtree(a)
 
 
+@pytest.mark.parametrize("world,fused", [(2, 1), (3, 1), (3, 0)])
+def test_recutting_world_across_processes(oracle, tmp_path, monkeypatch, world, fused, link_kind):
+    """Cuts that follow the plasma (opal_sim_set_recut; tests/test_gpu_recut.py has the thread-hosted worlds) between
+    PROCESSES: the all-reduces of the plan over torch.distributed, the particles of the cells that change hands through the
+    hipIpc mailboxes (edges created for 128 grow to what a re-cut moves: both ends know the count) or, host-staged, through
+    gloo messages whose buffers cannot grow (the plan is then held to what they hold).  Against the oracle's STATIC world
+    on global arrays: fields 1e-9, every particle in its global cell."""
+    from test_gpu_recut import compare_worlds, oracle_static_world
+    o = oracle
+    steps = 40
+    monkeypatch.setenv("OPAL_TEST_RECUT", "4,1.01,32")
+    monkeypatch.setenv("OPAL_TEST_LINK_CAP", "128" if link_kind == "peer" else "4096")
+    _launch("_gloo_hip_worker.py", world, ["recut", tmp_path, 0, 0, steps, fused])
+    got = []
+    for r in range(world):
+        d = dict(np.load(os.path.join(tmp_path, f"rank{r}.npz")))
+        d["stats"] = {"sizes": [int(v) for v in d["sizes"]], "recuts": int(d["recuts"]), "checks": int(d["checks"])}
+        d["dt"] = float(d["dt"])
+        got.append(d)
+    sizes0 = [int(g["init_size"]) for g in got]
+    assert sizes0 == [768 // world] * world
+    grids, pes, pis, _ = oracle_static_world(o, world, got, sizes0, 0.0, 1.0e-8, (0, 0), (1.0, 1.0, A_POSITRON), steps, 0.0)
+    sizes1 = compare_worlds(o, got, grids, pes, pis, sizes0, field_tol=1e-9, x_tol=1e-9)
+    assert sizes1 != sizes0 and got[0]["stats"]["recuts"] >= 3, (sizes1, got[0]["stats"])
+    if link_kind == "peer":
+        # (a re-cut by 32 cells moves 32 x 12 particles per species: more than the zone of a cut ever holds)
+        assert any(max(int(g["link_growth"][0]), int(g["link_growth"][1])) >= 32 * 12 + 64 for g in got), [g["link_growth"] for g in got]
+    n_moving = np.array([len(g["e_x"]) + len(g["i_x"]) for g in got], dtype=float)
+    n_static = np.array([len(pe) + len(pi) for pe, pi in zip(pes, pis)], dtype=float)
+    assert n_moving.max() / n_moving.mean() < n_static.max() / n_static.mean()
+
+
+def test_recutting_world_with_photon_emission(tmp_path, monkeypatch):
+    """configs[4]'s physics on three subdomains whose cuts go after the beam: electrons change subdomain with their optical
+    depths and ids, photons with theirs (links of 3 species slots, 12 fields per particle), through the re-cut as through
+    the step's own exchange.  The emission is keyed by particle id and step, not by subdomain (sim.cpp), so the re-cutting
+    world must hold the same electrons -- id by id, momentum and optical depth -- and the same photons as the static one."""
+    world = 3
+    monkeypatch.setenv("OPAL_TEST_LINK", "peer")
+    (tmp_path / "static").mkdir()
+    (tmp_path / "moving").mkdir()
+    _launch("_gloo_hip_worker.py", world, ["qed", tmp_path / "static", 0, 0, 0, 0])
+    monkeypatch.setenv("OPAL_TEST_RECUT", "5,1.01,16")
+    _launch("_gloo_hip_worker.py", world, ["qed", tmp_path / "moving", 0, 0, 0, 0])
+    a = [np.load(os.path.join(tmp_path, "static", f"rank{r}.npz")) for r in range(world)]
+    b = [np.load(os.path.join(tmp_path, "moving", f"rank{r}.npz")) for r in range(world)]
+    assert int(b[0]["recuts"]) >= 5 and [int(v) for v in b[0]["sizes"]] != [int(v) for v in a[0]["sizes"]]
+    assert [int(g["size"]) for g in b] == [int(v) for v in b[0]["sizes"]] and sum(int(v) for v in b[0]["sizes"]) == 3 * (2000 // 3)
+
+    def union(parts, name, keys):
+        starts = np.concatenate([[0], np.cumsum([int(v) for v in parts[0]["sizes"]])])
+        out = {k: np.concatenate([p[f"{name}_{k}"] for p in parts]) for k in keys}
+        out["cell"] = np.concatenate([p[f"{name}_cell"].astype(np.int64) + starts[r] for r, p in enumerate(parts)])
+        return out
+    ea, eb = union(a, "e", ("x", "ux", "uy", "w", "tau", "id")), union(b, "e", ("x", "ux", "uy", "w", "tau", "id"))
+    ia, ib = np.argsort(ea["id"]), np.argsort(eb["id"])
+    assert len(ea["id"]) == len(eb["id"]) > 100 and np.array_equal(ea["id"][ia], eb["id"][ib])
+    assert np.array_equal(ea["cell"][ia], eb["cell"][ib])
+    for k in ("x", "ux", "uy", "tau"):
+        fin = np.isfinite(ea[k][ia])
+        assert np.array_equal(fin, np.isfinite(eb[k][ib]))
+        assert np.max(np.abs(ea[k][ia][fin] - eb[k][ib][fin])) <= 1e-9 * max(1.0, np.max(np.abs(ea[k][ia][fin]))), k
+    pa, pb = union(a, "ph", ("x", "ux", "uy", "w")), union(b, "ph", ("x", "ux", "uy", "w"))
+    assert len(pa["x"]) == len(pb["x"]) > 1000
+    oa_, ob_ = np.lexsort((pa["ux"], pa["x"], pa["cell"])), np.lexsort((pb["ux"], pb["x"], pb["cell"]))
+    assert np.array_equal(pa["cell"][oa_], pb["cell"][ob_])
+    for k in ("x", "ux", "uy", "w"):
+        assert np.max(np.abs(pa[k][oa_] - pb[k][ob_])) <= 1e-9 * max(1.0, np.max(np.abs(pa[k][oa_]))), k
+
+
 def test_called_transports_grow_too(tmp_path):
     """Every transport whose buffers are the library's grows an edge that is too small (link.cpp: link_plan / link_grow), not
     the peer mailboxes alone: the native launcher's host-staged link (the fallback of GPUs that cannot map each other; RCCL's
