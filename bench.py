@@ -787,6 +787,10 @@ def main():
         # HIP events around every 5th launch of each tracked kernel (an odd stride samples both species);
         # timing every launch costs ~10 % of the step because each event record breaks back-to-back dispatch
         oa.prof_enable(5)
+        lk_wait = getattr(getattr(sim, "_bench_link", None), "wait", None)
+        if lk_wait:
+            lk_wait(reset=True)  # (drains the stream: in front of the barrier's own wait)
+            barrier()
         t0 = time.perf_counter()
         sim.step(steps)
         sim.sync()
@@ -891,10 +895,27 @@ def main():
             if lk is not None and hasattr(lk, "growth"):
                 cl, cr, ng = lk.growth()
                 mine["link_room_left_right"], mine["link_edges_grown"] = [cl, cr], ng
+            if lk_wait:
+                # how long this subdomain's tail kernel stood waiting for its neighbours' messages, per step: beside
+                # push_avg_ms it tells link latency (the same few microseconds everywhere) from imbalance or skew (long on the
+                # subdomains with few particles, nothing on the fullest)
+                us, nw = lk_wait()
+                mine["tail_wait_us_per_step"] = us / max(steps, 1)
+                mine["tail_waits"] = nw
             dist.all_gather_object(per_rank, mine)
-        return {"value": value, "elapsed": elapsed, "n_total": n_total, "preheat": done, "roofline": roof, "per_rank": per_rank,
-                "ms_per_step": 1e3 * elapsed / steps,
-                "frac_of_hbm_roofline_whole_step": value * bpu / (world * HBM_PEAK_GBS * 1e9)}
+        out = {"value": value, "elapsed": elapsed, "n_total": n_total, "preheat": done, "roofline": roof, "per_rank": per_rank,
+               "ms_per_step": 1e3 * elapsed / steps,
+               "frac_of_hbm_roofline_whole_step": value * bpu / (world * HBM_PEAK_GBS * 1e9)}
+        if per_rank:
+            # the step takes as long as the fullest subdomain's: max / mean of the particles the subdomains held at the end of
+            # the timed steps is the factor a perfectly balanced partition would be faster by
+            held = [float(p["particles"]) for p in per_rank]
+            out["imbalance_max_over_mean"] = max(held) * len(held) / max(sum(held), 1.0)
+            st = sim.recut_stats(world)
+            if st["checks"]:
+                out["recut"] = {"checks": st["checks"], "recuts": st["recuts"], "imbalance_at_last_check": st["imbalance"],
+                                "worst_imbalance_at_a_check": st["imbalance_worst"], "cells_per_subdomain": st["sizes"]}
+        return out
 
     def regroup(sim):
         """A re-binning, so that the push workgroups' chunks are cut for the kernel form about to run (the electrostatic
@@ -910,9 +931,21 @@ def main():
                "roofline": m["roofline"]}
         if m.get("per_rank"):
             out["per_rank"] = m["per_rank"]
+        for k in ("imbalance_max_over_mean", "recut"):
+            if k in m:
+                out[k] = m[k]
         if extra:
             out.update(extra)
         return out
+
+    def recut_spec(env, default):
+        """(every, threshold, max_shift) of a block's moving cuts (Simulation.set_recut), or None: OPAL_BENCH_*_RECUT=0 keeps the
+        reference's partition, made once at t = 0 (grid/mod.rs:157-206)"""
+        v = os.environ.get(env, default)
+        if not v or v == "0":
+            return None
+        e, t, m = v.split(",")
+        return int(e), float(t), int(m)
 
     def timed_only(sim, steps):
         """One more timed region right behind another one (the device is hot): K steps between two barriers."""
@@ -934,6 +967,12 @@ def main():
         priced with its own bytes."""
         oa.set_elision(True)
         simc = oa.Simulation(yaml_text=COLLIDING_BEAMS_YAML.format(npc=CB_NPC), rank=rank, numtasks=world, link=link_cb, stream=stream)
+        # The beam is 500 cells long and crosses the 4000-cell domain at c: under the reference's partition (made once, at
+        # t = 0) it is on one or two subdomains at a time.  The cuts go with it (checked every 32 steps, in which it moves 30
+        # cells; a cut moves 48 at the most).  OPAL_BENCH_CB_RECUT=0: the reference's partition.
+        cb_recut = recut_spec("OPAL_BENCH_CB_RECUT", "32,1.10,48") if world > 1 else None
+        if cb_recut:
+            simc.set_recut(*cb_recut)
         barrier()
         tw = time.perf_counter()
         if os.environ.get("OPAL_BENCH_CB_VERBOSE"):
@@ -1006,8 +1045,18 @@ def main():
         if world > 1:
             pr = [None] * world
             dist.all_gather_object(pr, {"rank": rank, "ms_per_step_own_clock": 1e3 * el_local / CB_STEPS,
-                                        "electrons": simc.electrons.live(), "photons": simc.photons.live()})
+                                        "electrons": simc.electrons.live(), "photons": simc.photons.live(),
+                                        "cells": int(simc.grid.size)})
             res["per_rank"] = pr
+            # (an electron costs the step twice what a photon does: 96 against 48 bytes)
+            load = [p["electrons"] + 0.5 * p["photons"] for p in pr]
+            res["imbalance_max_over_mean"] = max(load) * world / max(sum(load), 1.0)
+            res["subdomains_holding_a_tenth_of_their_share_of_the_electrons"] = sum(
+                1 for p in pr if p["electrons"] >= 0.1 * sum(q["electrons"] for q in pr) / world)
+            st = simc.recut_stats(world)
+            res["recut"] = ({"every_threshold_max_shift": list(cb_recut), "checks": st["checks"], "recuts": st["recuts"],
+                             "imbalance_at_last_check": st["imbalance"], "worst_imbalance_at_a_check": st["imbalance_worst"]}
+                            if cb_recut else "off: the reference's partition, made once at t = 0")
         del simc
         return res
 
@@ -1031,6 +1080,9 @@ def main():
     if args.workload == "laser_plasma":
         wkey = f"laser_plasma:{npc}"
         sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
+        top_recut = recut_spec("OPAL_BENCH_LP_RECUT", "25,1.08,16") if world > 1 else None
+        if top_recut:  # the cuts follow the particles (see the laser_plasma_interaction block)
+            sim.set_recut(*top_recut)
     else:
         wkey = f"two_stream:{nx}x{npc}"
         text = YAML.format(nx=nx, npc=npc)
@@ -1043,8 +1095,34 @@ def main():
     sim.set_fused(not args.unfused)
     if args.self_exchange and world == 1:
         sim.grid.set_self_exchange(True)
-    if os.environ.get("OPAL_BENCH_OVERLAP", "0") == "1":  # diagnostic: exchange on a second stream under the bulk push
+    # Edges first, exchange on a second stream under the bulk push (opal_sim_set_overlap): worth it only where the exchange
+    # takes longer than the small extra launch costs -- which one GPU cannot tell (there the exchange kernel and the bulk push
+    # compete for the same CUs).  So the run measures it where it is: 40 steps each way once the job is warm, the slower of
+    # the subdomains deciding, and keeps the faster.  OPAL_BENCH_OVERLAP=0 / 1 forces it off / on.
+    overlap_note = None
+    ov = os.environ.get("OPAL_BENCH_OVERLAP", "auto")
+    if ov == "1":
         sim.set_overlap(True)
+        overlap_note = {"kept": "on", "why": "OPAL_BENCH_OVERLAP=1"}
+    elif ov == "auto" and world > 1 and not args.unfused and args.workload == "two_stream":
+        sim.step(30)
+        sim.sync()
+        timing = {}
+        for on in (False, True, False, True):
+            sim.set_overlap(on)
+            sim.step(20)  # (the first steps after the switch re-bin with host maps, or stop doing so)
+            sim.sync()
+            barrier()
+            t0 = time.perf_counter()
+            sim.step(40)
+            sim.sync()
+            barrier()
+            timing.setdefault(on, []).append(all_max(time.perf_counter() - t0) / 40)
+        off_ms, on_ms = 1e3 * min(timing[False]), 1e3 * min(timing[True])
+        keep = on_ms < 0.98 * off_ms  # (every rank holds the same two numbers: all_max)
+        sim.set_overlap(keep)
+        overlap_note = {"kept": "on" if keep else "off", "ms_per_step_off": off_ms, "ms_per_step_on": on_ms,
+                        "how": "2 x 40 steps each way after a warm-up, max over ranks, best of two; on is kept if 2 % faster"}
 
     # One population, two measurements.  First the library's default path (elision on: an electrostatic launch can
     # only serve a population nothing but electrostatic launches have pushed), then -- the headline -- the general
@@ -1122,6 +1200,7 @@ def main():
                 "parallelism": f"{world} subdomain(s), 1 per GPU" if backend == "nccl" or world == 1 else f"{world} subdomains on {ndev} GPU(s)",
                 "link": link_desc,
                 "link_particle_capacity": link_capacity if link is not None else None,
+                "overlap": overlap_note,
                 "rccl_ranks": rccl_ranks,
                 "gpus_seen": gpus_seen,
                 "ranks": ranks_seen,
@@ -1225,6 +1304,12 @@ def main():
             sim3._bench_link = link3
             sizes = [None] * world
             dist.all_gather_object(sizes, int(sim3.grid.size))
+            # `balance: true` cuts on the electrons' density at t = 0 (grid/mod.rs:157-206); the pulse then piles the slab up in
+            # front of it and the first subdomains empty into the next ones.  The cuts follow (a check every 25 steps, a cut 16
+            # cells at a time).  OPAL_BENCH_LP_RECUT=0: the reference's partition.
+            lp_recut = recut_spec("OPAL_BENCH_LP_RECUT", "25,1.08,16")
+            if lp_recut:
+                sim3.set_recut(*lp_recut)
             m3 = measure(sim3, lp_steps, lp_warm, preheat=False, workload_key=f"laser_plasma:{lp_npc}")
             t3 = sim3.t
             del sim3, link3
@@ -1233,8 +1318,10 @@ def main():
                 m3, f"laser_plasma (hole_boring.yaml physics, BASELINE configs[3]) on "
                     + (f"{world} GPUs" if backend == "nccl" else f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)")
                     + f", {lp_npc} e- + {lp_npc} "
-                    f"C6+ per cell in 5000 of 20000 cells, balanced decomposition (subdomain sizes {sizes}), {lp_warm} "
-                    f"untimed steps to bring the pulse onto the slab, then {lp_steps} timed steps ending at "
+                    f"C6+ per cell in 5000 of 20000 cells, balanced decomposition (subdomain sizes at t = 0: {sizes}"
+                    + (f"; the cuts then follow the particles: a check every {lp_recut[0]} steps, re-cut above max / mean = "
+                       f"{lp_recut[1]}, {lp_recut[2]} cells at a time" if lp_recut else "; kept for the whole run, as the reference does")
+                    + f"), {lp_warm} untimed steps to bring the pulse onto the slab, then {lp_steps} timed steps ending at "
                     f"t = {t3:.3e} s; " + CONTRACT, lp_steps, {"link": kind3, "n_gpus": world})
 
         guarded("laser_plasma_interaction", float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300")), lp_body)

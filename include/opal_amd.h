@@ -147,6 +147,12 @@ int opal_pop_new(opal_pop_t **out, int species, size_t npc, opal_fn1 number_dens
 int opal_loader_generate(int species, size_t npc, opal_fn1 number_density, opal_fn3 ux, opal_fn3 uy, opal_fn3 uz,
                          void *user, double grid_xmin, double dx, size_t ncells, uint64_t seed, size_t capacity,
                          size_t *n_out, int32_t *cell, double *x, double *pux, double *puy, double *puz, double *w);
+/* Host threads the loaders use (Population::new is a serial loop in the reference, mod.rs:172-203; the particles are the
+ * same bit for bit whatever the count: every particle takes a fixed number of draws from the one generator, so its state at
+ * any cell is known).  0 (default): the cores there are, 16 at the most, for a Simulation's own expressions, and one for
+ * opal_pop_new / opal_loader_generate, whose callbacks belong to the caller; n > 0: that many everywhere -- the callbacks
+ * must then be callable from any thread. */
+int opal_set_loader_threads(int n);
 /* Ion::with_charge_state applied to every ion (main.rs:142-147, ion.rs:236-241) */
 int opal_pop_set_charge_state(opal_pop_t *p, double z_star, double z, double a);
 /* T::create for n particles (electron.rs:85-103, ion.rs:81-101): prev_x is derived from u, dx, dt */
@@ -325,6 +331,11 @@ int opal_link_peer_connect(opal_link_t *l, const void *left_handle64, const void
  * call then fails with OPAL_ERR_LINK), the kind of memory the mailboxes live in (0 uncached, 1 fine-grained, 2
  * plain), and the number of exchanges made so far. */
 int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32_t *exchanges);
+/* How long this subdomain has waited for its neighbours' messages inside the step's kernels (peer_device.hpp: peer_wait;
+ * the blocking MPI_Recv of yee.rs:366-402 and mod.rs:311-347 in the reference): microseconds in total and the number of
+ * waits, since creation or the last call with reset != 0.  On real hardware the wait is link latency where it is the same
+ * few microseconds on every subdomain, imbalance or skew where some wait long and others not at all.  Drains the stream. */
+int opal_link_peer_wait(opal_link_t *l, double *microseconds, uint64_t *waits, int reset);
 /* n halo-only exchanges with the neighbours on the link's stream: 0 if they completed and -- links with device buffers
  * -- every halo word that arrived is the one the neighbour on that side sent in that round (each round's halo names its
  * sender, side and round: a late, stale or torn message fails); links with device buffers then make 4 n exchanges back

@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nproc-per-node 8 -m opal_amd input.yaml       # one subdomain per GPU
 
 One process per GPU; the subdomains exchange through peer-mapped mailboxes over xGMI (or RCCL where the GPUs cannot
-address each other; OPAL_LINK=peer|rccl|torch forces one); outputs are written next to the input file by rank 0, as the
+address each other; OPAL_LINK=peer|rccl|torch forces one; OPAL_RECUT=every[,threshold[,max_shift]] lets the cuts between
+the subdomains follow the particles); outputs are written next to the input file by rank 0, as the
 reference does (main.rs:60-61)."""
 import os
 import sys
@@ -60,6 +61,12 @@ def main(argv):
     try:
         sim = oa.Simulation(yaml_path=argv[1], rank=rank, numtasks=world, link=link,
                             stream=torch.cuda.current_stream().cuda_stream)
+        if world > 1 and os.environ.get("OPAL_RECUT"):
+            # OPAL_RECUT=every[,threshold[,max_shift]]: the cuts follow the particles (Simulation.set_recut); unset: the
+            # reference's partition, made once at t = 0 (grid/mod.rs:157-206)
+            spec = os.environ["OPAL_RECUT"].split(",")
+            if int(spec[0]):
+                sim.set_recut(int(spec[0]), float(spec[1]) if len(spec) > 1 else 1.1, int(spec[2]) if len(spec) > 2 else 64)
         if rank == 0:
             print(f"Running {world} task{'s' if world > 1 else ''} on {world} GPU{'s' if world > 1 else ''}...")
         if world > 1:

@@ -143,6 +143,8 @@ SIGNATURES = {
     "opal_sim_photons": (vp, [vp]),
     "opal_sim_set_overlap": (C.c_int, [vp, C.c_int]),
     "opal_sim_overlapped_steps": (sz, [vp]),
+    "opal_link_peer_wait": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(C.c_uint64), C.c_int]),
+    "opal_set_loader_threads": (C.c_int, [C.c_int]),
     "opal_sim_set_recut": (C.c_int, [vp, sz, dbl, sz]),
     "opal_sim_recut_now": (C.c_int, [vp]),
     "opal_sim_recut_stats": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(sz)]),

@@ -2,7 +2,10 @@
 // the particle loader.  Plain C++ on the CPU; runs once per simulation.
 #include "host_setup.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 
@@ -106,40 +109,116 @@ int design_balanced(int numtasks, size_t size, double xmin, double dx, size_t mi
 // in out.tau: it only matters when photon emission is on; none for ions,
 // ion.rs:157-159; four for photons, photon.rs:126-133: the last two, the depths
 // against absorption and stimulated emission, are kept in out.tau / out.tau2).
+//
+// threads > 1: the same particles, bit for bit, from several host threads.  Every particle takes a fixed number of
+// draws from the one generator (1 for x, 3 for each (urand, nrand) pair -- Box-Muller spends two uniforms on a normal --,
+// 1 / 0 / 4 exponentials), so the generator's state at the start of any cell is the state at the start of the run
+// advanced by a known count.  One thread does nothing but advance it (a nanosecond a draw) and hands out the states at
+// the block boundaries as it passes them; the others take the blocks in order and do the expensive part -- logarithms,
+// cosines, the momentum expressions -- writing straight to each particle's place.  (xoshiro256** has no cheap jump by an
+// arbitrary count; advancing it is cheap enough.)
 void load_population(int species, size_t npc, const std::function<double(double)> &number_density,
                      const Fn3 &ux, const Fn3 &uy, const Fn3 &uz, double grid_xmin, double dx, size_t ncells,
-                     Rng &rng, HostSoA &out)
+                     Rng &rng, HostSoA &out, int threads)
 {
-    for (long c = 0; c < (long)ncells; c++) {
+    std::vector<double> weight(ncells);
+    std::vector<size_t> first(ncells + 1, 0);
+    for (size_t c = 0; c < ncells; c++) {
         double x = grid_xmin + (((double)c) + 0.5) * dx;
         double nreal = number_density(x) * dx;
-        double weight = nreal / ((double)npc);
-        size_t nsuper = nreal > 0.0 ? npc : 0;
-        for (size_t i = 0; i < nsuper; i++) {
-            double xf = rng.uniform();
-            double real_x = grid_xmin + (((double)c) + xf) * dx;
-            double ur = rng.uniform(), nr = rng.normal();
-            double vx = ux(real_x, ur, nr);
-            ur = rng.uniform(); nr = rng.normal();
-            double vy = uy(real_x, ur, nr);
-            ur = rng.uniform(); nr = rng.normal();
-            double vz = uz(real_x, ur, nr);
-            if (species == 0) out.tau.push_back(rng.exp1());
-            else if (species == 2) {
-                // photon.rs:126-133: tau[0], tau[1] (never read), tau_abs, tau_st
-                (void)rng.exp1();
-                (void)rng.exp1();
-                out.tau.push_back(rng.exp1());
-                out.tau2.push_back(rng.exp1());
-            }
-            out.cell.push_back((int32_t)c);
-            out.x.push_back(xf);
-            out.ux.push_back(vx);
-            out.uy.push_back(vy);
-            out.uz.push_back(vz);
-            out.w.push_back(weight);
-        }
+        weight[c] = nreal / ((double)npc);
+        first[c + 1] = first[c] + (nreal > 0.0 ? npc : 0);
     }
+    const size_t base = out.size(), total = first[ncells];
+    out.cell.resize(base + total);
+    out.x.resize(base + total);
+    out.ux.resize(base + total);
+    out.uy.resize(base + total);
+    out.uz.resize(base + total);
+    out.w.resize(base + total);
+    const size_t tau_base = out.tau.size(), tau2_base = out.tau2.size();
+    if (species == 0 || species == 2) out.tau.resize(tau_base + total);
+    if (species == 2) out.tau2.resize(tau2_base + total);
+    const size_t draws = 10 + (species == 0 ? 1 : species == 2 ? 4 : 0);
+    auto fill = [&](size_t c0, size_t c1, Rng r) {
+        for (size_t c = c0; c < c1; c++) {
+            for (size_t i = first[c]; i < first[c + 1]; i++) {
+                double xf = r.uniform();
+                double real_x = grid_xmin + (((double)c) + xf) * dx;
+                double ur = r.uniform(), nr = r.normal();
+                double vx = ux(real_x, ur, nr);
+                ur = r.uniform(); nr = r.normal();
+                double vy = uy(real_x, ur, nr);
+                ur = r.uniform(); nr = r.normal();
+                double vz = uz(real_x, ur, nr);
+                if (species == 0) out.tau[tau_base + i] = r.exp1();
+                else if (species == 2) {
+                    // photon.rs:126-133: tau[0], tau[1] (never read), tau_abs, tau_st
+                    (void)r.exp1();
+                    (void)r.exp1();
+                    out.tau[tau_base + i] = r.exp1();
+                    out.tau2[tau2_base + i] = r.exp1();
+                }
+                out.cell[base + i] = (int32_t)c;
+                out.x[base + i] = xf;
+                out.ux[base + i] = vx;
+                out.uy[base + i] = vy;
+                out.uz[base + i] = vz;
+                out.w[base + i] = weight[c];
+            }
+        }
+        return r;
+    };
+    if (threads <= 1 || total < 200000) {
+        rng = fill(0, ncells, rng);
+        return;
+    }
+    // blocks of whole cells holding about the same number of particles each, many more than threads (the tail is short)
+    const size_t nblk_want = (size_t)threads * 16;
+    std::vector<size_t> cut{0};
+    for (size_t b = 1; b < nblk_want; b++) {
+        size_t c = (size_t)(std::lower_bound(first.begin(), first.end(), total / nblk_want * b) - first.begin());
+        if (c > ncells) c = ncells;
+        if (c > cut.back()) cut.push_back(c);
+    }
+    if (cut.back() < ncells) cut.push_back(ncells);
+    const size_t nblk = cut.size() - 1;
+    std::vector<Rng> start(nblk);
+    std::atomic<size_t> ready{0}, next{0};
+    std::vector<std::thread> workers;
+    for (int t = 0; t < threads - 1; t++)
+        workers.emplace_back([&]() {
+            for (;;) {
+                const size_t b = next.fetch_add(1);
+                if (b >= nblk) return;
+                while (ready.load(std::memory_order_acquire) <= b) std::this_thread::yield();
+                fill(cut[b], cut[b + 1], start[b]);
+            }
+        });
+    Rng r = rng;
+    for (size_t b = 0; b < nblk; b++) {
+        start[b] = r;
+        ready.store(b + 1, std::memory_order_release);
+        for (size_t k = (first[cut[b + 1]] - first[cut[b]]) * draws; k; k--) (void)r.next();
+    }
+    rng = r;
+    // (the thread that advanced the generator helps with what is left)
+    for (;;) {
+        const size_t b = next.fetch_add(1);
+        if (b >= nblk) break;
+        fill(cut[b], cut[b + 1], start[b]);
+    }
+    for (std::thread &w : workers) w.join();
+}
+
+static int g_loader_threads = 0;  // 0: automatic for the driver's own expressions, one thread for a caller's callbacks
+void set_loader_threads(int n) { g_loader_threads = n < 0 ? 0 : n; }
+int loader_threads(bool own_expressions)
+{
+    if (g_loader_threads > 0) return g_loader_threads;
+    if (!own_expressions) return 1;  // a host language's callbacks need not be callable from other threads
+    unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min(16u, std::max(1u, hw));
 }
 
 }  // namespace opal

@@ -8,7 +8,7 @@
 //     same way), else host-staged messages over the sockets between neighbours -- every rank ends up with the same kind;
 //   * the output-time reductions (MPI_Reduce of the energies main.rs:23-31, the gather of the grid rows yee.rs:749-779, the
 //     histogram all-reductions hgram.rs:190-192, 249, 260) over a star of sockets through rank 0.
-// Environment: OPAL_LINK=peer|rccl|socket forces a transport, OPAL_LINK_CAPACITY the room for leavers per cut and step,
+// Environment: OPAL_RECUT=every[,threshold[,max_shift]] lets the cuts follow the particles (off by default), OPAL_LINK=peer|rccl|socket forces a transport, OPAL_LINK_CAPACITY the room for leavers per cut and step,
 // OPAL_RCCL_LIB the RCCL to dlopen (default librccl.so).
 #include <poll.h>
 #include <signal.h>
@@ -281,6 +281,16 @@ int run_rank(Comm &c, const char *path)
     opal_sim_t *sim = nullptr;
     int rc = opal_sim_create(&sim, path, c.rank, c.size, lc.link, stream);
     if (rc == OPAL_OK && c.size > 1) rc = opal_sim_set_collectives(sim, cb_allreduce, cb_gather, &c);
+    if (rc == OPAL_OK && c.size > 1) {
+        // OPAL_RECUT=every[,threshold[,max_shift]]: the cuts follow the particles (opal_sim_set_recut); unset: the reference's
+        // partition, made once at t = 0 (grid/mod.rs:157-206)
+        if (const char *e = getenv("OPAL_RECUT")) {
+            unsigned long every = 0, shift = 64;
+            double thr = 1.1;
+            const int got = sscanf(e, "%lu,%lf,%lu", &every, &thr, &shift);
+            if (got >= 1 && every) rc = opal_sim_set_recut(sim, every, thr, shift);
+        }
+    }
     if (rc == OPAL_OK && c.size > 1) {
         // the waits of the step's exchange are bounded: start together, however long each subdomain's loader took
         rc = opal_sim_sync(sim);

@@ -174,6 +174,10 @@ struct opal_pop {
     int last_interval;         // steps between the last two re-binnings (0: none yet): short = a hot population (particles.hip: ROTATE_BELOW)
     bool want_host_maps;       // keep h_cell_end / h_tab_slot current (the overlapped step's edge / bulk split reads them):
                                // re-binnings then wait for the device
+    // the step in which the cuts move (sim.cpp: sim_recut): this step's pushes store cells counted from the NEW left cut (old
+    // cell reframe_shift) and test leavers against the NEW size; arrivals are unpacked into that frame (particles.hip: PushArgs)
+    bool reframe;
+    int reframe_shift, reframe_size;
     int *d_dbg;                // opal_pop_debug_misses
     // Every particle uploaded so far carries the same weight w0 (a uniform plasma loaded with a fixed number per
     // cell): the pushes then take it from their arguments instead of streaming 8 bytes per particle.  Arrivals

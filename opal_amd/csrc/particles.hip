@@ -103,6 +103,11 @@ struct PushArgs {
     size_t lenp;
     int ppt;
     int size, L, len;
+    // The frame the results are stored in.  Normally the subdomain's own (out_shift = 0, out_size = size).  In the step in
+    // which the cuts move (sim.cpp: sim_recut) the grid is still the old one -- gather, deposit, tiles: `size` -- while the
+    // cell a particle is stored with, and the test of who has left, already belong to the NEW subdomain: its first cell is
+    // the old cell out_shift, it has out_size cells.  A beam that the cuts follow changes nobody's subdomain that way.
+    int out_shift, out_size;
     double dt, dt_over_dx, inv_dt, inv_dx, alpha, charge;
     int left_mode, right_mode;
     int zone;  // cells from a linked edge within which particles are counted into the message header (link_plan); 0: nobody asks
@@ -304,16 +309,17 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
     int send_side = -1;
     // (the ballot makes the test a scalar branch: away from the subdomain's edges no lane of the wave has left, and
     // the selects below are not even issued)
-    if (GATHER && __ballot((unsigned)newc >= (unsigned)a.size) && (unsigned)newc >= (unsigned)a.size) {
+    if (GATHER) newc -= a.out_shift;  // (the frame the result is stored in: PushArgs)
+    if (GATHER && __ballot((unsigned)newc >= (unsigned)a.out_size) && (unsigned)newc >= (unsigned)a.out_size) {
         const bool left = newc < 0;
         const int mode = left ? a.left_mode : a.right_mode;
         if (mode == EDGE_WRAP) {
-            newc += left ? a.size : -a.size;
+            newc += left ? a.out_size : -a.out_size;
         } else if (mode == EDGE_DELETE) {
             deleted = true;
         } else {
             send_side = left ? 0 : 1;
-            if (!left) newc -= a.size;  // mod.rs:291-293
+            if (!left) newc -= a.out_size;  // mod.rs:291-293
         }
     }
 
@@ -340,10 +346,10 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             // towards a neighbouring subdomain: count who stands within LINK_ZONE cells of that edge now -- nobody
             // else can cross it in the next LINK_ZONE steps, which is what sizes the coming messages (link.cpp)
             // (a.zone = 0 where there is no linked edge, or its transport does not plan message sizes: no lane passes)
-            if (__ballot(newc < a.zone || newc >= a.size - a.zone)) {
+            if (__ballot(newc < a.zone || newc >= a.out_size - a.zone)) {
                 if (a.left_mode == EDGE_SEND && newc < a.zone)
                     atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + a.zone_word, 1u);
-                if (a.right_mode == EDGE_SEND && newc >= a.size - a.zone)
+                if (a.right_mode == EDGE_SEND && newc >= a.out_size - a.zone)
                     atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + a.zone_word, 1u);
             }
             if (__ballot(newc != c_mem)) stk(cp.cell, kc, newc);
@@ -811,25 +817,25 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
         const double fl = floor(xn);
         const int s = min(max((int)fl, -1), 1);
         xn -= fl;
-        int newc = c + s;
+        int newc = c + s - a.out_shift;  // (the frame the result is stored in: PushArgs)
         bool deleted = false;
         int send_side = -1;
-        if ((unsigned)newc >= (unsigned)a.size) {
+        if ((unsigned)newc >= (unsigned)a.out_size) {
             const bool left = newc < 0;
             const int mode = left ? a.left_mode : a.right_mode;
             if (mode == EDGE_WRAP) {
-                newc += left ? a.size : -a.size;
+                newc += left ? a.out_size : -a.out_size;
             } else if (mode == EDGE_DELETE) {
                 deleted = true;
             } else {
                 send_side = left ? 0 : 1;
-                if (!left) newc -= a.size;
+                if (!left) newc -= a.out_size;
             }
         }
         if (!deleted && send_side < 0) {
             if (a.left_mode == EDGE_SEND && newc < a.zone)
                 atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + a.zone_word, 1u);
-            if (a.right_mode == EDGE_SEND && newc >= a.size - a.zone)
+            if (a.right_mode == EDGE_SEND && newc >= a.out_size - a.zone)
                 atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + a.zone_word, 1u);
             if (__ballot(newc != c)) stk(cellp, kc, newc);
             stk(xp, kc, xn);
@@ -1553,10 +1559,11 @@ struct RecutPackArgs {
 __global__ __launch_bounds__(256) void k_recut_pack(RecutPackArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned n_wave_aligned = (a.n + 63u) & ~63u;
+    const unsigned n = min(a.n, a.ctr->n_slots);  // (a.n: the host's upper bound of the slots in use)
+    const unsigned n_wave_aligned = (n + 63u) & ~63u;
     int err = 0;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_wave_aligned; i += gridDim.x * blockDim.x) {
-        const int c = i < a.n ? a.cell[i] : DEAD_CELL;
+        const int c = i < n ? a.cell[i] : DEAD_CELL;
         int side = -1;
         if (c != DEAD_CELL) {
             if (c < a.give_left) side = 0;
@@ -1814,6 +1821,8 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     a.lenp = g->lenp;
     a.ppt = p->ppt;
     a.size = (int)g->size; a.L = g->L; a.len = (int)g->len;
+    a.out_shift = p->reframe ? p->reframe_shift : 0;
+    a.out_size = p->reframe ? p->reframe_size : a.size;
     a.dt = dt;
     a.dt_over_dx = dt / g->dx;
     a.inv_dt = 1.0 / dt;
@@ -2070,7 +2079,7 @@ int prepare_unpack(opal_pop_t *p, opal_link_t *link, const opal_grid_t *g, Unpac
     u.w_uniform = p->w_uniform;
     u.w0 = p->w0;
     u.es_flag = g->d_esflag;
-    u.my_size = (int)g->size;
+    u.my_size = p->reframe ? p->reframe_size : (int)g->size;  // (arrivals come in the frame of the subdomain as it is after this step)
     u.emit_list = (p->emit_list_valid && p->emit_list_cap >= p->cap) ? p->d_emit_list : nullptr;
     if (!u.emit_list) p->emit_list_valid = false;  // arrivals the list does not know about
     p->sorted_exact = false;
@@ -2412,7 +2421,16 @@ int wait_published(const opal_pop_t *p)
 // next publication (into the PublishScope alive around the call, or by a launch of its own) and says whether the
 // population should be re-binned now.  The caller re-bins (do_sort) -- after anything it still has to launch for this
 // step (the linked step's tail kernel carries the publication and must see the slots where the push left them).
+int policy_step_inner(opal_pop_t *p, bool &sort_now);
 int policy_step(opal_pop_t *p, bool &sort_now)
+{
+    const int rc = policy_step_inner(p, sort_now);
+    // in the step in which the cuts move the cells already count from the new cut while the grid is the old one (PushArgs:
+    // out_shift): the re-binning, which goes by the grid's size, waits for the next step
+    if (p->reframe) sort_now = false;
+    return rc;
+}
+int policy_step_inner(opal_pop_t *p, bool &sort_now)
 {
     sort_now = false;
     p->steps_since_sort++;
@@ -3196,6 +3214,50 @@ int pop_cell_ends(opal_pop_t *p, const opal_grid_t *g, const unsigned **cell_end
     if (int rc = do_sort(p, g, true)) return rc;
     if (p->n_cell_end == g->size) *cell_end = p->h_cell_end;
     return OPAL_OK;
+}
+// particles of `p` per cell of `g` (live slots; drains the stream): counts[c], c < g->size
+int pop_cell_histogram(opal_pop_t *p, const opal_grid_t *g, std::vector<unsigned> &counts)
+{
+    const size_t ncells = g->size;
+    counts.assign(ncells, 0u);
+    if (p->upper_pending)
+        if (int rc = pop_tighten_upper(p)) return rc;
+    if (p->n_upper == 0) return OPAL_OK;
+    unsigned *d_hist = nullptr;
+    OPAL_HIP(hipMalloc(&d_hist, sizeof(unsigned) * (ncells + 2)));
+    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(unsigned) * (ncells + 2), p->stream);
+    if (e == hipSuccess) {
+        const unsigned nblk = (unsigned)((p->n_upper + 256 * SORT_PPT - 1) / (256 * SORT_PPT));
+        k_sort_hist<<<nblk, 256, 0, p->stream>>>(p->d_cell[p->cur], p->d_ctr, d_hist);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_hist, sizeof(unsigned) * ncells, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    hipFree(d_hist);
+    OPAL_HIP(e);
+    return OPAL_OK;
+}
+// The step in which the cuts move, the particles' side (PushArgs: out_shift): from here to pops_reframe_end the pushes of
+// `pops` store cells counted from the new left cut -- old cell `shift` -- and send what lies outside the `new_size` cells
+// from there on; nothing is re-binned meanwhile.
+void pops_reframe_begin(opal_pop_t *const *pops, int npops, int shift, size_t new_size)
+{
+    for (int i = 0; i < npops; i++)
+        if (pops[i]) {
+            pops[i]->reframe = true;
+            pops[i]->reframe_shift = shift;
+            pops[i]->reframe_size = (int)new_size;
+        }
+}
+void pops_reframe_end(opal_pop_t *const *pops, int npops)
+{
+    for (int i = 0; i < npops; i++)
+        if (pops[i]) {
+            pops[i]->reframe = false;
+            pops[i]->n_cell_end = 0;   // the host's cell map and the re-binning's cell ends were of the old frame
+            pops[i]->count_cells = 0;
+            pops[i]->sorted_exact = false;
+        }
 }
 // packs what the cells given away hold into the link's send messages (after link_begin) and moves the stayers' cell
 // indices to the new frame; `size` is the subdomain's size BEFORE the re-cut

@@ -48,6 +48,7 @@ struct PeerArgs {
     int pack_halo;         // the halo is taken from the grid rows (HaloSrc) instead of the send message
     HaloSrc halo;
     unsigned *err;         // device word: bit 0 = a neighbour's message never came; the word behind it: the senders' ticket
+    unsigned long long *wait;  // device words: [0] ticks (100 MHz) workgroup 0 has spent in peer_wait so far, [1] its waits
 };
 
 #ifdef __HIPCC__
@@ -185,6 +186,14 @@ __device__ inline void peer_wait(const PeerArgs &a)
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope: what the neighbours stored before their sequence numbers
+        // How long this subdomain stood waiting for its neighbours, kept by ONE workgroup of every launch that waits (the
+        // first: it always takes part).  What the number means on real hardware: my push was done and my message out, and
+        // the neighbours' were not yet here -- link latency if it is the same few microseconds on every subdomain, imbalance
+        // or clock skew if some subdomains wait long and others not at all (bench.py: per_rank.tail_wait_us_per_step).
+        if (blockIdx.x == 0 && a.wait) {
+            a.wait[0] += (unsigned long long)(wall_clock64() - t0);
+            a.wait[1] += 1ull;
+        }
     }
     __syncthreads();
 }

@@ -44,7 +44,9 @@ int pops_push_fused_pair_part(opal_pop_t *pe, opal_pop_t *pi, opal_link_t *link,
 int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_right, double ly, double lz);
 // a re-cut of the decomposition (sim_recut): the pieces in particles.hip and grid.hip
 int pop_live_count(opal_pop_t *p, size_t *n);
-int pop_cell_ends(opal_pop_t *p, const opal_grid_t *g, const unsigned **cell_end);
+int pop_cell_histogram(opal_pop_t *p, const opal_grid_t *g, std::vector<unsigned> &counts);
+void pops_reframe_begin(opal_pop_t *const *pops, int npops, int shift, size_t new_size);
+void pops_reframe_end(opal_pop_t *const *pops, int npops);
 int pops_recut_pack(opal_pop_t *const *pops, int npops, opal_link_t *link, size_t size, int give_left, int give_right, int delta);
 int pops_recut_finish(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int grid_recut(opal_grid_t *g, size_t size, double offset, const double *rows);
@@ -191,6 +193,10 @@ struct opal_sim {
     double imbalance_seen = 0.0;    // max / mean of the subdomains' particle cost at the last check (0: never checked)
     double imbalance_worst = 0.0;   // ... the worst seen at any check since opal_sim_recut_stats was last asked
     std::vector<size_t> cuts;       // first global cell of every subdomain, and one past the last one's
+    // a re-cut planned and not yet complete (sim_recut): the step that follows makes the hand-over
+    bool recut_pending = false;
+    std::vector<size_t> pending_cuts;
+    unsigned pending_ship[2] = {0, 0}, pending_hold[2] = {0, 0};
     opal_allreduce_fn allreduce = nullptr;
     opal_gather_fn gather = nullptr;
     void *coll_user = nullptr;
@@ -256,8 +262,9 @@ int load_species(opal_sim_t *s, const char *section, const char *density_key, in
             return f(a);
         };
     };
+    // (the expressions are the driver's own stack programs, Config::func: safe to evaluate from several threads)
     load_population(species, npc, [&](double x) { return ne(&x); }, f3(ux), f3(uy), f3(uz), opal_grid_xmin(s->grid),
-                    s->dx, opal_grid_size(s->grid), rng, soa);
+                    s->dx, opal_grid_size(s->grid), rng, soa, loader_threads(true));
     // headroom for arrivals from neighbouring subdomains between two re-binnings
     size_t cap = soa.size() + soa.size() / 8 + 65536;
     if (int rc = opal_pop_create(out, species, cap, s->stream)) return rc;
@@ -540,7 +547,7 @@ int opal_pop_new(opal_pop_t **out, int species, size_t npc, opal_fn1 number_dens
                     [&](double x, double a, double b) { return ux(x, a, b, user); },
                     [&](double x, double a, double b) { return uy(x, a, b, user); },
                     [&](double x, double a, double b) { return uz(x, a, b, user); }, opal_grid_xmin(grid),
-                    opal_grid_dx(grid), opal_grid_size(grid), rng, soa);
+                    opal_grid_dx(grid), opal_grid_size(grid), rng, soa, loader_threads(false));
     size_t cap = soa.size() + soa.size() / 8 + 65536;
     if (int rc = opal_pop_create(out, species, cap, hip_stream)) return rc;
     return opal_pop_upload_soa(*out, soa.size(), soa.cell.data(), soa.x.data(), soa.ux.data(), soa.uy.data(),
@@ -562,7 +569,8 @@ int opal_loader_generate(int species, size_t npc, opal_fn1 number_density, opal_
     load_population(species, npc, [&](double xx) { return number_density(xx, user); },
                     [&](double xx, double a, double b) { return ux(xx, a, b, user); },
                     [&](double xx, double a, double b) { return uy(xx, a, b, user); },
-                    [&](double xx, double a, double b) { return uz(xx, a, b, user); }, grid_xmin, dx, ncells, rng, soa);
+                    [&](double xx, double a, double b) { return uz(xx, a, b, user); }, grid_xmin, dx, ncells, rng, soa,
+                    loader_threads(false));
     *n_out = soa.size();
     if (soa.size() > capacity) {
         set_error("opal_loader_generate: %zu particles exceed the capacity %zu", soa.size(), capacity);
@@ -574,6 +582,12 @@ int opal_loader_generate(int species, size_t npc, opal_fn1 number_density, opal_
     if (puy) memcpy(puy, soa.uy.data(), sizeof(double) * soa.size());
     if (puz) memcpy(puz, soa.uz.data(), sizeof(double) * soa.size());
     if (w) memcpy(w, soa.w.data(), sizeof(double) * soa.size());
+    return OPAL_OK;
+}
+
+int opal_set_loader_threads(int n)
+{
+    set_loader_threads(n);
     return OPAL_OK;
 }
 
@@ -659,23 +673,121 @@ static int ensure_comm_stream(opal_sim_t *s)
 
 // Cuts that follow the plasma.  The reference balances the decomposition once, on the electrons' initial density
 // (grid/mod.rs:157-206, main.rs:103-110), and so does this driver by default; with opal_sim_set_recut the same partition
-// rule is applied again every few steps to the particles where they stand (recut.cpp), and what changes hands travels the
-// way leavers do.  Collective: every subdomain enters it at the same step.
+// rule is applied again every few steps to the particles where they stand (recut.cpp).  Collective: every subdomain
+// enters it at the same step.
 //   A. the subdomains' particle costs, all-reduced (one small message); below the threshold nothing else happens.
-//   B. every population re-binned exactly (its cell ends ARE the per-cell histogram), the per-species histograms of the
-//      whole domain all-reduced, the new cuts planned -- the same on every subdomain, from the same numbers.
-//   C. edges whose messages are too small for what crosses them grow (both ends know the count); the particles in the
-//      cells given away are packed as leavers with their cell index in the receiver's frame (mod.rs:291-293, 366-368)
-//      and exchanged through the link; the grid's columns that change hands (and the four ghost columns beyond) go
-//      through one more all-reduce of a window only their old owner fills; the grid is rebuilt in place, the arrivals
-//      appended, every population re-binned on the new grid; the link's bound is re-seeded with what stands near the new
-//      cuts (link_hold).  nxs / offsets follow, so {i}_grid.dat still gathers in rank order (yee.rs:749-779).
+//   B. a per-cell histogram of every species (one pass over the cell indices), the histograms of the whole domain
+//      all-reduced, the new cuts planned -- the same on every subdomain, from the same numbers; edges whose messages are too
+//      small for what can cross them grow (both ends know the count).
+//   C. the hand-over, one of two ways:
+//      * IN THE NEXT STEP (the fused linked step, and steps without current deposition: whenever no pass reads the particles'
+//        cells against the grid after the push).  That step's pushes gather and deposit on the grid as it is, but store every
+//        particle's cell counted from the NEW cut and send what lies outside the NEW subdomain (particles.hip: PushArgs
+//        out_shift) -- its ordinary leavers, through its ordinary exchange.  A particle changes subdomain only if it ends the
+//        step on the other side of the new cut: cuts that go with a beam move nobody.  After the step's field solve the grid
+//        columns that change hands (and the four ghost columns beyond) go through one all-reduce of a window only their old
+//        owner fills, and the grid is rebuilt in place.  Nothing is re-binned: a uniform shift keeps the order.
+//      * AT ONCE (the reference's operator order with deposition, photon absorption): particles in the cells given away are
+//        packed as leavers with their cell in the receiver's frame (mod.rs:291-293, 366-368), exchanged, appended, every
+//        population re-binned on the new grid.
+//   The link's bound is re-seeded with what stands near the new cuts (link_hold); nxs / offsets follow, so {i}_grid.dat
+//   still gathers in rank order (yee.rs:749-779).
 // Nothing of the physics depends on where the cuts are (tests/test_gpu_recut.py: a re-cutting world equals the static
 // oracle world), only the summation order of the deposit does.
-static int sim_recut(opal_sim_t *s, bool force)
+namespace {
+
+// the grid's columns to the new cuts: a window per moved cut -- the cells that change hands and the four beyond them, which
+// become the receiver's ghost cells -- filled by their old owner, all-reduced (every other subdomain adds zeros)
+int recut_grid(opal_sim_t *s, const std::vector<size_t> &cuts, const std::vector<size_t> &fresh)
 {
     const int N = s->numtasks, rank = s->rank;
-    if (N < 2) return OPAL_OK;
+    opal_grid_t *g = s->grid;
+    const size_t oldL = cuts[(size_t)rank], newL = fresh[(size_t)rank], newR = fresh[(size_t)rank + 1];
+    const size_t new_size = newR - newL;
+    const double *old_rows = grid_fetch_rows(g);
+    if (!old_rows) return OPAL_ERR_HIP;
+    const size_t old_lenp = g->lenp, old_len = g->len;
+    const int L = g->L;
+    struct Window { size_t a, b, at; int owner; };
+    const size_t ghost = opal_grid_min_size() / 2;  // yee.rs:239: four ghost cells (the minimum subdomain is two ghost layers)
+    std::vector<Window> win;
+    size_t wtotal = 0;
+    for (int i = 1; i < N; i++) {
+        const size_t o = cuts[(size_t)i], n = fresh[(size_t)i];
+        if (n == o) continue;
+        Window w = n > o ? Window{o, n + ghost, wtotal, i} : Window{n - ghost, o, wtotal, i - 1};
+        wtotal += 10 * (w.b - w.a);
+        win.push_back(w);
+    }
+    std::vector<double> wbuf(wtotal, 0.0);
+    for (const Window &w : win)
+        if (w.owner == rank)
+            for (int comp = 0; comp < 10; comp++)
+                for (size_t c = w.a; c < w.b; c++)
+                    wbuf[w.at + (size_t)comp * (w.b - w.a) + (c - w.a)] = old_rows[(size_t)(comp + 1) * old_lenp + (c - oldL) + (size_t)L];
+    if (wtotal && s->allreduce(s->coll_user, wbuf.data(), wbuf.size(), 0)) {
+        set_error("re-cut: the caller's allreduce failed");
+        return OPAL_ERR_LINK;
+    }
+    const size_t new_len = new_size + (size_t)g->L + (size_t)g->R;
+    std::vector<double> rows(10 * new_len, 0.0);
+    for (size_t j = 0; j < new_len; j++) {
+        const long gc = (long)newL + (long)j - (long)L;  // global cell of array index j (outside [newL, newR): ghost / boundary cells)
+        const Window *from = nullptr;
+        for (const Window &w : win)
+            if (w.owner != rank && gc >= (long)w.a && gc < (long)w.b) from = &w;
+        const long jo = gc - (long)oldL + (long)L;  // where my old array held that cell
+        for (int comp = 0; comp < 10; comp++) {
+            double val = 0.0;
+            if (from) val = wbuf[from->at + (size_t)comp * (from->b - from->a) + ((size_t)gc - from->a)];
+            else if (jo >= 0 && jo < (long)old_len) val = old_rows[(size_t)(comp + 1) * old_lenp + (size_t)jo];
+            rows[(size_t)comp * new_len + j] = val;
+        }
+    }
+    return grid_recut(g, new_size, (double)newL * s->dx, rows.data());
+}
+
+// the books after a re-cut: the link's bound re-seeded, the sizes every subdomain gathers the grid rows by
+void recut_done(opal_sim_t *s)
+{
+    link_hold(s->link, s->pending_hold);
+    s->cuts = s->pending_cuts;
+    for (int r = 0; r < s->numtasks; r++) s->nxs[(size_t)r] = s->cuts[(size_t)r + 1] - s->cuts[(size_t)r];
+    s->recuts++;
+    s->recut_pending = false;
+    if (getenv("OPAL_RECUT_DEBUG") && s->rank == 0) {
+        fprintf(stderr, "[recut] step %zu: sizes", s->step_index);
+        for (int r = 0; r < s->numtasks; r++) fprintf(stderr, " %zu", s->nxs[(size_t)r]);
+        fprintf(stderr, "\n");
+    }
+}
+
+// this step's messages ship, and its populations reserve room for, what the histogram says can cross each moving cut
+void recut_caps(opal_sim_t *s)
+{
+    opal_link_t *link = s->link;
+    for (int side = 0; side < 2; side++) {
+        const unsigned cap = (unsigned)link->cap_side[side];
+        const unsigned want = std::max(s->pending_ship[side], link->plan_cap[side]);
+        link->plan_cap[side] = std::min(cap, std::max(want, (unsigned)LINK_ROWS));
+        link->send_cap[side] = link_is_peer(link) ? cap : link->plan_cap[side];
+    }
+}
+
+// after the field solve of the step whose pushes went by the new cuts: the grid follows
+int sim_recut_finish(opal_sim_t *s)
+{
+    opal_pop_t *pops[3] = {s->electrons, s->ions, s->photons};
+    if (int rc = recut_grid(s, s->cuts, s->pending_cuts)) return rc;
+    pops_reframe_end(pops, 3);
+    recut_done(s);
+    return OPAL_OK;
+}
+
+int sim_recut(opal_sim_t *s, bool force)
+{
+    const int N = s->numtasks, rank = s->rank;
+    if (N < 2 || s->recut_pending) return OPAL_OK;  // (pending: planned, the next step makes the hand-over)
     if (!s->link || !s->allreduce) {
         set_error("a re-cut of %d subdomains needs a link and opal_sim_set_collectives (the all-reduce its plan is made from)", N);
         return OPAL_ERR_ARG;
@@ -722,13 +834,12 @@ static int sim_recut(opal_sim_t *s, bool force)
     // ---- B
     const size_t ncells = s->cuts[(size_t)N], size = g->size;
     std::vector<double> hist(3 * ncells, 0.0);
+    std::vector<unsigned> counts;
     for (int sp = 0; sp < 3; sp++) {
         if (!pops[sp]) continue;
-        const unsigned *ce = nullptr;
-        if (int rc = pop_cell_ends(pops[sp], g, &ce)) return rc;
-        if (!ce) continue;
+        if (int rc = pop_cell_histogram(pops[sp], g, counts)) return rc;
         double *h = hist.data() + (size_t)sp * ncells + s->cuts[(size_t)rank];
-        for (size_t c = 0; c < size; c++) h[c] = (double)(ce[c] - (c ? ce[c - 1] : 0u));
+        for (size_t c = 0; c < size; c++) h[c] = (double)counts[c];
     }
     if (int rc = reduce(hist.data(), hist.size())) return rc;
     std::vector<double> cost(ncells), most(ncells);
@@ -740,7 +851,8 @@ static int sim_recut(opal_sim_t *s, bool force)
     std::vector<double> room((size_t)N - 1);
     for (int i = 1; i < N; i++)
         room[(size_t)i - 1] = std::max(0.0, std::min(v[(size_t)N + (size_t)i - 1] - 2.0 * LINK_SLACK, (double)s->recut_max_particles));
-    std::vector<size_t> cuts(s->cuts), fresh((size_t)N + 1);
+    const std::vector<size_t> cuts(s->cuts);
+    std::vector<size_t> fresh((size_t)N + 1);
     double before = 0.0, after = 0.0;
     if (int rc = opal_recut_plan(N, cuts.data(), cost.data(), most.data(), opal_grid_min_size(), s->recut_max_shift, room.data(),
                                  fresh.data(), &before, &after))
@@ -749,23 +861,25 @@ static int sim_recut(opal_sim_t *s, bool force)
     // leave its neighbour with more than it had for a check or two; every cut only ever moves towards the place the rule
     // gives it, so the partition converges all the same, and holding out for an immediate gain would pin it where it is.)
     if (fresh == cuts) return OPAL_OK;
-    // ---- C
     const size_t oldL = cuts[(size_t)rank], oldR = cuts[(size_t)rank + 1], newL = fresh[(size_t)rank], newR = fresh[(size_t)rank + 1];
     const size_t new_size = newR - newL;
     const int give_left = newL > oldL ? (int)(newL - oldL) : 0, take_left = oldL > newL ? (int)(oldL - newL) : 0;
     const int give_right = oldR > newR ? (int)(oldR - newR) : 0;
-    auto most_in = [&](size_t a, size_t b) {  // particles of the fullest species in the global cells [a, b) (a bound on any one species')
+    auto most_in = [&](long a, long b) {  // particles of the fullest species in the global cells [a, b) (a bound on any one species')
         double n = 0.0;
-        for (size_t c = a; c < b && c < ncells; c++) n += most[c];
+        for (long c = std::max(a, 0L); c < b && c < (long)ncells; c++) n += most[(size_t)c];
         return n;
     };
-    unsigned ship[2] = {0, 0};  // slots per species this re-cut's messages carry through my left / right edge
+    // what can cross each of my edges in the hand-over: everything in the cells that change hands and, when the hand-over
+    // is a step's push, the cell either side (a particle moves less than a cell per push)
     size_t grow_to[2] = {0, 0};
-    const size_t moved[2] = {(size_t)most_in(std::min(oldL, newL), std::max(oldL, newL)), (size_t)most_in(std::min(oldR, newR), std::max(oldR, newR))};
+    const size_t at_old[2] = {oldL, oldR}, at_new[2] = {newL, newR};
     for (int side = 0; side < 2; side++) {
+        s->pending_ship[side] = 0;
         if (!(side == 0 ? to_left : to_right)) continue;
-        const size_t slots = (moved[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
-        ship[side] = (unsigned)slots;
+        const long lo = (long)std::min(at_old[side], at_new[side]) - 1, hi = (long)std::max(at_old[side], at_new[side]) + 1;
+        const size_t slots = ((size_t)most_in(lo, hi) + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+        s->pending_ship[side] = (unsigned)slots;
         if (slots > link->cap_side[side]) grow_to[side] = link_room_for(link, slots);
     }
     if (grow_to[0] || grow_to[1]) {
@@ -775,87 +889,46 @@ static int sim_recut(opal_sim_t *s, bool force)
         }
         if (int rc = link_grow(link, grow_to)) return rc;
     }
-    if (int rc = link_begin(link, st, 0)) return rc;  // (species mask 0: this exchange's zone counts are nobody's bound)
-    for (int side = 0; side < 2; side++) {
-        // both ends of an edge ship, and reserve room for, what the histogram says can cross it -- not the edge's whole room
-        const unsigned cap = (unsigned)link->cap_side[side];
-        link->plan_cap[side] = std::min(cap, std::max(ship[side], (unsigned)LINK_ROWS));
-        link->send_cap[side] = link_is_peer(link) ? cap : link->plan_cap[side];
-    }
-    if (int rc = pops_recut_pack(pops, 3, link, size, give_left, give_right, take_left - give_left)) return rc;
-    // the grid's columns: a window per moved cut -- the cells that change hands and the four beyond them, which become the
-    // receiver's ghost cells -- filled by their old owner, all-reduced (every other subdomain adds zeros)
-    const double *old_rows = grid_fetch_rows(g);
-    if (!old_rows) return OPAL_ERR_HIP;
-    const size_t old_lenp = g->lenp, old_len = g->len;
-    const int L = g->L;
-    struct Window { size_t a, b, at; int owner; };
-    const size_t ghost = opal_grid_min_size() / 2;  // yee.rs:239: four ghost cells (the minimum subdomain is two ghost layers)
-    std::vector<Window> win;
-    size_t wtotal = 0;
-    for (int i = 1; i < N; i++) {
-        const size_t o = cuts[(size_t)i], n = fresh[(size_t)i];
-        if (n == o) continue;
-        Window w = n > o ? Window{o, n + ghost, wtotal, i} : Window{n - ghost, o, wtotal, i - 1};
-        wtotal += 10 * (w.b - w.a);
-        win.push_back(w);
-    }
-    std::vector<double> wbuf(wtotal, 0.0);
-    for (const Window &w : win)
-        if (w.owner == rank)
-            for (int comp = 0; comp < 10; comp++)
-                for (size_t c = w.a; c < w.b; c++)
-                    wbuf[w.at + (size_t)comp * (w.b - w.a) + (c - w.a)] = old_rows[(size_t)(comp + 1) * old_lenp + (c - oldL) + (size_t)L];
-    if (wtotal)
-        if (int rc = reduce(wbuf.data(), wbuf.size())) return rc;
-    const size_t new_len = new_size + (size_t)g->L + (size_t)g->R;
-    std::vector<double> rows(10 * new_len, 0.0);
-    for (size_t j = 0; j < new_len; j++) {
-        const long gc = (long)newL + (long)j - (long)L;  // global cell of array index j (outside [newL, newR): ghost / boundary cells)
-        const Window *from = nullptr;
-        for (const Window &w : win)
-            if (w.owner != rank && gc >= (long)w.a && gc < (long)w.b) from = &w;
-        const long jo = gc - (long)oldL + (long)L;  // where my old array held that cell
-        for (int comp = 0; comp < 10; comp++) {
-            double val = 0.0;
-            if (from) val = wbuf[from->at + (size_t)comp * (from->b - from->a) + ((size_t)gc - from->a)];
-            else if (jo >= 0 && jo < (long)old_len) val = old_rows[(size_t)(comp + 1) * old_lenp + (size_t)jo];
-            rows[(size_t)comp * new_len + j] = val;
-        }
-    }
-    if (int rc = grid_recut(g, new_size, (double)newL * s->dx, rows.data())) return rc;
-    if (int rc = link_exchange_particles(link, to_left, to_right, st)) return rc;
-    if (int rc = pops_recut_finish(pops, 3, link, g)) return rc;
     // what stands within the zone of my new cuts, on both sides: the link's bound until exchanges made with these cuts have
     // filed their own counts (link_hold); photons born meanwhile come from the electrons there (link_plan)
     {
-        const size_t zone = (size_t)link_zone_cells(link);
-        unsigned need[2] = {0, 0};
-        const size_t at[2] = {newL, newR};
+        const long zone = (long)link_zone_cells(link) + 1;  // (+ 1: the hand-over step itself, when it is a push)
         for (int side = 0; side < 2; side++) {
+            s->pending_hold[side] = 0;
             if (!(side == 0 ? to_left : to_right)) continue;
-            // (a periodic wrap: the cut at 0 is the cut at ncells)
             double n = 0.0, ne = 0.0;
-            for (long c = (long)at[side] - (long)zone; c < (long)at[side] + (long)zone; c++) {
-                const size_t cc = (size_t)((c % (long)ncells + (long)ncells) % (long)ncells);
+            for (long c = (long)at_new[side] - zone; c < (long)at_new[side] + zone; c++) {
+                const size_t cc = (size_t)((c % (long)ncells + (long)ncells) % (long)ncells);  // (a periodic wrap: the cut at 0 is the cut at ncells)
                 n += most[cc];
                 ne += hist[cc];
             }
             if (link->nfields >= 12 && link->nslots >= 3) n += (double)zone * ne;
-            need[side] = (unsigned)std::min(n, 4.0e9);
+            s->pending_hold[side] = (unsigned)std::min(n, 4.0e9);
         }
-        link_hold(link, need);
     }
-    s->cuts = fresh;
-    for (int r = 0; r < N; r++) s->nxs[(size_t)r] = fresh[(size_t)r + 1] - fresh[(size_t)r];
-    s->recuts++;
-    if (getenv("OPAL_RECUT_DEBUG") && rank == 0) {
-        fprintf(stderr, "[recut] step %zu: imbalance %.3f -> %.3f (planned), sizes", s->step_index, before, after);
-        for (int r = 0; r < N; r++) fprintf(stderr, " %zu", s->nxs[(size_t)r]);
-        fprintf(stderr, "\n");
+    s->pending_cuts = fresh;
+    if (getenv("OPAL_RECUT_DEBUG") && rank == 0)
+        fprintf(stderr, "[recut] step %zu: imbalance %.3f -> %.3f (planned)\n", s->step_index, before, after);
+    // ---- C
+    const bool qed = s->photon_emission || s->photon_absorption;
+    const bool in_the_step = !s->photon_absorption && !getenv("OPAL_RECUT_AT_ONCE") &&
+                             ((s->fused && s->current_deposition && !qed) || !s->current_deposition);
+    if (in_the_step) {
+        pops_reframe_begin(pops, 3, (int)((long)newL - (long)oldL), new_size);
+        s->recut_pending = true;  // opal_sim_step: recut_caps after the step's link_begin, sim_recut_finish after its field solve
+        return OPAL_OK;
     }
+    if (int rc = link_begin(link, st, 0)) return rc;  // (species mask 0: this exchange's zone counts are nobody's bound)
+    recut_caps(s);
+    if (int rc = pops_recut_pack(pops, 3, link, size, give_left, give_right, take_left - give_left)) return rc;
+    if (int rc = recut_grid(s, cuts, fresh)) return rc;
+    if (int rc = link_exchange_particles(link, to_left, to_right, st)) return rc;
+    if (int rc = pops_recut_finish(pops, 3, link, g)) return rc;
+    recut_done(s);
     return OPAL_OK;
 }
+
+}  // namespace
 
 // main.rs:238-267
 int opal_sim_step(opal_sim_t *s, size_t n)
@@ -916,6 +989,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             opal_pop_t *pops[3] = {s->electrons, s->ions, qed ? s->photons : nullptr};
             const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
             if (int rc = link_begin(s->link, st, (s->electrons ? 1u : 0u) | (s->ions ? 2u : 0u) | (qed && s->photons ? 4u : 0u))) return rc;
+            if (s->recut_pending) recut_caps(s);  // (the step in which the cuts move: sim_recut)
             for (opal_pop_t *p : pops)
                 if (p)
                     if (int rc = pop_push_advance_noexchange(p, s->link, g, s->dt)) return rc;
@@ -947,6 +1021,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             if (int rc = grid_sync_advance(g, rl, rr, ly, lz, s->dt)) return rc;
             s->t += s->dt;
             s->step_index++;
+            if (s->recut_pending)
+                if (int rc = sim_recut_finish(s)) return rc;
             continue;
         }
         if (linked && s->fused && s->current_deposition && !qed) {
@@ -958,6 +1034,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             if (int rc = opal_grid_clear(g)) return rc;
             // (free after the first step: the unpack kernel re-zeroes the leaver counts)
             if (int rc = link_begin(s->link, st, (s->electrons ? 1u : 0u) | (s->ions ? 2u : 0u))) return rc;
+            if (s->recut_pending) recut_caps(s);  // (the step in which the cuts move: sim_recut)
             const double *rl = nullptr, *rr = nullptr;
             const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
             const bool peer = link_is_peer(s->link);
@@ -968,7 +1045,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             // GPU: the handful of edge workgroups would leave it idle on their own), and the message follows them
             // on that stream; the exchange -- pack, RCCL kernel, xGMI transfer, a neighbour that is a little
             // late -- is off the critical path as long as it takes less than the bulk push.
-            if (s->overlap && s->electrons && s->ions && pops_plan_split(s->electrons, s->ions, s->link, g) &&
+            // (not in the step in which the cuts move: its leavers come from as deep inside as the cuts go)
+            if (s->overlap && !s->recut_pending && s->electrons && s->ions && pops_plan_split(s->electrons, s->ions, s->link, g) &&
                 ensure_comm_stream(s) == OPAL_OK && link_can_use_stream(s->link, s->comm_stream)) {
                 OPAL_HIP(hipEventRecord(s->ev_edges, st));  // everything before this step (the clear, the last solve)
                 OPAL_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_edges, 0));
@@ -1013,6 +1091,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
             s->t += s->dt;
             s->step_index++;
+            if (s->recut_pending)
+                if (int rc = sim_recut_finish(s)) return rc;
             continue;
         }
         opal_pop_t *both[2] = {s->electrons, s->ions};

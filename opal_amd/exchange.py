@@ -276,6 +276,14 @@ class PeerLink:
         self._lib.opal_link_last_exchange_bytes(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def wait(self, reset=False):
+        """(microseconds spent waiting for the neighbours' messages inside the step's kernels, number of waits) since
+        creation or the last reset (opal_link_peer_wait)."""
+        us, n = C.c_double(), C.c_uint64()
+        if self._lib.opal_link_peer_wait(self.h, C.byref(us), C.byref(n), 1 if reset else 0):
+            raise RuntimeError(self._lib.opal_last_error().decode())
+        return us.value, n.value
+
     def set_bounded(self, on=True):
         pass  # nothing to plan: a message is as long as the leavers it carries
 

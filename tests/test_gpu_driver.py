@@ -220,3 +220,32 @@ def test_device_identity():
     assert "gfx" in name
     assert oa.device_identity(0) == (bus, name) or oa.device_count() > 1
 
+
+
+def test_loader_threads_do_not_change_the_initial_state():
+    """A Simulation loads its species with several host threads by default (host_setup.cpp: the one generator's state at any
+    cell is known, because every particle takes a fixed number of draws).  The particles -- electrons, then the ions, which
+    continue the same generator (main.rs:53, 116-147) -- must be those of the serial loop, bit for bit."""
+    import opal_amd as oa
+    from opal_amd import _lib
+    lib = _lib.load()
+    text = TWO_STREAM.replace("nx: 1000", "nx: 1024").replace("npc: 100", "npc: 400")
+    text = text.replace("ions:\n npc: 0\n", "ions:\n name: positron\n npc: 300\n Z: 1.0\n A: me/mp\n ni: 20.0\n"
+                                             " ux: 0.01 * nrand\n uy: 0.0\n uz: 0.001 * urand\n output: x:px\n")
+    assert "positron" in text
+    states = []
+    for threads in (1, 6):
+        assert lib.opal_set_loader_threads(threads) == 0
+        try:
+            sim = oa.Simulation(yaml_text=text)
+        finally:
+            lib.opal_set_loader_threads(0)
+        states.append((sim.electrons.soa(), sim.ions.soa() if sim.ions is not None else None))
+        del sim
+    (e1, i1), (e6, i6) = states
+    assert len(e1["x"]) == 1024 * 400
+    for a, b in ((e1, e6), (i1, i6)):
+        if a is None:
+            continue
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k

@@ -366,3 +366,54 @@ def test_configs3_shape_laser_plasma(oa, npc):
     sim.sync()
     f2, ke2, ki2 = sim.energies()
     assert (ke2 + ki2) > (ke1 + ki1)
+
+
+def test_configs1_five_steps_against_the_oracle_particle_by_particle(oa):
+    """BASELINE configs[1] at its full size -- 4096 cells, 2441 + 2441 per cell, 2e7 particles -- five steps of the YAML
+    driver's fused path (both species in one launch, the chunk table of a 1e7-slot population, several rounds of
+    workgroups per launch) against the C oracle from the same initial particles: Ex on every cell to 1e-9 of its scale,
+    every particle's cell exactly and its x, ux to 1e-12.  Everywhere else the oracle is compared at 1e3-1e5 particles and
+    the full sizes are held by properties; this is the one place where launch logic that only exists at size meets it.
+    Particles are matched by (cell, x): 2441 uniform offsets per cell lie ~1e-7 apart, the two runs differ by ~1e-15."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle as o
+    o.build()
+    nx, npc, steps, dx = 4096, 2441, 5, 500.0
+    sim = oa.Simulation(yaml_text=TWO_STREAM.format(nx=nx, npc=npc))
+    dt = sim.dt
+    keys = ("cell", "x", "ux", "uy", "uz", "w")
+    init_e, init_i = sim.electrons.soa(), sim.ions.soa()
+    assert len(init_e["x"]) == len(init_i["x"]) == nx * npc
+    og = o.Grid.single(nx, 0.0, dx)
+    pe = o.Population.from_soa(o.ELECTRON, *[init_e[k] for k in keys], dx, dt)
+    pi = o.Population.from_soa(o.ION, *[init_i[k] for k in keys], dx, dt)
+    pi.set_charge_state(1.0, 1.0, A_POSITRON)
+    del init_e, init_i
+    threads = max(1, min(o.max_threads(), 16))
+    t = 0.0
+    for _ in range(steps):
+        assert o.world_step([og], [pe], [pi], True, t, dt, nthreads=threads) == 0
+        t += dt
+    sim.step(steps)
+    sim.sync()
+    ref = og.raw("Ex")[og.left_bdy_size:og.left_bdy_size + nx]
+    got = _interior(sim.grid, "Ex")
+    assert np.max(np.abs(ref)) > 0.0
+    assert np.max(np.abs(got - ref)) <= 1e-9 * np.max(np.abs(ref)), np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+    jref = og.raw("jx")[og.left_bdy_size:og.left_bdy_size + nx]
+    jgot = _interior(sim.grid, "jx")
+    assert np.max(np.abs(jgot - jref)) <= 1e-9 * np.max(np.abs(jref))
+    for mine, theirs in ((sim.electrons, pe), (sim.ions, pi)):
+        a, b = mine.soa(fields=("x", "ux")), theirs.soa()
+        assert len(a["x"]) == len(b["x"]) == nx * npc
+        ia, ib = np.lexsort((a["x"], a["cell"])), np.lexsort((b["x"], b["cell"]))
+        assert np.array_equal(a["cell"][ia], b["cell"][ib].astype(np.int32))      # every particle in the oracle's cell
+        assert np.max(np.abs(a["x"][ia] - b["x"][ib])) <= 1e-12
+        scale = np.max(np.abs(b["ux"]))
+        assert np.max(np.abs(a["ux"][ia] - b["ux"][ib])) <= 1e-12 * scale
+        del a, b, ia, ib
+    f, ke, ki = sim.energies()
+    assert abs(ke - pe.total_kinetic_energy()) <= 1e-11 * ke and abs(ki - pi.total_kinetic_energy()) <= 1e-11 * ki
+    assert abs(f - og.em_field_energy()) <= 1e-9 * f

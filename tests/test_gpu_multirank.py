@@ -552,6 +552,43 @@ def test_recutting_world_with_photon_emission(tmp_path, monkeypatch):
         assert np.max(np.abs(pa[k][oa_] - pb[k][ob_])) <= 1e-9 * max(1.0, np.max(np.abs(pa[k][oa_]))), k
 
 
+@pytest.mark.parametrize("transport", ["peer", "socket"])
+def test_launcher_with_moving_cuts_writes_the_same_files(tmp_path, transport):
+    """`OPAL_RECUT=every,threshold,max_shift opal_amd -n 3 input.yaml`: the cuts follow the particles, and every output is
+    what the run with the reference's fixed partition writes -- the grid rows still gathered in rank order by the sizes the
+    subdomains have NOW (yee.rs:749-779), energies reduced, histograms all-reduced."""
+    import subprocess
+    from test_gpu_recut import NONUNIFORM
+    exe = os.path.join(ROOT, "opal_amd", "bin", "opal_amd")
+    assert os.path.exists(exe), "opal_amd/bin/opal_amd is built by __graft_entry__.build()"
+    text = NONUNIFORM.replace("end: 1.0e-12", "end: 40.5 * 0.95e-8 / c").replace("n_outputs: 2", "n_outputs: 4")
+    outs = {}
+    for kind, extra in (("fixed", {}), ("moving", {"OPAL_RECUT": "4,1.01,32", "OPAL_RECUT_DEBUG": "1"})):
+        d = tmp_path / kind
+        d.mkdir()
+        (d / "slab.yaml").write_text(text)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OPAL_LINK=transport, **extra)
+        res = subprocess.run([exe, "-n", "3", str(d / "slab.yaml")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        outs[kind] = res.stdout.decode()
+        assert res.returncode == 0, outs[kind][-3000:]
+    assert outs["moving"].count("[recut] step") >= 3, outs["moving"][-2000:]   # the cuts did move
+    files = sorted(f for f in os.listdir(tmp_path / "fixed") if f != "slab.yaml")
+    assert files == sorted(f for f in os.listdir(tmp_path / "moving") if f != "slab.yaml") and len(files) == 5 * 4
+    for i in range(5):
+        ra, rb = np.loadtxt(tmp_path / "fixed" / f"{i}_grid.dat"), np.loadtxt(tmp_path / "moving" / f"{i}_grid.dat")
+        assert ra.shape == rb.shape == (768, 11)
+        assert np.max(np.abs(ra[:, 0] - rb[:, 0])) <= 1e-15 * 768e-8 * 4  # x of every cell: offset + index * dx, a rounding apart
+        for c in range(1, 11):
+            scale = max(np.max(np.abs(ra[:, c])), 1e-300)
+            assert np.max(np.abs(ra[:, c] - rb[:, c])) <= 1e-9 * scale, (i, c)
+        ea = [line.split() for line in open(tmp_path / "fixed" / f"{i}_energy.dat")]
+        eb = [line.split() for line in open(tmp_path / "moving" / f"{i}_energy.dat")]
+        for (k, va), (_, vb) in zip(ea, eb):
+            assert float(va) == pytest.approx(float(vb), rel=2e-6, abs=1e-300), (i, k)
+        for sp in ("electron", "positron"):
+            assert (tmp_path / "fixed" / f"{i}_{sp}_x-px.fits").stat().st_size == (tmp_path / "moving" / f"{i}_{sp}_x-px.fits").stat().st_size
+
+
 def test_called_transports_grow_too(tmp_path):
     """Every transport whose buffers are the library's grows an edge that is too small (link.cpp: link_plan / link_grow), not
     the peer mailboxes alone: the native launcher's host-staged link (the fallback of GPUs that cannot map each other; RCCL's

@@ -319,6 +319,41 @@ def test_loader_matches_oracle(oa, oracle):
             assert np.array_equal(a[:n.value], ref[k]), k
 
 
+def test_parallel_loader_is_the_serial_loader_bit_for_bit(oa):
+    """Population::new is one loop over one generator (mod.rs:172-203).  The loader may run it on several host threads
+    (opal_set_loader_threads; a Simulation does by default): every particle takes a fixed number of draws -- 11 for an
+    electron, 10 for an ion, 14 for a photon -- so the generator's state at any cell is known, one thread advances it, the
+    others fill.  Same arrays bit for bit, whatever the species, with empty cells in between, and the generator is left where
+    the serial loop leaves it (the next species continues from there)."""
+    lib = oa._lib.load()
+    from opal_amd._lib import FN1, FN3
+    nx, npc, dx = 300, 800, 500.0
+    dens = lambda x: 20.0 if (x > 3000.0 and not 60000.0 < x < 75000.0) else 0.0
+    cbs = (FN1(lambda x, u: dens(x)), FN3(lambda x, a, b, u: 0.1 * b + a), FN3(lambda x, a, b, u: b), FN3(lambda x, a, b, u: x * 1e-9 + a * b))
+    cap = nx * npc
+
+    def generate(species, threads):
+        assert lib.opal_set_loader_threads(threads) == 0
+        cell = np.zeros(cap, np.int32)
+        arrs = [np.zeros(cap) for _ in range(5)]
+        n = C.c_size_t()
+        try:
+            rc = lib.opal_loader_generate(species, npc, *cbs, None, 0.0, dx, nx, 5, cap, C.byref(n), cell.ctypes.data,
+                                          *[a.ctypes.data for a in arrs])
+        finally:
+            lib.opal_set_loader_threads(0)
+        assert rc == 0
+        return n.value, cell, arrs
+
+    for species in (0, 1, 2):
+        n1, c1, a1 = generate(species, 1)
+        n4, c4, a4 = generate(species, 5)
+        assert n1 == n4 > 200000          # (above the size below which the loader does not bother with threads)
+        assert np.array_equal(c1, c4)
+        for u, v in zip(a1, a4):
+            assert np.array_equal(u, v)
+
+
 def test_rng_known_answers(oracle):
     """xoshiro256** seeded via SplitMix64: first outputs for seed 0 (public reference values of the
     generator: splitmix64(0) state then xoshiro256starstar)."""
