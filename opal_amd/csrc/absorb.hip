@@ -378,6 +378,7 @@ int opal_absorb(opal_pop_t *e, opal_pop_t *ph, const opal_grid_t *grid, uint64_t
         k_absorb_apply<<<(nph + 255) / 256, 256, 0, e->stream>>>(a, 0xffffffffu);
         OPAL_HIP(hipGetLastError());
         ph->n_upper += nph;  // upper bound: one stimulated emission per photon at the most
+        ph->added_since_pub += nph;
         ph->sorted_exact = false;
         ph->emit_list_valid = false;
         e->emit_list_valid = false;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(ADV_TILE) void k_sync_advance(SyncArgs sa, AdvArgs 
 {
     __shared__ double lds[ADV_LDS];
     // (the policy's counters leave from the last workgroup: off the synchronize workgroup's longer chain where there is another)
-    if (pub.n && blockIdx.x == gridDim.x - 1) publish_counters(pub);
+    if ((pub.n || pub.zero) && blockIdx.x == gridDim.x - 1) publish_counters(pub);
     if (blockIdx.x == 0) {
         sync_advance_edges(sa, a, lds);
     } else {
@@ -199,7 +199,7 @@ int grid_sync_advance(opal_grid_t *g, const double *recv_left, const double *rec
     AdvArgs a;
     grid_advance_args(g, dt, a);
     if (a.edge_left > ADV_EDGE || a.edge_right > ADV_EDGE) {  // (a grid too short to have an interior, yet longer than one workgroup's edges)
-        if (pub && pub->n) k_publish_only<<<1, 64, 0, g->stream>>>(*pub);
+        if (pub && (pub->n || pub->zero)) k_publish_only<<<1, 64, 0, g->stream>>>(*pub);
         if (int rc = grid_apply_sync(g, recv_left, recv_right, ly, lz)) return rc;
         return opal_grid_advance(g, dt);
     }

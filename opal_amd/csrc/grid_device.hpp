@@ -61,6 +61,7 @@ __device__ inline void publish_counters(const PublishBatch &b)
         if (e < b.n) reinterpret_cast<volatile unsigned *>(&b.dst[e]->c)[w] = reinterpret_cast<const unsigned *>(b.src[e])[w];
         __threadfence_system();
         if (e < b.n && w == 0) b.dst[e]->seq = b.seq[e];
+        if (threadIdx.x == 0 && b.zero) *b.zero = 0u;  // (behind the copy: the published counters still show the count)
     }
 }
 

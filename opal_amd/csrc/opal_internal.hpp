@@ -58,6 +58,9 @@ struct PublishBatch {
     PubCounters *dst[4];
     unsigned seq[4];
     int n;
+    // a device word the same kernel clears once the counters have gone out: the electrons' emitter count, which the step's
+    // emission has consumed by then (run_push would otherwise zero it with a launch of its own before every push)
+    unsigned *zero;
 };
 
 enum { EX_CHI = 0, EX_WORK = 1, EX_Y = 2, EX_Z = 3, EX_TAU = 4, EX_ID = 5, EX_TAU_ABS = 6, EX_TAU_ST = 7, EX_BIRTH = 8, NEX = 9 };
@@ -178,6 +181,7 @@ struct opal_pop {
     // cell reframe_shift) and test leavers against the NEW size; arrivals are unpacked into that frame (particles.hip: PushArgs)
     bool reframe;
     int reframe_shift, reframe_size;
+    bool n_emit_clean;         // d_ctr->n_emit is zero: a kernel of the last step cleared it (PublishBatch::zero)
     int *d_dbg;                // opal_pop_debug_misses
     // Every particle uploaded so far carries the same weight w0 (a uniform plasma loaded with a fixed number per
     // cell): the pushes then take it from their arguments instead of streaming 8 bytes per particle.  Arrivals

@@ -236,6 +236,7 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
     constexpr bool DEPOSIT = MODE != MODE_ADVANCE;
     int newc = c, rel, idx;
     double xn = xi, inv_g;
+    double qed_tau = 0.0, qed_chi = 0.0, qed_gh = 1.0;
     if (GATHER) {
         rel = c + a.L - base;
         V3 E, B;
@@ -258,10 +259,10 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
                     a.ex[EX_Y][i] += r.v_old.y * a.dt;  // electron.rs:315-316: advanced with the pre-push velocity
                     a.ex[EX_Z][i] += r.v_old.z * a.dt;
                 }
-                if (EXTRAS == 2) {  // electron.rs:284-288
-                    const double tau = a.ex[EX_TAU][i] - qed_rate(r.chi, r.gamma_half) * a.dt;
-                    a.ex[EX_TAU][i] = tau;
-                    emits = tau < 0.0;  // electron.rs:209; dropped below if the particle leaves this subdomain
+                if (EXTRAS == 2) {  // electron.rs:284-288: the optical depth is run down at the END of this function
+                    qed_tau = a.ex[EX_TAU][i];  // (loaded here: the latency hides behind the rest of the push)
+                    qed_chi = r.chi;
+                    qed_gh = r.gamma_half;
                 }
             }
         } else if (SPECIES == OPAL_PHOTON) {
@@ -322,8 +323,6 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             if (!left) newc -= a.out_size;  // mod.rs:291-293
         }
     }
-
-    if (EXTRAS == 2 && (deleted || send_side >= 0)) emits = false;  // it radiates where it arrives (or nowhere)
 
     if (DEPOSIT && !deleted) {
         double macrocharge = wt * a.charge;
@@ -388,6 +387,16 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             }
             cp.cell[kc] = DEAD_CELL;
         }
+    }
+    if (EXTRAS == 2 && SPECIES == OPAL_ELECTRON && GATHER) {
+        // electron.rs:284-288, tau -= rate(chi, gamma_half) dt -- here, behind the write-back, where nothing of the push is
+        // live any more: the rate's logarithm and exponential (photon_emission.rs:59-79) are the kernel's widest stretch of
+        // temporaries, and beside the momentum, the weights and the loads in flight they cost it two waves per SIMD
+        // (141 registers against 96; round 5).  A particle that leaves ships the value (k_pack_extras reads the array
+        // afterwards) and radiates where it arrives (or nowhere).
+        const double tau = qed_tau - qed_rate(qed_chi, qed_gh) * a.dt;
+        a.ex[EX_TAU][cp.chunk0 + kc] = tau;
+        emits = tau < 0.0 && !(deleted || send_side >= 0);  // electron.rs:209
     }
 }
 
@@ -730,8 +739,11 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
     }
 }
 
+#ifndef OPAL_QED_WAVES
+#define OPAL_QED_WAVES 4  // waves per SIMD the push that runs the optical depth down is compiled for (see process_particle's last lines)
+#endif
 template <int SPECIES, int MODE, bool RHO, int EXTRAS, bool SENDX>
-__global__ __launch_bounds__(BLOCK, (EXTRAS == 0 && MODE == MODE_FUSED) ? 6 : 1) void k_push(PushArgs a)
+__global__ __launch_bounds__(BLOCK, (EXTRAS == 0 && MODE == MODE_FUSED) ? 6 : (EXTRAS == 2 ? OPAL_QED_WAVES : 1)) void k_push(PushArgs a)
 {
     __shared__ double s_field[MODE != MODE_DEPOSIT ? 6 * TILE : 1];
     __shared__ double s_acc[MODE != MODE_ADVANCE ? 4 * TILE * REPL : 1];
@@ -1415,7 +1427,7 @@ __global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
     }
     // (the policy's counters go out from workgroup 0: where another workgroup runs synchronize and the field solve's
     // edges -- the longest chain of the launch -- the ~2 us of the write to host memory are off it)
-    if (blockIdx.x == 0 && b.pub.n) publish_counters(b.pub);
+    if (blockIdx.x == 0 && (b.pub.n || b.pub.zero)) publish_counters(b.pub);
     if (blockIdx.x == 0 && b.bounds) {
         // this exchange's zone counts -- mine from the send headers, the neighbours' from the received ones -- go to the
         // link's ring in mapped host memory (link.cpp: link_plan) from the first workgroup: the write and its
@@ -1900,7 +1912,9 @@ int run_push(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int mo
     if (p->species == OPAL_ELECTRON && p->extras == 2 && p->d_ex[EX_TAU] && mode != MODE_DEPOSIT) {
         // the push compacts this step's emitters as it goes (see push_body): start an empty list
         if (int rc = ensure_emit_list(p)) return rc;
-        OPAL_HIP(hipMemsetAsync(&p->d_ctr->n_emit, 0, sizeof(unsigned), p->stream));
+        // (the driver's steps have the field solve's launch clear the count once the emission has consumed it: PublishBatch::zero)
+        if (!p->n_emit_clean) OPAL_HIP(hipMemsetAsync(&p->d_ctr->n_emit, 0, sizeof(unsigned), p->stream));
+        p->n_emit_clean = false;
         a.emit_list = p->d_emit_list;
         p->emit_list_valid = true;
     }
@@ -2491,10 +2505,10 @@ int policy_step_inner(opal_pop_t *p, bool &sort_now)
         p->h_ctr_seen = p->h_pub->c;
         p->ctr_pending = false;
     }
-    if (fresh && p->species != OPAL_PHOTON) {
-        // the slot count of a check ago, and what has been reserved for arrivals since that publication was asked for: a
-        // bound on the slots in use now (arrivals are all that is ever appended to electrons and ions; a re-binning in
-        // between would have withdrawn the publication: sort_end)
+    if (fresh) {
+        // the slot count of a check ago, and what has been reserved since that publication was asked for -- for arrivals
+        // (prepare_unpack), for the photons an emission or an absorption pass may append (qed.hip, absorb.hip): a bound on
+        // the slots in use now (a re-binning in between would have withdrawn the publication: sort_end)
         const size_t bound = (size_t)p->h_ctr_seen.n_slots + p->added_since_pub;
         if (bound < p->n_upper) p->n_upper = bound;
     }

@@ -549,10 +549,16 @@ int opal_emit_radiation(opal_pop_t *e, opal_pop_t *ph, uint64_t seed, uint32_t s
     OPAL_HIP(hipGetLastError());
     ph->sorted_exact = false;
     ph->n_upper += emitters;  // upper bound: the filters may have dropped some
+    ph->added_since_pub += emitters;
     ph->prev_valid = false;   // Photon::create(.., dx = 0, dt = 0): prev_x is 0/0 until the first push
     if (n_emitted) {
         *n_emitted = emitters;
         ph->added_since_snapshot += emitters;  // a snapshot still in flight does not know about these
+    } else if (ph->sort_interval < 0) {
+        // under the adaptive re-binning policy the photons' counters reach the host every other step anyway (policy_step takes
+        // the bound down with them): no copy of the slot count on the stream every step (round 5: a 4-byte copy and its event
+        // between two 0.1 ms kernels)
+        ph->added_since_snapshot += emitters;
     } else if (int rc = pop_snapshot_upper(ph, emitters)) {
         return rc;
     }

@@ -1097,7 +1097,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         }
         opal_pop_t *both[2] = {s->electrons, s->ions};
         PublishBatch pub{};
-        bool sort_now[2] = {false, false}, deferred = false;
+        bool sort_now[2] = {false, false}, deferred = false, deferred_qed = false;
+        opal_pop_t *qed_pops[2] = {nullptr, nullptr};
         // With photon emission on, the reference's order is advance -> emit -> deposit (main.rs:240-258) and
         // the deposit's transverse currents use the velocity after the recoil, so the fused push+deposit
         // pass does not apply: the separate operators run in the reference's order.
@@ -1135,9 +1136,18 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                 if (s->ions)
                     if (int rc = opal_pop_advance(s->ions, s->link, s->grid, s->dt)) return rc;
             }
+            // a lone subdomain with emission: the step's bookkeeping rides on the field solve's launch -- the re-binning
+            // policy's counters of electrons and photons (one publication instead of a launch each), the emitter count
+            // cleared for the next push -- and the re-binnings it decides follow that launch
+            const bool batch_qed = qed && !linked && !s->photon_absorption && s->photon_emission && s->electrons && s->photons;
             if (qed) {
-                if (s->photons)
-                    if (int rc = opal_pop_advance(s->photons, s->link, s->grid, s->dt)) return rc;  // main.rs:242-244
+                if (s->photons) {
+                    if (batch_qed) {
+                        if (int rc = pop_push_advance_noexchange(s->photons, nullptr, s->grid, s->dt)) return rc;  // main.rs:242-244
+                    } else if (int rc = opal_pop_advance(s->photons, s->link, s->grid, s->dt)) {
+                        return rc;
+                    }
+                }
                 if (int rc = absorb_now()) return rc;
                 if (s->electrons && !s->photon_emission)
                     if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
@@ -1146,8 +1156,16 @@ int opal_sim_step(opal_sim_t *s, size_t n)
                                                      s->t, s->photon_energy_min, s->photon_angle_max,
                                                      s->max_formation_length, nullptr))
                         return rc;
-                    if (!linked)
+                    if (batch_qed) {
+                        qed_pops[0] = s->electrons;
+                        qed_pops[1] = s->photons;
+                        if (int rc = pops_policy(qed_pops, 2, &pub, sort_now)) return rc;
+                        pub.zero = &s->electrons->d_ctr->n_emit;  // (consumed by the emission above)
+                        s->electrons->n_emit_clean = true;
+                        deferred_qed = true;
+                    } else if (!linked) {
                         if (int rc = pop_maybe_sort(s->electrons, s->grid)) return rc;
+                    }
                 }
             }
             if (s->current_deposition) {
@@ -1179,6 +1197,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         }
         if (deferred)
             if (int rc = pops_sort_decided(both, 2, sort_now, s->grid)) return rc;
+        if (deferred_qed)
+            if (int rc = pops_sort_decided(qed_pops, 2, sort_now, s->grid)) return rc;
         s->t += s->dt;
     }
     return OPAL_OK;
