@@ -913,7 +913,8 @@ def main():
             out["imbalance_max_over_mean"] = max(held) * len(held) / max(sum(held), 1.0)
             st = sim.recut_stats(world)
             if st["checks"]:
-                out["recut"] = {"checks": st["checks"], "recuts": st["recuts"], "imbalance_at_last_check": st["imbalance"],
+                out["recut"] = {"checks": st["checks"], "recuts": st["recuts"], "seconds_in_checks_and_recuts_since_the_start": st["seconds"],
+                                "imbalance_at_last_check": st["imbalance"],
                                 "worst_imbalance_at_a_check": st["imbalance_worst"], "cells_per_subdomain": st["sizes"]}
         return out
 
@@ -1055,6 +1056,7 @@ def main():
                 1 for p in pr if p["electrons"] >= 0.1 * sum(q["electrons"] for q in pr) / world)
             st = simc.recut_stats(world)
             res["recut"] = ({"every_threshold_max_shift": list(cb_recut), "checks": st["checks"], "recuts": st["recuts"],
+                             "seconds_in_checks_and_recuts_since_the_start": st["seconds"],
                              "imbalance_at_last_check": st["imbalance"], "worst_imbalance_at_a_check": st["imbalance_worst"]}
                             if cb_recut else "off: the reference's partition, made once at t = 0")
         del simc
@@ -1213,6 +1215,9 @@ def main():
             out["steps_long"] = m["steps_long"]
         if m.get("per_rank"):
             out["per_rank"] = m["per_rank"]
+        for k_ in ("imbalance_max_over_mean", "recut"):
+            if k_ in m:
+                out[k_] = m[k_]
         if m_default is not None:
             out["default_path"] = block(m_default, DEFAULT, half)
     del sim

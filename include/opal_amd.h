@@ -442,11 +442,12 @@ size_t opal_sim_overlapped_steps(const opal_sim_t *s); /* how many steps so far 
  * made once.  Results do not depend on where the cuts are (only the deposit's summation order does).
  * opal_sim_recut_now: one check + re-cut at once, whatever the threshold (collective; for callers that step by hand).
  * opal_sim_recut_stats: checks and re-cuts so far, max / mean at the last check and the worst since the previous call
- * (0: never checked), and the subdomains' present sizes (numtasks entries; any pointer may be null). */
+ * (0: never checked), the subdomains' present sizes (numtasks entries), and the host time the step loop has spent in
+ * checks and re-cuts so far, the draining of the device before a plan included (any pointer may be null). */
 int opal_sim_set_recut(opal_sim_t *s, size_t every, double threshold, size_t max_shift);
 int opal_sim_recut_now(opal_sim_t *s);
 int opal_sim_recut_stats(opal_sim_t *s, size_t *checks, size_t *recuts, double *imbalance_last, double *imbalance_worst,
-                         size_t *nx_of_every_subdomain);
+                         size_t *nx_of_every_subdomain, double *seconds);
 /* The plan of a re-cut, pure host arithmetic (no device): cuts[0 .. numtasks] are the first global cell of every
  * subdomain and one past the last; cost[c] the load of global cell c, most[c] the particle count of its fullest species
  * (null: cost); edge_room[i - 1] the particles per species cut i may move (null or negative: any number).  new_cuts gets

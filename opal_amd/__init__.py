@@ -527,11 +527,12 @@ class Simulation:
 
     def recut_stats(self, numtasks):
         """dict: checks, recuts, imbalance (max / mean at the last check; 0.0: never checked), imbalance_worst (since the
-        previous call), sizes (interior cells of every subdomain now)."""
-        a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_double(), C.c_double()
+        previous call), sizes (interior cells of every subdomain now), seconds (host time spent in checks and re-cuts so far)."""
+        a, b, c, d, t = C.c_size_t(), C.c_size_t(), C.c_double(), C.c_double(), C.c_double()
         nx = (C.c_size_t * numtasks)()
-        _check(self._lib.opal_sim_recut_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), nx))
-        return {"checks": a.value, "recuts": b.value, "imbalance": c.value, "imbalance_worst": d.value, "sizes": list(nx)}
+        _check(self._lib.opal_sim_recut_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), nx, C.byref(t)))
+        return {"checks": a.value, "recuts": b.value, "imbalance": c.value, "imbalance_worst": d.value, "sizes": list(nx),
+                "seconds": t.value}
 
     @property
     def t(self):

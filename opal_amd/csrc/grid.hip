@@ -249,7 +249,24 @@ int grid_recut(opal_grid_t *g, size_t size, double offset, const double *rows)
         return OPAL_ERR_ARG;
     }
     OPAL_HIP(hipStreamSynchronize(g->stream));
-    const size_t len = size + (size_t)g->L + (size_t)g->R, lenp = (len + 63) / 64 * 64, nb = sizeof(double) * lenp;
+    const size_t len = size + (size_t)g->L + (size_t)g->R;
+    if (len <= g->lenp) {
+        // the rows have room (a decomposed grid is built with some to spare, opal_grid_build): the same buffers, the same
+        // row stride, new contents -- no allocation, no pinned-memory call on the path of a re-cut
+        // (the pinned scratch as an image of the device rows -- jx jy jz rho, then Ex .. Bz, each lenp long: two copies)
+        const size_t P = g->lenp, nb = sizeof(double) * P;
+        double *pin = g->h_pin;
+        memset(pin, 0, 10 * nb);
+        for (int c = 0; c < 3; c++) memcpy(pin + (size_t)c * P, rows + (size_t)(1 + c) * len, sizeof(double) * len);
+        memcpy(pin + 3 * P, rows, sizeof(double) * len);  // rho
+        for (int c = 0; c < 6; c++) memcpy(pin + (size_t)(4 + c) * P, rows + (size_t)(4 + c) * len, sizeof(double) * len);
+        OPAL_HIP(hipMemcpyAsync(g->d_jb[0], pin, 4 * nb, hipMemcpyHostToDevice, g->stream));
+        OPAL_HIP(hipMemcpyAsync(g->d_eb[0], pin + 4 * P, 6 * nb, hipMemcpyHostToDevice, g->stream));
+        OPAL_HIP(hipMemsetAsync(g->d_eb[1], 0, 6 * nb, g->stream));
+        OPAL_HIP(hipMemsetAsync(g->d_jb[1], 0, 4 * nb, g->stream));
+        OPAL_HIP(hipStreamSynchronize(g->stream));  // (the staging area is the grid's own scratch: free again)
+    } else {
+    const size_t lenp = (len + len / 4 + 256 + 63) / 64 * 64, nb = sizeof(double) * lenp;
     double *eb[2] = {nullptr, nullptr}, *jb[2] = {nullptr, nullptr}, *pin = nullptr;
     auto drop = [&]() {
         for (int k = 0; k < 2; k++) {
@@ -285,12 +302,13 @@ int grid_recut(opal_grid_t *g, size_t size, double offset, const double *rows)
     hipHostFree(g->h_pin);
     g->d_eb[0] = eb[0]; g->d_eb[1] = eb[1]; g->d_jb[0] = jb[0]; g->d_jb[1] = jb[1];
     g->h_pin = pin;
+    g->lenp = lenp;
+    }
     g->cur = 0;
     g->jcur = 0;
     g->j_spare_zero = true;
     g->size = size;
     g->len = len;
-    g->lenp = lenp;
     g->offset = offset;
     // a transverse field that came with the new cells ends the electrostatic launches here too (opal_grid_set_raw)
     for (int c = 5; c < 10; c++)
@@ -358,6 +376,9 @@ int opal_grid_build(opal_grid_t **out, int id, int numtasks, int left, int right
     g->offset = offset[id];
     g->len = g->size + (size_t)g->L + (size_t)g->R;
     g->lenp = (g->len + 63) / 64 * 64;
+    // one of several subdomains: rows with room to spare, so that cuts that move (sim.cpp: sim_recut) rewrite the rows they
+    // have instead of allocating new ones (a few KB per row)
+    if (numtasks > 1) g->lenp = (g->len + g->len / 4 + 256 + 63) / 64 * 64;
     g->stream = (hipStream_t)hip_stream;
     g->cur = 0;
     g->d_damp = nullptr;

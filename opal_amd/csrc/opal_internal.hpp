@@ -196,6 +196,8 @@ struct opal_pop {
     unsigned char *d_abs_event;
     unsigned int *d_abs_partner, *d_abs_counts;
     size_t abs_cap;
+    unsigned int *d_hist;      // pop_cell_histogram's scratch (a re-cut's plan), hist_cap words
+    size_t hist_cap;
     unsigned int *d_count;     // sort scratch: ncells + 2
     size_t count_cap;
     double *d_partial;

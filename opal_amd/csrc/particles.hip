@@ -369,7 +369,15 @@ __device__ __forceinline__ void process_particle(const PushArgs &a, const ChunkP
             // a leaver stands within a cell of the cut on the far side after this exchange and may come back: it belongs
             // to the zone count of the edge it crosses (neither end's push would count it otherwise: link.cpp)
             if (a.zone) atomicAdd(reinterpret_cast<unsigned *>(msg) + a.zone_word, 1u);
-            unsigned slot = atomicAdd(reinterpret_cast<unsigned *>(msg) + LINK_H_COUNT + a.send_slot, 1u);
+            // One reservation per wave and side, not one per leaver: next to a cut that sits in a pile-up -- where cuts that
+            // follow the particles do sit -- thousands leave every step, and in the step in which a cut moves hundreds of
+            // thousands do, all bumping ONE counter (round 5: the 4-rank laser-plasma rehearsal spent a third of its step there).
+            // (through a pointer that is the same in every lane -- one side at a time --, so that the compiler's atomic optimizer
+            // turns the increments of a wave into one atomic and a prefix count, as it does for the zone counts above)
+            unsigned slot = 0;
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++)
+                if (send_side == sd) slot = atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[sd]) + LINK_H_COUNT + a.send_slot, 1u);
             if (slot < a.send_cap[send_side]) {
                 *link_cell(msg, a.send_layout, a.send_slot, slot) = newc;
                 *link_field(msg, a.send_layout, a.send_slot, 0, slot) = xn;
@@ -861,7 +869,10 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
             // a leaver stands within a cell of the cut on the far side after this exchange and may come back: it belongs
             // to the zone count of the edge it crosses (neither end's push would count it otherwise: link.cpp)
             if (a.zone) atomicAdd(reinterpret_cast<unsigned *>(msg) + a.zone_word, 1u);
-            unsigned slot = atomicAdd(reinterpret_cast<unsigned *>(msg) + LINK_H_COUNT + a.send_slot, 1u);
+            unsigned slot = 0;  // (one reservation per wave and side: process_particle has the reason)
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++)
+                if (send_side == sd) slot = atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[sd]) + LINK_H_COUNT + a.send_slot, 1u);
             if (slot < a.send_cap[send_side]) {
                 *link_cell(msg, a.send_layout, a.send_slot, slot) = newc;
                 *link_field(msg, a.send_layout, a.send_slot, 0, slot) = xn;
@@ -2602,6 +2613,7 @@ int opal_pop_free(opal_pop_t *p)
         if (p->d_ex_alt[q]) hipFree(p->d_ex_alt[q]);
     }
     if (p->d_count) hipFree(p->d_count);
+    if (p->d_hist) hipFree(p->d_hist);
     if (p->d_emit_list) hipFree(p->d_emit_list);
     if (p->d_tab_slot) hipFree(p->d_tab_slot);
     if (p->d_dbg) hipFree(p->d_dbg);
@@ -3237,8 +3249,14 @@ int pop_cell_histogram(opal_pop_t *p, const opal_grid_t *g, std::vector<unsigned
     if (p->upper_pending)
         if (int rc = pop_tighten_upper(p)) return rc;
     if (p->n_upper == 0) return OPAL_OK;
-    unsigned *d_hist = nullptr;
-    OPAL_HIP(hipMalloc(&d_hist, sizeof(unsigned) * (ncells + 2)));
+    if (p->hist_cap < ncells + 2) {
+        if (p->d_hist) hipFree(p->d_hist);
+        p->d_hist = nullptr;
+        p->hist_cap = 0;
+        OPAL_HIP(hipMalloc(&p->d_hist, sizeof(unsigned) * (ncells + ncells / 2 + 2)));
+        p->hist_cap = ncells + ncells / 2 + 2;
+    }
+    unsigned *d_hist = p->d_hist;
     hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(unsigned) * (ncells + 2), p->stream);
     if (e == hipSuccess) {
         const unsigned nblk = (unsigned)((p->n_upper + 256 * SORT_PPT - 1) / (256 * SORT_PPT));
@@ -3247,9 +3265,16 @@ int pop_cell_histogram(opal_pop_t *p, const opal_grid_t *g, std::vector<unsigned
     }
     if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_hist, sizeof(unsigned) * ncells, hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
-    hipFree(d_hist);
     OPAL_HIP(e);
     return OPAL_OK;
+}
+// live particles of `p` as the re-binning policy last saw them published (at most a few steps old), without touching the
+// stream; false: nothing published yet (or the population is not under the adaptive policy): pop_live_count
+bool pop_live_estimate(const opal_pop_t *p, size_t *n)
+{
+    if (p->sort_interval >= 0 || p->pub_seq == 0 || p->h_ctr_seen.n_slots == 0) return false;
+    *n = (size_t)p->h_ctr_seen.n_slots - std::min(p->h_ctr_seen.n_slots, p->h_ctr_seen.n_dead);
+    return true;
 }
 // The step in which the cuts move, the particles' side (PushArgs: out_shift): from here to pops_reframe_end the pushes of
 // `pops` store cells counted from the new left cut -- old cell `shift` -- and send what lies outside the `new_size` cells

@@ -45,6 +45,7 @@ int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_
 // a re-cut of the decomposition (sim_recut): the pieces in particles.hip and grid.hip
 int pop_live_count(opal_pop_t *p, size_t *n);
 int pop_cell_histogram(opal_pop_t *p, const opal_grid_t *g, std::vector<unsigned> &counts);
+bool pop_live_estimate(const opal_pop_t *p, size_t *n);
 void pops_reframe_begin(opal_pop_t *const *pops, int npops, int shift, size_t new_size);
 void pops_reframe_end(opal_pop_t *const *pops, int npops);
 int pops_recut_pack(opal_pop_t *const *pops, int npops, opal_link_t *link, size_t size, int give_left, int give_right, int delta);
@@ -190,6 +191,7 @@ struct opal_sim {
     size_t recut_every = 0, recut_max_shift = 64, recut_max_particles = (size_t)1 << 24;
     double recut_threshold = 1.10;
     size_t recut_checks = 0, recuts = 0;
+    double recut_seconds = 0.0;     // host time spent in checks and re-cuts so far (what the step loop waited for them)
     double imbalance_seen = 0.0;    // max / mean of the subdomains' particle cost at the last check (0: never checked)
     double imbalance_worst = 0.0;   // ... the worst seen at any check since opal_sim_recut_stats was last asked
     std::vector<size_t> cuts;       // first global cell of every subdomain, and one past the last one's
@@ -750,7 +752,7 @@ int recut_grid(opal_sim_t *s, const std::vector<size_t> &cuts, const std::vector
 // the books after a re-cut: the link's bound re-seeded, the sizes every subdomain gathers the grid rows by
 void recut_done(opal_sim_t *s)
 {
-    link_hold(s->link, s->pending_hold);
+    if (!getenv("OPAL_RECUT_NO_HOLD")) link_hold(s->link, s->pending_hold);  // (the knob: a diagnostic)
     s->cuts = s->pending_cuts;
     for (int r = 0; r < s->numtasks; r++) s->nxs[(size_t)r] = s->cuts[(size_t)r + 1] - s->cuts[(size_t)r];
     s->recuts++;
@@ -777,10 +779,12 @@ void recut_caps(opal_sim_t *s)
 // after the field solve of the step whose pushes went by the new cuts: the grid follows
 int sim_recut_finish(opal_sim_t *s)
 {
+    const auto t0 = std::chrono::steady_clock::now();
     opal_pop_t *pops[3] = {s->electrons, s->ions, s->photons};
     if (int rc = recut_grid(s, s->cuts, s->pending_cuts)) return rc;
     pops_reframe_end(pops, 3);
     recut_done(s);
+    s->recut_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return OPAL_OK;
 }
 
@@ -808,11 +812,15 @@ int sim_recut(opal_sim_t *s, bool force)
     };
     const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
     // ---- A
+    // (the loads as the re-binning policy last saw them published -- at most a few steps old, read from mapped host memory --
+    // where there is such a publication: the check then costs the host one small all-reduce and the device nothing; the host
+    // runs a step or two ahead of the device and waits for its neighbours while the device works the queue down)
     std::vector<double> v(2 * (size_t)N, 0.0);
     for (int sp = 0; sp < 3; sp++)
         if (pops[sp]) {
             size_t live = 0;
-            if (int rc = pop_live_count(pops[sp], &live)) return rc;
+            if (force || !pop_live_estimate(pops[sp], &live))
+                if (int rc = pop_live_count(pops[sp], &live)) return rc;
             v[(size_t)rank] += weight[sp] * (double)live;
         }
     if (to_right && rank + 1 < N) {
@@ -830,18 +838,66 @@ int sim_recut(opal_sim_t *s, bool force)
     s->recut_checks++;
     s->imbalance_seen = total > 0.0 ? worst * (double)N / total : 1.0;
     s->imbalance_worst = std::max(s->imbalance_worst, s->imbalance_seen);
+    if (getenv("OPAL_RECUT_DEBUG") && rank == 0 && atoi(getenv("OPAL_RECUT_DEBUG")) > 1) {
+        fprintf(stderr, "[recut] step %zu check: loads", s->step_index);
+        for (int r = 0; r < N; r++) fprintf(stderr, " %.0f", v[(size_t)r]);
+        fprintf(stderr, " -> max / mean %.4f\n", s->imbalance_seen);
+    }
     if (!force && s->imbalance_seen < s->recut_threshold) return OPAL_OK;
     // ---- B
+    // The plan needs the histogram only near the cuts -- a cut moves max_shift cells at the most, and the prefix sum AT a cut is
+    // the sum of the subdomains before it -- so what is all-reduced is a window of every species' histogram round every cut
+    // (wide enough for the link's bound at the new cut too) and every subdomain's totals: a few thousand numbers whatever
+    // the size of the domain.  Outside the windows a subdomain's remaining particles are spread evenly: a cut whose place
+    // lies out there goes max_shift cells towards it either way.
     const size_t ncells = s->cuts[(size_t)N], size = g->size;
-    std::vector<double> hist(3 * ncells, 0.0);
+    const long W = (long)s->recut_max_shift + (long)link_zone_cells(link) + 3;
+    struct Win { long a, b; size_t at; };
+    std::vector<Win> wins;
+    size_t wtot = 0;
+    for (int i = 0; i <= N; i++) {
+        Win w{std::max(0L, (long)s->cuts[(size_t)i] - W), std::min((long)ncells, (long)s->cuts[(size_t)i] + W), wtot};
+        wtot += 3 * (size_t)(w.b - w.a);
+        wins.push_back(w);
+    }
+    std::vector<double> wv(wtot + 3 * (size_t)N, 0.0);
     std::vector<unsigned> counts;
+    const long myL = (long)s->cuts[(size_t)rank];
     for (int sp = 0; sp < 3; sp++) {
         if (!pops[sp]) continue;
         if (int rc = pop_cell_histogram(pops[sp], g, counts)) return rc;
-        double *h = hist.data() + (size_t)sp * ncells + s->cuts[(size_t)rank];
-        for (size_t c = 0; c < size; c++) h[c] = (double)counts[c];
+        double total_sp = 0.0;
+        for (size_t c = 0; c < size; c++) total_sp += (double)counts[c];
+        wv[wtot + (size_t)sp * (size_t)N + (size_t)rank] = total_sp;
+        for (const Win &w : wins)
+            for (long c = std::max(w.a, myL); c < std::min(w.b, myL + (long)size); c++)
+                wv[w.at + (size_t)sp * (size_t)(w.b - w.a) + (size_t)(c - w.a)] = (double)counts[(size_t)(c - myL)];
     }
-    if (int rc = reduce(hist.data(), hist.size())) return rc;
+    if (int rc = reduce(wv.data(), wv.size())) return rc;
+    std::vector<double> hist(3 * ncells, 0.0);
+    {
+        std::vector<char> known(ncells, 0);
+        for (int sp = 0; sp < 3; sp++)
+            for (const Win &w : wins)
+                for (long c = w.a; c < w.b; c++) {
+                    hist[(size_t)sp * ncells + (size_t)c] = wv[w.at + (size_t)sp * (size_t)(w.b - w.a) + (size_t)(c - w.a)];
+                    known[(size_t)c] = 1;
+                }
+        for (int r = 0; r < N; r++) {
+            const size_t a = s->cuts[(size_t)r], b = s->cuts[(size_t)r + 1];
+            size_t unknown = 0;
+            for (size_t c = a; c < b; c++) unknown += known[c] ? 0 : 1;
+            if (!unknown) continue;
+            for (int sp = 0; sp < 3; sp++) {
+                double in_windows = 0.0;
+                for (size_t c = a; c < b; c++)
+                    if (known[c]) in_windows += hist[(size_t)sp * ncells + c];
+                const double each = std::max(0.0, wv[wtot + (size_t)sp * (size_t)N + (size_t)r] - in_windows) / (double)unknown;
+                for (size_t c = a; c < b; c++)
+                    if (!known[c]) hist[(size_t)sp * ncells + c] = each;
+            }
+        }
+    }
     std::vector<double> cost(ncells), most(ncells);
     for (size_t c = 0; c < ncells; c++) {
         const double e = hist[c], i = hist[ncells + c], ph = hist[2 * ncells + c];
@@ -976,8 +1032,12 @@ int opal_sim_step(opal_sim_t *s, size_t n)
     } rho_guard{s->grid};
     for (size_t k = 0; k < n; k++) {
         // cuts that follow the plasma (off unless asked for: opal_sim_set_recut): between two steps, where nothing is in flight
-        if (s->recut_every && s->numtasks > 1 && s->step_index && s->step_index % s->recut_every == 0)
-            if (int rc = sim_recut(s, false)) return rc;
+        if (s->recut_every && s->numtasks > 1 && s->step_index && s->step_index % s->recut_every == 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = sim_recut(s, false);
+            s->recut_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rc) return rc;
+        }
         s->grid->want_rho = k + 1 == n;
         if (linked && !(s->fused && s->current_deposition && !qed)) {
             // The reference's operator order across subdomains (main.rs:240-267) with the leavers of every
@@ -1426,7 +1486,7 @@ int opal_sim_recut_now(opal_sim_t *s)
 }
 
 int opal_sim_recut_stats(opal_sim_t *s, size_t *checks, size_t *recuts, double *imbalance_last, double *imbalance_worst,
-                         size_t *nx_of_every_subdomain)
+                         size_t *nx_of_every_subdomain, double *seconds)
 {
     if (!s) {
         set_error("null simulation handle");
@@ -1437,6 +1497,7 @@ int opal_sim_recut_stats(opal_sim_t *s, size_t *checks, size_t *recuts, double *
     if (imbalance_last) *imbalance_last = s->imbalance_seen;
     if (imbalance_worst) *imbalance_worst = s->imbalance_worst;
     s->imbalance_worst = 0.0;
+    if (seconds) *seconds = s->recut_seconds;
     if (nx_of_every_subdomain)
         for (size_t r = 0; r < s->nxs.size(); r++) nx_of_every_subdomain[r] = s->nxs[r];
     return OPAL_OK;
