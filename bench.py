@@ -1082,7 +1082,7 @@ def main():
     if args.workload == "laser_plasma":
         wkey = f"laser_plasma:{npc}"
         sim = oa.Simulation(yaml_text=LASER_PLASMA_YAML.format(npc=npc), rank=rank, numtasks=world, link=link, stream=stream)
-        top_recut = recut_spec("OPAL_BENCH_LP_RECUT", "25,1.08,16") if world > 1 else None
+        top_recut = recut_spec("OPAL_BENCH_LP_RECUT", "25,1.12,32") if world > 1 else None
         if top_recut:  # the cuts follow the particles (see the laser_plasma_interaction block)
             sim.set_recut(*top_recut)
     else:
@@ -1312,7 +1312,7 @@ def main():
             # `balance: true` cuts on the electrons' density at t = 0 (grid/mod.rs:157-206); the pulse then piles the slab up in
             # front of it and the first subdomains empty into the next ones.  The cuts follow (a check every 25 steps, a cut 16
             # cells at a time).  OPAL_BENCH_LP_RECUT=0: the reference's partition.
-            lp_recut = recut_spec("OPAL_BENCH_LP_RECUT", "25,1.08,16")
+            lp_recut = recut_spec("OPAL_BENCH_LP_RECUT", "25,1.12,32")
             if lp_recut:
                 sim3.set_recut(*lp_recut)
             m3 = measure(sim3, lp_steps, lp_warm, preheat=False, workload_key=f"laser_plasma:{lp_npc}")

@@ -2184,6 +2184,7 @@ int unpack_arrivals(opal_pop_t *const *pops, int npops, opal_link_t *link, const
     // links (bound ~25 000 slots, ~30 leavers a step) keep the single workgroups.
     static const unsigned parts_at = getenv("OPAL_TAIL_PARTS_AT") ? (unsigned)atoi(getenv("OPAL_TAIL_PARTS_AT")) : 65536u;  // (tests)
     b.parts = (peer_exchange && std::max(link->plan_cap[0], link->plan_cap[1]) >= parts_at) ? TAIL_PARTS : 1;
+    if (peer_exchange && link->burst_parts) b.parts = (int)link->burst_parts;
     b.first_slot = b.parts > 1 ? link->d_tail_words : nullptr;
     const unsigned nblk = (b.n ? 2 * b.n * b.parts : 1) + b.has_sync;
     if (b.has_adv) k_link_tail<ADV_TILE, true><<<nblk + grid_interior_tiles(b.adv), ADV_TILE, 0, st>>>(b);

@@ -105,6 +105,10 @@ int peer_exchange2(void *user, const void *send_left, const void *send_right, vo
     a.send[0] = static_cast<const char *>(send_left);
     a.send[1] = static_cast<const char *>(send_right);
     // (a halo-only exchange is 88 words: one workgroup)
+    // (Not more workgroups for larger messages: every workgroup of the launch ends in a wait for the neighbours' messages, and
+    // workgroups that wait must never keep the neighbours' senders off the chip -- round 5: 257 workgroups of the tail kernel per
+    // rank, four ranks on one card, every rank's publishing workgroup behind its own waiting ones: 20 s, the timeout.  64 x 1024
+    // threads of six ranks fit a card at once.)
     k_peer_move<<<head_only ? 1 : PEER_MOVE_BLOCKS, 1024, 0, l->stream>>>(a, static_cast<char *>(recv_left), static_cast<char *>(recv_right),
                                                                            l->peer->d_err + 1);
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -125,10 +125,15 @@ __device__ inline void peer_send_rows(const PeerArgs &a, int side, unsigned slot
     c = c < a.cap[side] ? c : a.cap[side];
     const unsigned blocks = (c + LINK_ROWS - 1) / LINK_ROWS, wpb = a.layout.blk / 8;
     for (unsigned b = part; b < blocks; b += of) {
-        const size_t off = (LINK_HEAD_BYTES + ((size_t)b * a.layout.nslots + slot) * a.layout.blk) / 8;
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(msg) + off;
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(a.dst[side] + PEER_FLAG_BYTES) + off;
-        for (unsigned i = threadIdx.x; i < wpb; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (16 bytes per lane: a row block is a multiple of 16 bytes at a multiple of 16 -- the mailboxes are uncached or
+        // fine-grained memory, where a plain store is written through as the 8-byte system-scope ones of the header are; the
+        // publisher's system-scope fence and release order them before the sequence number.  Round 5: the hand-over of a
+        // re-cut moves tens of megabytes through here in one step.)
+        const size_t off = LINK_HEAD_BYTES + ((size_t)b * a.layout.nslots + slot) * a.layout.blk;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(msg + off);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(a.dst[side] + PEER_FLAG_BYTES + off);
+        for (unsigned i = threadIdx.x; i < wpb / 2; i += blockDim.x) __builtin_nontemporal_store(src[i], dst + i);
     }
 }
 __device__ inline void peer_send_head(const PeerArgs &a, unsigned rows_of)

@@ -752,6 +752,7 @@ int recut_grid(opal_sim_t *s, const std::vector<size_t> &cuts, const std::vector
 // the books after a re-cut: the link's bound re-seeded, the sizes every subdomain gathers the grid rows by
 void recut_done(opal_sim_t *s)
 {
+    s->link->burst_parts = 0;
     if (!getenv("OPAL_RECUT_NO_HOLD")) link_hold(s->link, s->pending_hold);  // (the knob: a diagnostic)
     s->cuts = s->pending_cuts;
     for (int r = 0; r < s->numtasks; r++) s->nxs[(size_t)r] = s->cuts[(size_t)r + 1] - s->cuts[(size_t)r];
@@ -774,6 +775,12 @@ void recut_caps(opal_sim_t *s)
         link->plan_cap[side] = std::min(cap, std::max(want, (unsigned)LINK_ROWS));
         link->send_cap[side] = link_is_peer(link) ? cap : link->plan_cap[side];
     }
+    // megabytes may change hands in this one exchange: twice the tail kernel's usual senders and unpackers per species and
+    // side.  (Not more: they are workgroups of 1024 threads that all wait for the neighbours' messages, and the workgroup that
+    // publishes this subdomain's message comes last in the launch -- with 64 per species and side, four ranks sharing a card in
+    // a rehearsal kept one another's publishers off the chip until the 20 s timeout.  65 workgroups of six ranks fit at once.)
+    const unsigned most = std::max(s->pending_ship[0], s->pending_ship[1]);
+    link->burst_parts = most >= (1u << 17) ? 16u : 0u;
 }
 
 // after the field solve of the step whose pushes went by the new cuts: the grid follows
@@ -785,6 +792,9 @@ int sim_recut_finish(opal_sim_t *s)
     pops_reframe_end(pops, 3);
     recut_done(s);
     s->recut_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("OPAL_RECUT_DEBUG") && atoi(getenv("OPAL_RECUT_DEBUG")) > 2 && s->rank == 0)
+        fprintf(stderr, "[recut] step %zu host ms: the grid's columns (drain of the hand-over step, all-reduce, rows rewritten) %.3f\n", s->step_index,
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return OPAL_OK;
 }
 
@@ -811,6 +821,10 @@ int sim_recut(opal_sim_t *s, bool force)
         return OPAL_OK;
     };
     const bool to_left = opal_grid_to_left(g) >= 0, to_right = opal_grid_to_right(g) >= 0;
+    const bool timing = getenv("OPAL_RECUT_DEBUG") && atoi(getenv("OPAL_RECUT_DEBUG")) > 2 && rank == 0;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return 1e3 * std::chrono::duration<double>(b - a).count(); };
+    const auto tA = now();
     // ---- A
     // (the loads as the re-binning policy last saw them published -- at most a few steps old, read from mapped host memory --
     // where there is such a publication: the check then costs the host one small all-reduce and the device nothing; the host
@@ -844,6 +858,7 @@ int sim_recut(opal_sim_t *s, bool force)
         fprintf(stderr, " -> max / mean %.4f\n", s->imbalance_seen);
     }
     if (!force && s->imbalance_seen < s->recut_threshold) return OPAL_OK;
+    const auto tB = now();
     // ---- B
     // The plan needs the histogram only near the cuts -- a cut moves max_shift cells at the most, and the prefix sum AT a cut is
     // the sum of the subdomains before it -- so what is all-reduced is a window of every species' histogram round every cut
@@ -873,7 +888,9 @@ int sim_recut(opal_sim_t *s, bool force)
             for (long c = std::max(w.a, myL); c < std::min(w.b, myL + (long)size); c++)
                 wv[w.at + (size_t)sp * (size_t)(w.b - w.a) + (size_t)(c - w.a)] = (double)counts[(size_t)(c - myL)];
     }
+    const auto tB1 = now();
     if (int rc = reduce(wv.data(), wv.size())) return rc;
+    const auto tB2 = now();
     std::vector<double> hist(3 * ncells, 0.0);
     {
         std::vector<char> known(ncells, 0);
@@ -969,6 +986,9 @@ int sim_recut(opal_sim_t *s, bool force)
     const bool qed = s->photon_emission || s->photon_absorption;
     const bool in_the_step = !s->photon_absorption && !getenv("OPAL_RECUT_AT_ONCE") &&
                              ((s->fused && s->current_deposition && !qed) || !s->current_deposition);
+    if (timing)
+        fprintf(stderr, "[recut] step %zu host ms: loads + all-reduce %.3f, histograms %.3f, their all-reduce %.3f, plan + growth %.3f\n",
+                s->step_index, ms(tA, tB), ms(tB, tB1), ms(tB1, tB2), ms(tB2, now()));
     if (in_the_step) {
         pops_reframe_begin(pops, 3, (int)((long)newL - (long)oldL), new_size);
         s->recut_pending = true;  // opal_sim_step: recut_caps after the step's link_begin, sim_recut_finish after its field solve
