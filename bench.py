@@ -914,6 +914,7 @@ def main():
             st = sim.recut_stats(world)
             if st["checks"]:
                 out["recut"] = {"checks": st["checks"], "recuts": st["recuts"], "seconds_in_checks_and_recuts_since_the_start": st["seconds"],
+                                "steps_in_which_a_cut_drifted": st["drift_steps"], "drift_cells_per_step_of_the_interior_cuts": st["drift_cells_per_step"],
                                 "imbalance_at_last_check": st["imbalance"],
                                 "worst_imbalance_at_a_check": st["imbalance_worst"], "cells_per_subdomain": st["sizes"]}
         return out
@@ -1057,6 +1058,7 @@ def main():
             st = simc.recut_stats(world)
             res["recut"] = ({"every_threshold_max_shift": list(cb_recut), "checks": st["checks"], "recuts": st["recuts"],
                              "seconds_in_checks_and_recuts_since_the_start": st["seconds"],
+                             "steps_in_which_a_cut_drifted": st["drift_steps"], "drift_cells_per_step_of_the_interior_cuts": st["drift_cells_per_step"],
                              "imbalance_at_last_check": st["imbalance"], "worst_imbalance_at_a_check": st["imbalance_worst"]}
                             if cb_recut else "off: the reference's partition, made once at t = 0")
         del simc

@@ -448,6 +448,12 @@ int opal_sim_set_recut(opal_sim_t *s, size_t every, double threshold, size_t max
 int opal_sim_recut_now(opal_sim_t *s);
 int opal_sim_recut_stats(opal_sim_t *s, size_t *checks, size_t *recuts, double *imbalance_last, double *imbalance_worst,
                          size_t *nx_of_every_subdomain, double *seconds);
+/* Between two plans the cuts DRIFT: each interior cut carries a velocity learnt from what the plans keep asking of it (a beam
+ * that crosses the domain at c, main.rs has no counterpart) and moves a cell at a time inside the step's own pushes, with no
+ * plan, no all-reduce and no data from a neighbour.  cells_per_step_of_every_cut: numtasks + 1 entries (the outer ones 0);
+ * drift_steps: steps in which some cut moved that way.  OPAL_RECUT_NO_DRIFT=1 in the environment keeps the cuts still
+ * between plans. */
+int opal_sim_drift_stats(opal_sim_t *s, double *cells_per_step_of_every_cut, size_t *drift_steps);
 /* The plan of a re-cut, pure host arithmetic (no device): cuts[0 .. numtasks] are the first global cell of every
  * subdomain and one past the last; cost[c] the load of global cell c, most[c] the particle count of its fullest species
  * (null: cost); edge_room[i - 1] the particles per species cut i may move (null or negative: any number).  new_cuts gets

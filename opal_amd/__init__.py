@@ -531,8 +531,11 @@ class Simulation:
         a, b, c, d, t = C.c_size_t(), C.c_size_t(), C.c_double(), C.c_double(), C.c_double()
         nx = (C.c_size_t * numtasks)()
         _check(self._lib.opal_sim_recut_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), nx, C.byref(t)))
+        v = (C.c_double * (numtasks + 1))()
+        ds = C.c_size_t()
+        _check(self._lib.opal_sim_drift_stats(self.h, v, C.byref(ds)))
         return {"checks": a.value, "recuts": b.value, "imbalance": c.value, "imbalance_worst": d.value, "sizes": list(nx),
-                "seconds": t.value}
+                "seconds": t.value, "drift_cells_per_step": list(v)[1:numtasks], "drift_steps": ds.value}
 
     @property
     def t(self):

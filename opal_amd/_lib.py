@@ -147,6 +147,7 @@ SIGNATURES = {
     "opal_set_loader_threads": (C.c_int, [C.c_int]),
     "opal_sim_set_recut": (C.c_int, [vp, sz, dbl, sz]),
     "opal_sim_recut_now": (C.c_int, [vp]),
+    "opal_sim_drift_stats": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(sz)]),
     "opal_sim_recut_stats": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(dbl), C.POINTER(dbl), C.POINTER(sz), C.POINTER(dbl)]),
     "opal_recut_plan": (C.c_int, [C.c_int, vp, vp, vp, sz, sz, vp, vp, C.POINTER(dbl), C.POINTER(dbl)]),
     "opal_grid_set_self_exchange": (C.c_int, [vp, C.c_int]),

@@ -239,6 +239,90 @@ int grid_exchange_halo(opal_grid_t *g, opal_link_t *link, bool exchange, const d
     return OPAL_OK;
 }
 
+// The rows of a subdomain whose left cut has moved by dL cells, without any of its neighbours' data (sim.cpp: cuts that drift
+// a cell at a time): array index j of the new array is index j + dL of the old one.  What a one-cell move uncovers is a cell
+// the subdomain already holds -- a ghost cell, whose E and B the last field solve computed as the neighbour did (the two
+// nearest ghost cells either side are exact after a step: yee.rs:1-58) -- and what falls off the far end of the array are
+// outermost ghosts, which the next synchronize overwrites before anything reads them.
+__global__ void k_grid_shift(const double *__restrict__ eb_in, double *__restrict__ eb_out, const double *__restrict__ j_in,
+                             double *__restrict__ j_out, size_t lenp_in, size_t lenp_out, int old_len, int new_len, int dL)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= new_len) return;
+    const int o = j + dL;
+    const bool in = o >= 0 && o < old_len;
+#pragma unroll
+    for (int c = 0; c < 6; c++) eb_out[(size_t)c * lenp_out + j] = in ? eb_in[(size_t)c * lenp_in + o] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) j_out[(size_t)c * lenp_out + j] = in ? j_in[(size_t)c * lenp_in + o] : 0.0;
+}
+
+int grid_recut(opal_grid_t *g, size_t size, double offset, const double *rows);
+
+int grid_shift(opal_grid_t *g, int dL, size_t new_size, double new_offset)
+{
+    const size_t new_len = new_size + (size_t)g->L + (size_t)g->R;
+    if (new_size < (size_t)(2 * GHOST_SIZE)) {
+        set_error("grid_shift: %zu cells fall below the minimum", new_size);
+        return OPAL_ERR_ARG;
+    }
+    if (new_len > g->lenp) {
+        // the subdomain has outgrown its rows (the last one of a domain whose cuts all drift away from it gains a cell a step):
+        // longer rows -- a quarter to spare again --, the old ones shifted into them
+        const size_t lenp = (new_len + new_len / 4 + 256 + 63) / 64 * 64, nb = sizeof(double) * lenp;
+        double *eb[2] = {nullptr, nullptr}, *jb[2] = {nullptr, nullptr}, *pin = nullptr;
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipMalloc(&eb[k], 6 * nb);
+            if (e == hipSuccess) e = hipMalloc(&jb[k], 4 * nb);
+            if (e == hipSuccess) e = hipMemsetAsync(eb[k], 0, 6 * nb, g->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(jb[k], 0, 4 * nb, g->stream);
+        }
+        if (e == hipSuccess) e = hipHostMalloc(&pin, sizeof(double) * 11 * lenp);
+        if (e == hipSuccess) {
+            k_grid_shift<<<(unsigned)((new_len + 255) / 256), 256, 0, g->stream>>>(g->d_eb[g->cur], eb[0], g->d_jb[g->jcur], jb[0], g->lenp,
+                                                                                  lenp, (int)g->len, (int)new_len, dL);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) {
+            for (int k = 0; k < 2; k++) {
+                if (eb[k]) hipFree(eb[k]);
+                if (jb[k]) hipFree(jb[k]);
+            }
+            if (pin) hipHostFree(pin);
+            return hip_fail(e, "grid_shift: longer rows");
+        }
+        hipFree(g->d_eb[0]); hipFree(g->d_eb[1]); hipFree(g->d_jb[0]); hipFree(g->d_jb[1]);
+        hipHostFree(g->h_pin);
+        g->d_eb[0] = eb[0]; g->d_eb[1] = eb[1]; g->d_jb[0] = jb[0]; g->d_jb[1] = jb[1];
+        g->h_pin = pin;
+        g->lenp = lenp;
+        g->cur = 0;
+        g->jcur = 0;
+        g->j_spare_zero = true;
+        g->size = new_size;
+        g->len = new_len;
+        g->offset = new_offset;
+        return OPAL_OK;
+    }
+    if (!g->j_spare_zero) {  // (between a field solve and the next clear the spare current rows are zero: normally the case)
+        OPAL_HIP(hipMemsetAsync(g->d_jb[g->jcur ^ 1], 0, sizeof(double) * 4 * g->lenp, g->stream));
+        g->j_spare_zero = true;
+    }
+    k_grid_shift<<<(unsigned)((new_len + 255) / 256), 256, 0, g->stream>>>(g->d_eb[g->cur], g->d_eb[g->cur ^ 1], g->d_jb[g->jcur],
+                                                                          g->d_jb[g->jcur ^ 1], g->lenp, g->lenp, (int)g->len, (int)new_len, dL);
+    OPAL_HIP(hipGetLastError());
+    // the rows just left become the spares: the old current rows zeroed (the next clear flips to them)
+    OPAL_HIP(hipMemsetAsync(g->d_jb[g->jcur], 0, sizeof(double) * 4 * g->lenp, g->stream));
+    g->cur ^= 1;
+    g->jcur ^= 1;
+    g->size = new_size;
+    g->len = new_len;
+    g->offset = new_offset;
+    return OPAL_OK;
+}
+
 // A subdomain whose cuts have moved (sim.cpp: sim_recut): `size` interior cells from `offset` on, boundary regions as they
 // were (yee.rs:278-292 goes by rank and boundary kind, which do not change), and the 10 rows rho jx jy jz Ex Ey Ez Bx By Bz of
 // the new array -- `rows`, host memory, new_len doubles each -- as the state.  The handle stays the one the caller holds.

@@ -120,6 +120,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     unsigned need[2] = {0, 0};
     // (a peer link files every LINK_PEER_EVERY-th exchange only and counts LINK_PEER_ZONE cells: see link.hpp)
     const bool peer = link_is_peer(l);
+    // (how old an entry may be, in exchanges -- the counted zone itself is zone_scale times as wide while cuts drift: link.hpp)
     const unsigned zone_cells = peer ? (unsigned)LINK_PEER_ZONE : (unsigned)LINK_ZONE;
     auto entry_of = [&](int sp, const LinkBounds **out) -> int {  // most recent usable entry that counted species sp
         *out = nullptr;
@@ -170,7 +171,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
             if (!b || (sp == 2 && qed && !be)) return OPAL_OK;  // no history to go by: every slot
             for (int side = 0; side < 2; side++) {
                 unsigned n = b->mine[side][sp] + b->theirs[side][sp];
-                if (sp == 2 && qed) n += zone_cells * (be->mine[side][0] + be->theirs[side][0]);
+                if (sp == 2 && qed) n += zone_cells * (be->mine[side][0] + be->theirs[side][0]);  // (one photon per electron and exchange)
                 need[side] = need[side] > n ? need[side] : n;
             }
         }
@@ -213,7 +214,7 @@ void link_hold(opal_link_t *l, const unsigned need[2])
     l->hold_need[1] = need[1];
 }
 
-int link_zone_cells(const opal_link_t *l) { return link_is_peer(l) ? LINK_PEER_ZONE : LINK_ZONE; }
+int link_zone_cells(const opal_link_t *l) { return (link_is_peer(l) ? LINK_PEER_ZONE : LINK_ZONE) * (l->zone_scale > 1 ? (int)l->zone_scale : 1); }
 
 int link_grow(opal_link_t *l, const size_t new_cap_in[2])
 {

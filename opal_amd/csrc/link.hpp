@@ -98,6 +98,8 @@ struct opal_link {
     // the re-cut, so that count covers j < zone; entries of exchanges before hold_from are never used again.
     bool hold_on;
     unsigned hold_from, hold_need[2];
+    unsigned zone_scale;   // 0 / 1: the zone as it is; 2: twice as wide -- while cuts drift a cell at a time (sim.cpp) a leaver of
+                           // exchange X was, k exchanges earlier, within 2 k cells of where the cut stood THEN
     unsigned burst_parts;  // != 0: the next tail kernel shares every (species, side) among this many workgroups (the step in
                            // which a re-cut hands hundreds of thousands of particles over: sim.cpp; back to 0 afterwards)
     // peer-mapped mailboxes (peer.hip, peer_device.hpp): the kernels of the step move the messages themselves

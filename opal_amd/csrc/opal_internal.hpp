@@ -181,6 +181,7 @@ struct opal_pop {
     // cell reframe_shift) and test leavers against the NEW size; arrivals are unpacked into that frame (particles.hip: PushArgs)
     bool reframe;
     int reframe_shift, reframe_size;
+    bool sort_deferred;  // the policy asked for a re-binning during such a step: made once the grid has followed
     bool n_emit_clean;         // d_ctr->n_emit is zero: a kernel of the last step cleared it (PublishBatch::zero)
     int *d_dbg;                // opal_pop_debug_misses
     // Every particle uploaded so far carries the same weight w0 (a uniform plasma loaded with a fixed number per

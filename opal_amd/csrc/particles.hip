@@ -1879,6 +1879,7 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
         // the particles next to a linked edge are counted for transports whose message sizes the host plans, and for
         // peer links, where the same bound sizes the room the populations reserve for arrivals (link_plan)
         a.zone = link_is_peer(link) ? LINK_PEER_ZONE : (link->bounded && link->exchange2) ? LINK_ZONE : 0;
+        if (link->zone_scale > 1) a.zone *= (int)link->zone_scale;  // (cuts that drift: link.hpp)
         a.zone_word = link_h_zone(link->xseq) + slot;  // (the exchange this push packs for is number xseq)
     }
     size_t per_block = (size_t)BLOCK * p->ppt;
@@ -2452,8 +2453,11 @@ int policy_step(opal_pop_t *p, bool &sort_now)
 {
     const int rc = policy_step_inner(p, sort_now);
     // in the step in which the cuts move the cells already count from the new cut while the grid is the old one (PushArgs:
-    // out_shift): the re-binning, which goes by the grid's size, waits for the next step
-    if (p->reframe) sort_now = false;
+    // out_shift): the re-binning, which goes by the grid's size, waits until the grid has followed (pops_sort_deferred)
+    if (p->reframe) {
+        p->sort_deferred = p->sort_deferred || sort_now;
+        sort_now = false;
+    }
     return rc;
 }
 int policy_step_inner(opal_pop_t *p, bool &sort_now)
@@ -3288,6 +3292,16 @@ void pops_reframe_begin(opal_pop_t *const *pops, int npops, int shift, size_t ne
             pops[i]->reframe_shift = shift;
             pops[i]->reframe_size = (int)new_size;
         }
+}
+// the re-binnings the policy decided on while the cells counted from cuts the grid had not followed yet
+int pops_sort_deferred(opal_pop_t *const *pops, int npops, const opal_grid_t *g)
+{
+    for (int i = 0; i < npops; i++)
+        if (pops[i] && pops[i]->sort_deferred) {
+            pops[i]->sort_deferred = false;
+            if (int rc = do_sort(pops[i], g, false)) return rc;
+        }
+    return OPAL_OK;
 }
 void pops_reframe_end(opal_pop_t *const *pops, int npops)
 {

@@ -51,6 +51,8 @@ void pops_reframe_end(opal_pop_t *const *pops, int npops);
 int pops_recut_pack(opal_pop_t *const *pops, int npops, opal_link_t *link, size_t size, int give_left, int give_right, int delta);
 int pops_recut_finish(opal_pop_t *const *pops, int npops, opal_link_t *link, const opal_grid_t *g);
 int grid_recut(opal_grid_t *g, size_t size, double offset, const double *rows);
+int grid_shift(opal_grid_t *g, int dL, size_t new_size, double new_offset);
+int pops_sort_deferred(opal_pop_t *const *pops, int npops, const opal_grid_t *g);
 const double *grid_fetch_rows(const opal_grid_t *g);
 }
 
@@ -199,6 +201,15 @@ struct opal_sim {
     bool recut_pending = false;
     std::vector<size_t> pending_cuts;
     unsigned pending_ship[2] = {0, 0}, pending_hold[2] = {0, 0};
+    // Cuts that DRIFT between two plans: a beam that crosses the domain at c takes its particles past a fixed cut a cell's
+    // worth per step, and a plan every few dozen steps hands the same particles back.  Each interior cut therefore carries a
+    // velocity (cells per step) learnt from what the plans keep asking of it, and between plans moves one cell at a time in
+    // the step's own pushes (PushArgs out_shift) -- no plan, no all-reduce, no column from a neighbour: a one-cell move only
+    // uncovers cells the subdomain holds as ghosts (grid.hip: grid_shift).  Every subdomain computes the same moves.
+    bool drift_on = true, pending_is_drift = false;
+    std::vector<double> drift_v, drift_acc;  // per interior cut i = 1 .. N-1 (index i)
+    size_t drift_shifts = 0;                 // steps in which some cut drifted
+    size_t last_plan_step = 0;
     opal_allreduce_fn allreduce = nullptr;
     opal_gather_fn gather = nullptr;
     void *coll_user = nullptr;
@@ -788,14 +799,67 @@ int sim_recut_finish(opal_sim_t *s)
 {
     const auto t0 = std::chrono::steady_clock::now();
     opal_pop_t *pops[3] = {s->electrons, s->ions, s->photons};
+    if (s->pending_is_drift) {
+        // a drift step: the rows shift by the move of my left cut, on the device; nothing is drained, nobody is asked
+        const size_t r = (size_t)s->rank;
+        const int dL = (int)((long)s->pending_cuts[r] - (long)s->cuts[r]);
+        const size_t new_size = s->pending_cuts[r + 1] - s->pending_cuts[r];
+        if (int rc = grid_shift(s->grid, dL, new_size, (double)s->pending_cuts[r] * s->dx)) return rc;
+        pops_reframe_end(pops, 3);
+        if (int rc = pops_sort_deferred(pops, 3, s->grid)) return rc;
+        s->cuts = s->pending_cuts;
+        for (int q = 0; q < s->numtasks; q++) s->nxs[(size_t)q] = s->cuts[(size_t)q + 1] - s->cuts[(size_t)q];
+        s->recut_pending = s->pending_is_drift = false;
+        s->drift_shifts++;
+        return OPAL_OK;
+    }
     if (int rc = recut_grid(s, s->cuts, s->pending_cuts)) return rc;
     pops_reframe_end(pops, 3);
+    if (int rc = pops_sort_deferred(pops, 3, s->grid)) return rc;
     recut_done(s);
     s->recut_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("OPAL_RECUT_DEBUG") && atoi(getenv("OPAL_RECUT_DEBUG")) > 2 && s->rank == 0)
         fprintf(stderr, "[recut] step %zu host ms: the grid's columns (drain of the hand-over step, all-reduce, rows rewritten) %.3f\n", s->step_index,
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return OPAL_OK;
+}
+
+// whether the hand-over of a re-cut can be made by the next step's own pushes (sim_recut, C)
+bool recut_in_the_step(const opal_sim_t *s)
+{
+    const bool qed = s->photon_emission || s->photon_absorption;
+    return !s->photon_absorption && !getenv("OPAL_RECUT_AT_ONCE") && ((s->fused && s->current_deposition && !qed) || !s->current_deposition);
+}
+
+// One step's drift: every interior cut whose accumulated velocity has reached a cell moves by one, as far as every subdomain
+// keeps its minimum size; the step that follows stores cells and tests leavers in the new frame (as the hand-over of a plan).
+void sim_drift_begin(opal_sim_t *s)
+{
+    const int N = s->numtasks;
+    if (!s->drift_on || N < 2 || s->recut_pending || !s->link || s->drift_v.size() != (size_t)N + 1 || !recut_in_the_step(s)) return;
+    bool any = false;
+    std::vector<size_t> fresh(s->cuts);
+    for (int i = 1; i < N; i++) {
+        if (s->drift_v[(size_t)i] == 0.0) continue;
+        s->drift_acc[(size_t)i] += s->drift_v[(size_t)i];
+        const int d = s->drift_acc[(size_t)i] >= 1.0 ? 1 : s->drift_acc[(size_t)i] <= -1.0 ? -1 : 0;
+        if (!d) continue;
+        s->drift_acc[(size_t)i] -= (double)d;
+        fresh[(size_t)i] = (size_t)((long)fresh[(size_t)i] + d);
+        any = true;
+    }
+    if (!any) return;
+    const size_t min_size = opal_grid_min_size();
+    for (int r = 0; r < N; r++)
+        if (fresh[(size_t)r + 1] < fresh[(size_t)r] + min_size) return;  // (a subdomain at its minimum: this step's moves are dropped, by everybody alike)
+    const size_t r = (size_t)s->rank;
+    opal_pop_t *pops[3] = {s->electrons, s->ions, s->photons};
+    if (s->photons && s->link->nslots < 3) pops[2] = nullptr;
+    s->pending_cuts = fresh;
+    s->pending_ship[0] = s->pending_ship[1] = 0;
+    s->pending_is_drift = true;
+    pops_reframe_begin(pops, 3, (int)((long)fresh[r] - (long)s->cuts[r]), fresh[r + 1] - fresh[r]);
+    s->recut_pending = true;
 }
 
 int sim_recut(opal_sim_t *s, bool force)
@@ -866,7 +930,7 @@ int sim_recut(opal_sim_t *s, bool force)
     // the size of the domain.  Outside the windows a subdomain's remaining particles are spread evenly: a cut whose place
     // lies out there goes max_shift cells towards it either way.
     const size_t ncells = s->cuts[(size_t)N], size = g->size;
-    const long W = (long)s->recut_max_shift + (long)link_zone_cells(link) + 3;
+    const long W = (long)s->recut_max_shift + 2 * (long)(link_is_peer(link) ? LINK_PEER_ZONE : LINK_ZONE) + 3;
     struct Win { long a, b; size_t at; };
     std::vector<Win> wins;
     size_t wtot = 0;
@@ -965,7 +1029,8 @@ int sim_recut(opal_sim_t *s, bool force)
     // what stands within the zone of my new cuts, on both sides: the link's bound until exchanges made with these cuts have
     // filed their own counts (link_hold); photons born meanwhile come from the electrons there (link_plan)
     {
-        const long zone = (long)link_zone_cells(link) + 1;  // (+ 1: the hand-over step itself, when it is a push)
+        // (+ 1: the hand-over step itself, when it is a push; twice the zone where cuts may drift meanwhile: link.hpp zone_scale)
+        const long zone = (long)(link_is_peer(link) ? LINK_PEER_ZONE : LINK_ZONE) * (s->drift_on ? 2 : 1) + 1;
         for (int side = 0; side < 2; side++) {
             s->pending_hold[side] = 0;
             if (!(side == 0 ? to_left : to_right)) continue;
@@ -983,9 +1048,27 @@ int sim_recut(opal_sim_t *s, bool force)
     if (getenv("OPAL_RECUT_DEBUG") && rank == 0)
         fprintf(stderr, "[recut] step %zu: imbalance %.3f -> %.3f (planned)\n", s->step_index, before, after);
     // ---- C
-    const bool qed = s->photon_emission || s->photon_absorption;
-    const bool in_the_step = !s->photon_absorption && !getenv("OPAL_RECUT_AT_ONCE") &&
-                             ((s->fused && s->current_deposition && !qed) || !s->current_deposition);
+    const bool in_the_step = recut_in_the_step(s);
+    // what the plan asks of each cut, per step since the last plan, is what the cut should have been doing by itself: half of
+    // it goes into the cut's drift (a beam's cuts settle at its speed, and the plans then find nothing to correct; a cut
+    // nobody asks anything of for a while comes to rest)
+    if (s->drift_on && in_the_step && !getenv("OPAL_RECUT_NO_DRIFT")) {
+        if (s->drift_v.size() != (size_t)N + 1) {
+            s->drift_v.assign((size_t)N + 1, 0.0);
+            s->drift_acc.assign((size_t)N + 1, 0.0);
+        }
+        const double steps = (double)std::max<size_t>(1, s->step_index - s->last_plan_step);
+        bool drifting = false;
+        for (int i = 1; i < N; i++) {
+            double &v = s->drift_v[(size_t)i];
+            v += 0.5 * ((double)fresh[(size_t)i] - (double)cuts[(size_t)i]) / steps;
+            v = std::max(-1.0, std::min(1.0, v));
+            if (std::fabs(v) < 0.02) v = 0.0;
+            drifting = drifting || v != 0.0;
+        }
+        s->last_plan_step = s->step_index;
+        link->zone_scale = drifting ? 2u : 1u;  // (counted from this step's pushes on; the hold below covers the exchanges before)
+    }
     if (timing)
         fprintf(stderr, "[recut] step %zu host ms: loads + all-reduce %.3f, histograms %.3f, their all-reduce %.3f, plan + growth %.3f\n",
                 s->step_index, ms(tA, tB), ms(tB, tB1), ms(tB1, tB2), ms(tB2, now()));
@@ -1058,6 +1141,7 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             s->recut_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (rc) return rc;
         }
+        if (s->recut_every && s->numtasks > 1) sim_drift_begin(s);  // (a cut that drifts moves a cell in this step's pushes)
         s->grid->want_rho = k + 1 == n;
         if (linked && !(s->fused && s->current_deposition && !qed)) {
             // The reference's operator order across subdomains (main.rs:240-267) with the leavers of every
@@ -1493,6 +1577,19 @@ int opal_sim_set_recut(opal_sim_t *s, size_t every, double threshold, size_t max
         s->recut_threshold = threshold;
         s->recut_max_shift = max_shift ? max_shift : 64;
     }
+    return OPAL_OK;
+}
+
+int opal_sim_drift_stats(opal_sim_t *s, double *cells_per_step_of_every_cut, size_t *drift_steps)
+{
+    if (!s) {
+        set_error("null simulation handle");
+        return OPAL_ERR_ARG;
+    }
+    if (cells_per_step_of_every_cut)
+        for (int i = 0; i <= s->numtasks; i++)
+            cells_per_step_of_every_cut[i] = s->drift_v.size() == (size_t)s->numtasks + 1 ? s->drift_v[(size_t)i] : 0.0;
+    if (drift_steps) *drift_steps = s->drift_shifts;
     return OPAL_OK;
 }
 

@@ -108,7 +108,7 @@ def maybe_recut(sim, world):
 def recut_report(sim, world):
     st = sim.recut_stats(world)
     return {"sizes": np.array(st["sizes"]), "recuts": st["recuts"], "checks": st["checks"], "size": sim.grid.size,
-            "L": sim.grid.left_bdy_size}
+            "L": sim.grid.left_bdy_size, "drift_steps": st["drift_steps"], "drift_v": np.array(st["drift_cells_per_step"])}
 
 
 def dump(outdir, rank, g, pe, pi, extra=None):

@@ -538,6 +538,8 @@ def test_recutting_world_with_photon_emission(tmp_path, monkeypatch):
     a = [np.load(os.path.join(tmp_path, "static", f"rank{r}.npz")) for r in range(world)]
     b = [np.load(os.path.join(tmp_path, "moving", f"rank{r}.npz")) for r in range(world)]
     assert int(b[0]["recuts"]) >= 5 and [int(v) for v in b[0]["sizes"]] != [int(v) for v in a[0]["sizes"]]
+    # the beam flies left at c: between the plans its cuts drift with it, a cell a step, in the steps' own pushes
+    assert int(b[0]["drift_steps"]) >= 100 and np.min(b[0]["drift_v"]) < -0.3, (int(b[0]["drift_steps"]), b[0]["drift_v"])
     assert [int(g["size"]) for g in b] == [int(v) for v in b[0]["sizes"]] and sum(int(v) for v in b[0]["sizes"]) == 3 * (2000 // 3)
 
     def union(parts, name, keys):

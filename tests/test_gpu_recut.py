@@ -137,6 +137,12 @@ def test_recutting_laser_plasma_world_is_the_static_world(oracle, tmp_path, worl
     steps = got[0]["steps"]
     st = got[0]["stats"]
     assert st["checks"] == (steps - 1) // 10 and st["recuts"] >= 5, st
+    # between the plans the cut the front pushes on drifts with it, a cell at a time in the steps' own pushes
+    # (the fused step; the reference's operator order re-cuts at once and its cuts stand still between two plans)
+    if fused:
+        assert st["drift_steps"] >= 20 and any(v > 0.0 for v in st["drift_cells_per_step"]), st
+    else:
+        assert st["drift_steps"] == 0
     sizes0 = [int(g["init_size"]) for g in got]
     cfgp = tmp_path / "lp.yaml"
     cfgp.write_text(text)
