@@ -40,7 +40,7 @@ struct PopCounters {
     unsigned int hot_yz;       // some slot may hold a non-zero uy or uz (see opal_pop::cold_yz)
     unsigned int n_slow_pass;  // wave passes through the slow path since last sort (what the misses cost, see maybe_sort)
     unsigned int n_sorted;     // slots [0, n_sorted) are where the last re-binning put them (chunk table); behind: appended since
-    unsigned int pad[1];
+    unsigned int bad_cell;     // a cell index that failed the gather's range check (err bit 1), for the error message
 };
 
 // EX_TAU_ABS, EX_TAU_ST, EX_BIRTH: a photon's optical depths against absorption / stimulated emission and its birth

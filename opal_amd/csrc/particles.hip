@@ -625,7 +625,10 @@ __device__ __forceinline__ void push_body(const PushArgs &a, unsigned block, dou
         constexpr int LO = GATHER ? TILE_LO : 2, HI = GATHER ? TILE_HI : TILE - 3, REACH = GATHER ? 3 : 2;
         if (GATHER) {
             ok = (unsigned)c < (unsigned)a.size;  // yee.rs:501-502
-            if (!ok) err |= 2;
+            if (!ok) {
+                err |= 2;
+                a.ctr->bad_cell = (unsigned)c;
+            }
         } else {
             int idx = c + a.L;
             ok = idx >= 2 && idx < a.len - 2;  // yee.rs:578-579
@@ -1685,9 +1688,11 @@ int check_pop_err(opal_pop_t *p)
                       "(photon_emission.rs:143-144 unimplemented!())");
             return OPAL_ERR_ASSERT;
         }
-        set_error("particle invariant violated on device (flags 0x%x):%s%s%s", err,
+        char where[64] = "";
+        if (err & 2) snprintf(where, sizeof where, " [a particle in cell %d]", (int)p->h_ctr->bad_cell);
+        set_error("particle invariant violated on device (flags 0x%x):%s%s%s%s", err,
                   (err & 1) ? " moved >= 1 cell in a step (electron.rs:313 / ion.rs:199);" : "",
-                  (err & 2) ? " gather index out of range (yee.rs:501-502);" : "",
+                  (err & 2) ? " gather index out of range (yee.rs:501-502);" : "", where,
                   (err & 4) ? " deposit index out of range (yee.rs:578-579);" : "");
         return OPAL_ERR_ASSERT;
     }
@@ -1896,7 +1901,10 @@ int build_args(opal_pop_t *p, opal_link_t *link, opal_grid_t *g, double dt, int 
     // (safe while no arrival can have reached the middle of the subdomain: less than a cell per step since the last
     // re-binning, see push_body)
     // (and only where arrivals are all that is ever appended: photons are also born in place, anywhere)
-    a.tail_sides = (OPAL_TWO_SIDED_TAIL && p->species != OPAL_PHOTON && p->n_tab && link && g->size >= 8 * TILE &&
+    // (and not in the step in which the cuts move: the two workgroups of a chunk tell their particles apart by the half of the
+    // subdomain the STORED cell lies in, and a cell already stored in the new frame may read as the other half's -- or as
+    // outside the subdomain the launch goes by: round 5, six ranks, a false range error and the risk of a second push)
+    a.tail_sides = (OPAL_TWO_SIDED_TAIL && !p->reframe && p->species != OPAL_PHOTON && p->n_tab && link && g->size >= 8 * TILE &&
                     (size_t)p->steps_since_sort + 2 * TILE < g->size / 2 && a.left_mode == EDGE_SEND && a.right_mode == EDGE_SEND && mode != MODE_DEPOSIT) ? 2 : 1;
     nblk = p->n_tab + (unsigned)((behind + per_block - 1) / per_block) * (unsigned)a.tail_sides;
     return OPAL_OK;
@@ -3224,6 +3232,38 @@ int pops_unpack_and_maybe_sort(opal_pop_t *const *pops, int npops, opal_link_t *
     for (int i = 0; i < npops && i < 4; i++)
         if (pops[i] && sort_now[i])
             if (int rc = do_sort(pops[i], g, false)) return rc;
+    return OPAL_OK;
+}
+
+// Diagnostic (OPAL_DEBUG_CELLS=1, sim.cpp): the first live slot whose cell lies outside [0, size), with where it stands
+__global__ void k_check_cells(const int *__restrict__ cell, const PopCounters *ctr, int size, unsigned *out)
+{
+    const unsigned n = ctr->n_slots;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = cell[i];
+        if (c != DEAD_CELL && (unsigned)c >= (unsigned)size)
+            if (atomicCAS(out, 0u, 1u) == 0u) {
+                out[1] = i; out[2] = (unsigned)c; out[3] = n; out[4] = ctr->n_sorted; out[5] = ctr->n_dead;
+            }
+    }
+}
+int pop_debug_check_cells(opal_pop_t *p, const opal_grid_t *g, const char *when, size_t step)
+{
+    if (!p || p->n_upper == 0) return OPAL_OK;
+    unsigned *d = nullptr, h[8] = {0};
+    OPAL_HIP(hipMalloc(&d, sizeof h));
+    OPAL_HIP(hipMemsetAsync(d, 0, sizeof h, p->stream));
+    k_check_cells<<<1024, 256, 0, p->stream>>>(p->d_cell[p->cur], p->d_ctr, (int)g->size, d);
+    OPAL_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, p->stream));
+    OPAL_HIP(hipStreamSynchronize(p->stream));
+    hipFree(d);
+    if (h[0]) {
+        set_error("debug: species %d, %s step %zu: slot %u holds cell %d (subdomain of %zu cells); slots in use %u, sorted %u, vacated %u; "
+                  "host: n_upper %zu, n_sorted %u, n_tab %u, ppt %d, steps since re-binning %d, reframe %d",
+                  p->species, when, step, h[1], (int)h[2], g->size, h[3], h[4], h[5], p->n_upper, p->n_sorted, p->n_tab, p->ppt,
+                  p->steps_since_sort, (int)p->reframe);
+        return OPAL_ERR_ASSERT;
+    }
     return OPAL_OK;
 }
 

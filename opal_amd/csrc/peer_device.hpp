@@ -125,15 +125,20 @@ __device__ inline void peer_send_rows(const PeerArgs &a, int side, unsigned slot
     c = c < a.cap[side] ? c : a.cap[side];
     const unsigned blocks = (c + LINK_ROWS - 1) / LINK_ROWS, wpb = a.layout.blk / 8;
     for (unsigned b = part; b < blocks; b += of) {
-        // (16 bytes per lane: a row block is a multiple of 16 bytes at a multiple of 16 -- the mailboxes are uncached or
-        // fine-grained memory, where a plain store is written through as the 8-byte system-scope ones of the header are; the
-        // publisher's system-scope fence and release order them before the sequence number.  Round 5: the hand-over of a
-        // re-cut moves tens of megabytes through here in one step.)
-        const size_t off = LINK_HEAD_BYTES + ((size_t)b * a.layout.nslots + slot) * a.layout.blk;
+        // 16 bytes per lane, written through to memory as the 8-byte system-scope stores of the header are (sc0 sc1: the
+        // compiler has no 16-byte atomic store to ask for, and a plain or non-temporal store may stay in this GPU's L2, which a
+        // neighbour that reads its mailbox uncached never sees -- round 5: six ranks, garbage cells).  A row block is a
+        // multiple of 16 bytes at a multiple of 16; the publisher's system-scope fence orders them before the sequence number.
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const size_t off = LINK_HEAD_BYTES + ((size_t)b * a.layout.nslots + slot) * a.layout.blk;
         const u32x4 *src = reinterpret_cast<const u32x4 *>(msg + off);
         u32x4 *dst = reinterpret_cast<u32x4 *>(a.dst[side] + PEER_FLAG_BYTES + off);
-        for (unsigned i = threadIdx.x; i < wpb / 2; i += blockDim.x) __builtin_nontemporal_store(src[i], dst + i);
+        for (unsigned i = threadIdx.x; i < wpb / 2; i += blockDim.x) {
+            const u32x4 v = src[i];
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + i), "v"(v) : "memory");
+        }
+        // (the compiler does not count stores it did not emit: every wave waits for its own here, before the publisher's barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 __device__ inline void peer_send_head(const PeerArgs &a, unsigned rows_of)

@@ -46,6 +46,7 @@ int grid_apply_sync(opal_grid_t *g, const double *recv_left, const double *recv_
 int pop_live_count(opal_pop_t *p, size_t *n);
 int pop_cell_histogram(opal_pop_t *p, const opal_grid_t *g, std::vector<unsigned> &counts);
 bool pop_live_estimate(const opal_pop_t *p, size_t *n);
+int pop_debug_check_cells(opal_pop_t *p, const opal_grid_t *g, const char *when, size_t step);
 void pops_reframe_begin(opal_pop_t *const *pops, int npops, int shift, size_t new_size);
 void pops_reframe_end(opal_pop_t *const *pops, int npops);
 int pops_recut_pack(opal_pop_t *const *pops, int npops, opal_link_t *link, size_t size, int give_left, int give_right, int delta);
@@ -210,7 +211,7 @@ struct opal_sim {
     std::vector<double> drift_v, drift_acc;  // per interior cut i = 1 .. N-1 (index i)
     size_t drift_shifts = 0;                 // steps in which some cut drifted
     size_t last_plan_step = 0;
-    double drift_min = 0.5;  // a cut drifts once the plans ask this many cells per step of it (OPAL_RECUT_DRIFT_MIN)
+    double drift_min = 0.6;  // a cut drifts once the plans ask this many cells per step of it (OPAL_RECUT_DRIFT_MIN)
     opal_allreduce_fn allreduce = nullptr;
     opal_gather_fn gather = nullptr;
     void *coll_user = nullptr;
@@ -1065,7 +1066,7 @@ int sim_recut(opal_sim_t *s, bool force)
             v += 0.5 * ((double)fresh[(size_t)i] - (double)cuts[(size_t)i]) / steps;
             v = std::max(-1.0, std::min(1.0, v));
             if (std::fabs(v) < 0.02) v = 0.0;
-            // A cut only drifts with what moves like a beam (half a cell per step or more: 0.5 c).  A cut that follows a
+            // A cut only drifts with what moves like a beam (0.6 cells per step or more).  A cut that follows a
             // front through a hot, dense plasma -- hole boring: 0.2-0.35 cells per step -- gains nothing from moving a cell at
             // a time: the particles in the cell it crosses move every way, so a cell's worth changes hands per cell whoever
             // moves the cut, and moving it in many small steps cost the 4-rank laser-plasma rehearsal a factor of 2.5 (round 5).
@@ -1138,6 +1139,8 @@ int opal_sim_step(opal_sim_t *s, size_t n)
         opal_grid_t *g;
         ~RhoGuard() { g->want_rho = true; }
     } rho_guard{s->grid};
+    static const bool debug_cells = getenv("OPAL_DEBUG_CELLS") != nullptr;
+    static const size_t debug_from = getenv("OPAL_DEBUG_CELLS") ? (size_t)atol(getenv("OPAL_DEBUG_CELLS")) : 0;
     for (size_t k = 0; k < n; k++) {
         // cuts that follow the plasma (off unless asked for: opal_sim_set_recut): between two steps, where nothing is in flight
         if (s->recut_every && s->numtasks > 1 && s->step_index && s->step_index % s->recut_every == 0) {
@@ -1190,8 +1193,12 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             if (int rc = grid_sync_advance(g, rl, rr, ly, lz, s->dt)) return rc;
             s->t += s->dt;
             s->step_index++;
+            const bool was_handover = s->recut_pending;
             if (s->recut_pending)
                 if (int rc = sim_recut_finish(s)) return rc;
+            if (debug_cells && s->step_index >= debug_from)
+                for (opal_pop_t *p : {s->electrons, s->ions})
+                    if (int rc = pop_debug_check_cells(p, s->grid, was_handover ? "after the hand-over" : "after", s->step_index)) return rc;
             continue;
         }
         if (linked && s->fused && s->current_deposition && !qed) {
@@ -1260,8 +1267,12 @@ int opal_sim_step(opal_sim_t *s, size_t n)
             }
             s->t += s->dt;
             s->step_index++;
+            const bool was_handover = s->recut_pending;
             if (s->recut_pending)
                 if (int rc = sim_recut_finish(s)) return rc;
+            if (debug_cells && s->step_index >= debug_from)
+                for (opal_pop_t *p : {s->electrons, s->ions})
+                    if (int rc = pop_debug_check_cells(p, s->grid, was_handover ? "after the hand-over" : "after", s->step_index)) return rc;
             continue;
         }
         opal_pop_t *both[2] = {s->electrons, s->ions};
