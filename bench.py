@@ -940,6 +940,28 @@ def main():
             out.update(extra)
         return out
 
+    def runs_per_block():
+        both = os.environ.get("OPAL_BENCH_BOTH_PARTITIONS")
+        return 2 if ((backend == "nccl" and ndev >= world) if both is None else both == "1") else 1
+
+    def both_partitions(run, recut):
+        """A decomposed block with moving cuts.  Where every rank has a card of its own the block is run a second time on the
+        reference's partition (made once, at t = 0) -- what balance is worth can only be measured there, and is not known
+        before the first run on such a node: the block is the faster of the two, the other one is kept beside it
+        (`other_partition`).  Ranks that share a card take turns on it, so that only the cost of moving cuts would show:
+        one run there (OPAL_BENCH_BOTH_PARTITIONS=1 / 0 forces the one or the other)."""
+        res = run(recut)
+        if not recut or runs_per_block() == 1:
+            return res
+        brief = lambda r, name: {"cuts": name, **{k: r[k] for k in ("value", "unit", "ms_per_step", "imbalance_max_over_mean",
+                                                                   "per_rank", "recut") if k in r}}
+        static = run(None)
+        faster_static = all_max(1.0 if static["value"] > res["value"] else 0.0) > 0.5  # (one verdict on every rank)
+        keep, other = (static, res) if faster_static else (res, static)
+        keep["cuts"] = "static" if faster_static else "moving"
+        keep["other_partition"] = brief(other, "moving" if faster_static else "static")
+        return keep
+
     def recut_spec(env, default):
         """(every, threshold, max_shift) of a block's moving cuts (Simulation.set_recut), or None: OPAL_BENCH_*_RECUT=0 keeps the
         reference's partition, made once at t = 0 (grid/mod.rs:157-206)"""
@@ -962,7 +984,7 @@ def main():
                 "what": "the same simulation, the same kernel form, a second timed region of this many steps right behind the "
                         "first: the figure a short `--steps` does not depend on"}
 
-    def colliding_beams(link_cb, what):
+    def colliding_beams(link_cb, what, cb_recut=None):
         """BASELINE configs[4] on this run's ranks: untimed up to the collision, then CB_STEPS timed steps through it in
         segments of CB_SEG (the photon population grows by the step: each segment is credited with the electrons and the
         mean of the photons it began and ended with).  updates = electrons + photons pushed; every kernel of the step
@@ -972,7 +994,6 @@ def main():
         # The beam is 500 cells long and crosses the 4000-cell domain at c: under the reference's partition (made once, at
         # t = 0) it is on one or two subdomains at a time.  The cuts go with it (checked every 32 steps, in which it moves 30
         # cells; a cut moves 48 at the most).  OPAL_BENCH_CB_RECUT=0: the reference's partition.
-        cb_recut = recut_spec("OPAL_BENCH_CB_RECUT", "32,1.10,48") if world > 1 else None
         if cb_recut:
             simc.set_recut(*cb_recut)
         barrier()
@@ -1298,7 +1319,7 @@ def main():
         # A second set of mailboxes (open ends, room for a relativistic front) is set up for it.
         lp_npc, lp_warm, lp_steps = 10000, 21000, 2000
 
-        def lp_body():
+        def lp_run(lp_recut):
             nonlocal link
             link = None
             link3, kind3 = make_link(rank, world, link_device, lp_link_capacity(lp_npc), stream=stream, to_left=rank != 0,
@@ -1311,10 +1332,6 @@ def main():
             sim3._bench_link = link3
             sizes = [None] * world
             dist.all_gather_object(sizes, int(sim3.grid.size))
-            # `balance: true` cuts on the electrons' density at t = 0 (grid/mod.rs:157-206); the pulse then piles the slab up in
-            # front of it and the first subdomains empty into the next ones.  The cuts follow (a check every 25 steps, a cut 16
-            # cells at a time).  OPAL_BENCH_LP_RECUT=0: the reference's partition.
-            lp_recut = recut_spec("OPAL_BENCH_LP_RECUT", "25,1.12,32")
             if lp_recut:
                 sim3.set_recut(*lp_recut)
             m3 = measure(sim3, lp_steps, lp_warm, preheat=False, workload_key=f"laser_plasma:{lp_npc}")
@@ -1331,12 +1348,18 @@ def main():
                     + f"), {lp_warm} untimed steps to bring the pulse onto the slab, then {lp_steps} timed steps ending at "
                     f"t = {t3:.3e} s; " + CONTRACT, lp_steps, {"link": kind3, "n_gpus": world})
 
-        guarded("laser_plasma_interaction", float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300")), lp_body)
+        def lp_body():
+            # `balance: true` cuts on the electrons' density at t = 0 (grid/mod.rs:157-206); the pulse then piles the slab up in
+            # front of it and the first subdomains empty into the next ones.  The cuts follow (a check every 25 steps, a cut 32
+            # cells at a time).  OPAL_BENCH_LP_RECUT=0: the reference's partition.
+            return both_partitions(lp_run, recut_spec("OPAL_BENCH_LP_RECUT", "25,1.12,32"))
+
+        guarded("laser_plasma_interaction", float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300")) * runs_per_block(), lp_body)
 
     if world > 1 and full_line and not args.no_colliding_beams:
         # BASELINE configs[4] on the same N GPUs: 4000 cells in N subdomains, the beam and its photons crossing the cuts at
         # c (links laid out for photon emission: 3 species slots, 12 fields per particle, open ends)
-        def cb_body():
+        def cb_run(cb_recut):
             nonlocal link
             link = None
             cap = int(os.environ.get("OPAL_BENCH_CB_CAPACITY") or (1 << 18))
@@ -1344,12 +1367,15 @@ def main():
                                      to_right=rank != world - 1, prefer=order,
                                      log=lambda m_: print(m_.replace("[opal_amd]", "[bench]"), file=sys.stderr))
             res = colliding_beams(link4, CB_WHAT + "; " + (f"{world} GPUs" if backend == "nccl" else
-                                                             f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)"))
+                                                             f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)"), cb_recut)
             res.update(link=kind4, n_gpus=world, link_particle_capacity=cap)
             del link4
             return res
 
-        guarded("colliding_beams", float(os.environ.get("OPAL_BENCH_CB_DEADLINE", "240")), cb_body)
+        def cb_body():
+            return both_partitions(cb_run, recut_spec("OPAL_BENCH_CB_RECUT", "32,1.10,48"))
+
+        guarded("colliding_beams", float(os.environ.get("OPAL_BENCH_CB_DEADLINE", "240")) * runs_per_block(), cb_body)
 
     if rank == 0:
         if world == 1 and args.workload == "two_stream" and not weak and not args.no_secondary and not args.self_exchange \

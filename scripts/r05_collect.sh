@@ -26,6 +26,11 @@ if [ $STAGE = static$N ]; then
   OPAL_BENCH_LP_RECUT=0 OPAL_BENCH_CB_RECUT=0 python bench.py --gpus $N --steps 100 --warmup 10 --no-cpu-baseline > $O/r05_bench_${N}ranks_on_1gpu_rehearsal_static_cuts.json 2>> $O/bench.err
   echo "rehearsal $N (static cuts) done"
 fi
+# both partitions in one line (what a node with a card per rank does by itself): the block is the faster one, the other is kept beside it
+if [ $STAGE = both$N ]; then
+  OPAL_BENCH_BOTH_PARTITIONS=1 python bench.py --gpus $N --steps 100 --warmup 10 --no-cpu-baseline > $O/r05_bench_${N}ranks_on_1gpu_rehearsal_both_partitions.json 2>> $O/bench.err
+  echo "rehearsal $N (both partitions) done"
+fi
 done
 if [ $STAGE = all ] || [ $STAGE = lp ]; then
 python bench.py --workload laser_plasma --npc 2000 --warmup 21000 --steps 2000 --no-cpu-baseline > $O/r05_bench_laser_plasma_2e7_interaction.json 2>> $O/bench.err
