@@ -122,12 +122,12 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     const bool peer = link_is_peer(l);
     // (how old an entry may be, in exchanges -- the counted zone itself is zone_scale times as wide while cuts drift: link.hpp)
     const unsigned zone_cells = peer ? (unsigned)LINK_PEER_ZONE : (unsigned)LINK_ZONE;
-    auto entry_of = [&](int sp, const LinkBounds **out) -> int {  // most recent usable entry that counted species sp
+    auto entry_of = [&](int sp, const LinkBounds **out, bool before_the_hold) -> int {  // most recent usable entry that counted species sp
         *out = nullptr;
         unsigned e = X - LINK_ZONE;
         if (peer) e -= e % LINK_PEER_EVERY;
         for (;; e -= peer ? LINK_PEER_EVERY : 1) {
-            if (l->hold_on && e < l->hold_from) break;  // counted near where the cuts were before they moved
+            if (l->hold_on && e < l->hold_from && !before_the_hold) break;  // counted near where the cuts were before they moved
             // overwritten since (or about to be).  (An old entry is as good as a recent one for a called transport: the
             // exchanges after it that did not count the species did not push it either, so at most LINK_ZONE pushes of
             // it lie between the entry and X.  A peer link skips entries whatever they counted, so age itself bounds.)
@@ -157,19 +157,29 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     const LinkBounds *be = nullptr;
     const bool qed = l->nfields >= 12 && l->nslots >= 3;
     const bool held = l->hold_on && X - l->hold_from < zone_cells;  // (X >= hold_from: xseq only grows)
-    if (held) {
-        // the cuts moved fewer than zone_cells exchanges ago: what stood near them then (link_hold)
-        need[0] = l->hold_need[0];
-        need[1] = l->hold_need[1];
-    } else {
+    // the cuts moved fewer than zone_cells exchanges ago: what stood near them then (link_hold) -- for a side whose cut did
+    // move.  The cut of the other side is where it was: what was counted there, before the hold or after, stands (a rank far
+    // from the front would otherwise reserve, and grow its edges to, the histogram's generous figure at every re-cut of
+    // somebody else's cuts -- and re-bin three times as often for the room: the 6-rank rehearsal of configs[3]).
+    const bool side_held[2] = {held && l->hold_side[0], held && l->hold_side[1]};
+    bool unknown[2] = {false, false};
+    for (int side = 0; side < 2; side++)
+        if (side_held[side]) need[side] = l->hold_need[side];
+    if (!(side_held[0] && side_held[1])) {
         if (qed && (species_mask & 4u))
-            if (int rc = entry_of(0, &be)) return rc;
+            if (int rc = entry_of(0, &be, held)) return rc;
         for (int sp = 0; sp < l->nslots; sp++) {
             if (!(species_mask & (1u << sp))) continue;
             const LinkBounds *b;
-            if (int rc = entry_of(sp, &b)) return rc;
-            if (!b || (sp == 2 && qed && !be)) return OPAL_OK;  // no history to go by: every slot
+            if (int rc = entry_of(sp, &b, held)) return rc;
+            if (!b || (sp == 2 && qed && !be)) {  // no history to go by: every slot
+                if (!held) return OPAL_OK;
+                unknown[0] = !side_held[0];
+                unknown[1] = !side_held[1];
+                break;
+            }
             for (int side = 0; side < 2; side++) {
+                if (side_held[side]) continue;
                 unsigned n = b->mine[side][sp] + b->theirs[side][sp];
                 if (sp == 2 && qed) n += zone_cells * (be->mine[side][0] + be->theirs[side][0]);  // (one photon per electron and exchange)
                 need[side] = need[side] > n ? need[side] : n;
@@ -179,7 +189,7 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     unsigned slots[2];
     size_t grow_to[2] = {0, 0};
     for (int side = 0; side < 2; side++) {
-        slots[side] = (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+        slots[side] = unknown[side] ? full[side] : (need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
         if (slots[side] > full[side] && l->growable && need[side]) {
             // More particles stand within reach of this cut than its messages have room for: the edge grows before the
             // push that could overflow it is enqueued (the reference's receive_vec takes messages of any size,
@@ -206,12 +216,14 @@ int link_plan(opal_link_t *l, unsigned species_mask)
     return OPAL_OK;
 }
 
-void link_hold(opal_link_t *l, const unsigned need[2])
+void link_hold(opal_link_t *l, const unsigned need[2], const bool moved[2])
 {
     l->hold_on = true;
     l->hold_from = l->xseq;
-    l->hold_need[0] = need[0];
-    l->hold_need[1] = need[1];
+    for (int side = 0; side < 2; side++) {
+        l->hold_need[side] = need[side];
+        l->hold_side[side] = moved ? moved[side] : true;
+    }
 }
 
 int link_zone_cells(const opal_link_t *l) { return (link_is_peer(l) ? LINK_PEER_ZONE : LINK_ZONE) * (l->zone_scale > 1 ? (int)l->zone_scale : 1); }

@@ -98,6 +98,7 @@ struct opal_link {
     // the re-cut, so that count covers j < zone; entries of exchanges before hold_from are never used again.
     bool hold_on;
     unsigned hold_from, hold_need[2];
+    bool hold_side[2];  // the cut on that side moved: a side whose cut stayed goes on by what was counted there (before or after)
     unsigned zone_scale;   // 0 / 1: the zone as it is; 2: twice as wide -- while cuts drift a cell at a time (sim.cpp) a leaver of
                            // exchange X was, k exchanges earlier, within 2 k cells of where the cut stood THEN
     unsigned burst_parts;  // != 0: the next tail kernel shares every (species, side) among this many workgroups (the step in
@@ -143,7 +144,8 @@ void link_peer_grow_abort(opal_link_t *l, void *state);            // a growth b
 // Synchronises with the link's stream: called where the host waits for the device anyway.
 int link_peer_check(opal_link_t *l);
 // the cuts have just moved: need[side] particles per species stand within the zone of the left / right cut now (see hold_on)
-void link_hold(opal_link_t *l, const unsigned need[2]);
+// moved[side]: whether that cut changed at all (null: both did)
+void link_hold(opal_link_t *l, const unsigned need[2], const bool moved[2] = nullptr);
 // cells either side of a cut within which the pushes count particles into the message headers (what link_plan's bound covers)
 int link_zone_cells(const opal_link_t *l);
 }  // namespace opal

@@ -574,7 +574,8 @@ int opal_link_plan_selftest(void)
             l.xseq = X;
             if (X == 21) {
                 const unsigned need21[2] = {5000u, 7000u};
-                link_hold(&l, need21);
+                const bool moved21[2] = {true, false};  // (the right cut stays where it is: its side goes on by the entries)
+                link_hold(&l, need21, moved21);
             }
             if (int rc = link_plan(&l, mask)) return rc;
             // the specification
@@ -602,12 +603,12 @@ int opal_link_plan_selftest(void)
                     }
             }
             // ... and after the cuts have moved (link_hold at exchange 21, sim.cpp: sim_recut): what stood near the new cuts
-            // then for the next zone exchanges, and never again an entry of an exchange before the move
+            // then for the next zone exchanges -- on the side whose cut moved --, and never again an entry of an exchange before the move
             const unsigned held_at = 21, held_need[2] = {5000u, 7000u};
             const unsigned zone_cells = peer ? (unsigned)LINK_PEER_ZONE : (unsigned)LINK_ZONE;
             if (X >= held_at) {
                 if (X - held_at < zone_cells) {
-                    for (int side = 0; side < 2; side++) want[side] = (held_need[side] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;
+                    want[0] = (held_need[0] + LINK_SLACK + LINK_ROWS - 1) / LINK_ROWS * LINK_ROWS;  // (want[1]: as if nothing had happened)
                 } else {
                     unsigned need[2] = {0, 0};
                     bool all = true;

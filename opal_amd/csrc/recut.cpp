@@ -60,9 +60,12 @@ extern "C" int opal_recut_plan(int numtasks, const size_t *cuts, const double *c
         if (old + max_shift < hi) hi = old + max_shift;
         k = std::min(std::max(k, lo), hi);
         const double room = edge_room ? edge_room[i - 1] : -1.0;
-        if (room >= 0.0) {  // no more particles of one species than the edge's messages hold
-            while (k > old && M[k] - M[old] > room) k--;
-            while (k < old && M[old] - M[k] > room) k++;
+        if (room >= 0.0) {
+            // no more particles of one species than the edge's messages hold: the cells that change hands and the cell either
+            // side (when the hand-over is a step's own push, a particle moves up to a cell meanwhile: sim.cpp, sim_recut C)
+            auto at_stake = [&](size_t a, size_t b) { return M[std::min(b + 1, ncells)] - M[a > 0 ? a - 1 : 0]; };  // a < b
+            while (k > old && at_stake(old, k) > room) k--;
+            while (k < old && at_stake(k, old) > room) k++;
         }
         new_cuts[i] = k;
     }

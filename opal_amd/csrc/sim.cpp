@@ -202,6 +202,7 @@ struct opal_sim {
     bool recut_pending = false;
     std::vector<size_t> pending_cuts;
     unsigned pending_ship[2] = {0, 0}, pending_hold[2] = {0, 0};
+    bool pending_moved[2] = {true, true};  // whether the plan moves my left / right cut at all (link_hold)
     // Cuts that DRIFT between two plans: a beam that crosses the domain at c takes its particles past a fixed cut a cell's
     // worth per step, and a plan every few dozen steps hands the same particles back.  Each interior cut therefore carries a
     // velocity (cells per step) learnt from what the plans keep asking of it, and between plans moves one cell at a time in
@@ -766,7 +767,7 @@ int recut_grid(opal_sim_t *s, const std::vector<size_t> &cuts, const std::vector
 void recut_done(opal_sim_t *s)
 {
     s->link->burst_parts = 0;
-    if (!getenv("OPAL_RECUT_NO_HOLD")) link_hold(s->link, s->pending_hold);  // (the knob: a diagnostic)
+    if (!getenv("OPAL_RECUT_NO_HOLD")) link_hold(s->link, s->pending_hold, s->pending_moved);  // (the knob: a diagnostic)
     s->cuts = s->pending_cuts;
     for (int r = 0; r < s->numtasks; r++) s->nxs[(size_t)r] = s->cuts[(size_t)r + 1] - s->cuts[(size_t)r];
     s->recuts++;
@@ -1035,6 +1036,7 @@ int sim_recut(opal_sim_t *s, bool force)
         const long zone = (long)(link_is_peer(link) ? LINK_PEER_ZONE : LINK_ZONE) * (s->drift_on ? 2 : 1) + 1;
         for (int side = 0; side < 2; side++) {
             s->pending_hold[side] = 0;
+            s->pending_moved[side] = at_new[side] != at_old[side];
             if (!(side == 0 ? to_left : to_right)) continue;
             double n = 0.0, ne = 0.0;
             for (long c = (long)at_new[side] - zone; c < (long)at_new[side] + zone; c++) {
