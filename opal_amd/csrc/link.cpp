@@ -222,7 +222,7 @@ void link_hold(opal_link_t *l, const unsigned need[2], const bool moved[2])
     l->hold_from = l->xseq;
     for (int side = 0; side < 2; side++) {
         l->hold_need[side] = need[side];
-        l->hold_side[side] = moved ? moved[side] : true;
+        l->hold_side[side] = moved && !getenv("OPAL_HOLD_BOTH_SIDES") ? moved[side] : true;  // (the knob: a diagnostic)
     }
 }
 

@@ -1389,8 +1389,12 @@ constexpr int TAIL_PARTS = 8;
 
 __device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigned of, unsigned long long *first_slot, unsigned seq);
 
+// (8 waves per SIMD asked for: two of these 16-wave workgroups per CU.  At the 7 the compiler otherwise settles on -- 106 scalar
+// registers -- a CU takes ONE, the chip 256, and six subdomains rehearsing on one card need up to 6 x 65 in the step that
+// hands a re-cut over: the workgroups that wait for the neighbours' messages then keep the neighbours' senders off the chip
+// until the timeout.  A subdomain that has its card to itself never needs more than 65 + its interior tiles.)
 template <int NT, bool ADV>
-__global__ __launch_bounds__(NT) void k_link_tail(UnpackBatch b)
+__global__ __launch_bounds__(NT, NT >= 1024 ? 8 : 1) void k_link_tail(UnpackBatch b)
 {
     static_assert(!ADV || NT == ADV_TILE, "the field solve's workgroups are ADV_TILE threads");
     __shared__ double s_adv[ADV ? 2 * 6 * (ADV_EDGE + 2 * ADV_HALO) : 1];
@@ -1493,10 +1497,10 @@ __device__ void unpack_one(const UnpackArgs &a, int side, unsigned part, unsigne
             s_base = atomicAdd(&a.ctr->n_slots, total);
             __hip_atomic_store(first_slot, ((unsigned long long)seq << 32) | s_base, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            const long long t0 = wall_clock64();
+            SpinClock clock;  // (peer_device.hpp: the time spent polling, not the difference of two readings)
             unsigned long long v;
             while (((v = __hip_atomic_load(first_slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
-                if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+                if (clock.expired()) {
                     atomicOr(&a.ctr->err, 16);
                     v = (unsigned long long)a.pop_cap;  // (past the end: this share is dropped, the error ends the run)
                     break;

@@ -425,8 +425,9 @@ int opal_link_create_peer(opal_link_t **out, int rank, int size, size_t particle
     p->box_mem[0] = p->base0;
     p->box_mem[1] = p->base0 + region;
     e = hipMemset(p->base0, 0, p->total0);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, 2 * sizeof(unsigned));  // [0] error word, [1] k_peer_move's ticket
-    if (e == hipSuccess) e = hipMemset(p->d_err, 0, 2 * sizeof(unsigned));
+    // [0] error word, [1] k_peer_move's ticket, [2..5] the first wait that gave up: side, the sequence number it waited for, the one it saw, its workgroup
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, 8 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(p->d_err, 0, 8 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_wait, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(p->d_wait, 0, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -675,14 +676,17 @@ int opal_link_peer_status(opal_link_t *l, int *timeouts, int *alloc_kind, uint32
         set_error("opal_link_peer_status: not a link made by opal_link_create_peer");
         return OPAL_ERR_ARG;
     }
-    unsigned err = 0;
-    OPAL_HIP(hipMemcpyAsync(&err, l->peer->d_err, sizeof err, hipMemcpyDeviceToHost, l->stream));
+    unsigned errw[8] = {0};
+    OPAL_HIP(hipMemcpyAsync(errw, l->peer->d_err, sizeof errw, hipMemcpyDeviceToHost, l->stream));
     OPAL_HIP(hipStreamSynchronize(l->stream));
+    const unsigned err = errw[0];
     if (timeouts) *timeouts = (int)(err & 1u);
     if (alloc_kind) *alloc_kind = l->peer->alloc_kind;
     if (exchanges) *exchanges = l->peer->seq;
     if (err) {
-        set_error("peer link: a neighbour's message did not arrive within %.0f s", (double)PEER_TIMEOUT_TICKS / 1e8);
+        set_error("peer link: a neighbour's message did not arrive within %.0f s (subdomain %d: the %s mailbox held sequence number %u where "
+                  "%u was waited for, workgroup %u; %u exchanges enqueued so far)", (double)PEER_TIMEOUT_TICKS / 1e8, l->rank,
+                  errw[2] ? "right" : "left", errw[4], errw[3], errw[5], l->peer->seq);
         return OPAL_ERR_LINK;
     }
     return OPAL_OK;

@@ -28,6 +28,28 @@ constexpr size_t PEER_FLAG_BYTES = 64;          // the sequence number's line, i
 constexpr size_t PEER_CTL_BYTES = 256;          // in front of an edge's two mailboxes: the line through which the two ends of
                                                 // the edge hand each other the handle of LARGER mailboxes (peer.hip: link_peer_grow)
 constexpr long long PEER_TIMEOUT_TICKS = 2000000000LL;  // 20 s of wall_clock64() (100 MHz)
+constexpr long long PEER_TICK_MAX = 1000000LL;          // the most one pass of a polling loop is counted for (10 ms)
+
+#ifdef __HIPCC__
+// The time a wave has spent polling, summed pass by pass.  NOT `now - start`: with six processes sharing one card (round 5's
+// rehearsals) the waits of two subdomains on the same neighbour gave up at the same exchange -- the mailbox still held the
+// message of two exchanges before -- in runs that, by the host's clock, never stalled (they reached the next drain sooner than
+// runs without the error): the difference of two readings of the counter had jumped by more than the 20 s, whether because
+// the waves were off the chip in between (other processes' turn) or because the counter itself is not one clock for
+// everybody.  One pass of a polling loop takes microseconds; a longer gap is not time spent waiting here and counts for
+// PEER_TICK_MAX at the most, so that a wait only gives up after 20 s of its own polling (>= 2000 anomalies otherwise).
+struct SpinClock {
+    long long last, spent;
+    __device__ SpinClock() : last(wall_clock64()), spent(0) {}
+    __device__ bool expired()
+    {
+        const long long now = wall_clock64(), d = now - last;
+        last = now;
+        spent += d < 0 ? 0 : d > PEER_TICK_MAX ? PEER_TICK_MAX : d;
+        return spent > PEER_TIMEOUT_TICKS;
+    }
+};
+#endif
 
 // what a packed halo is read from (grid rows), when the sending kernel packs it itself
 struct HaloSrc {
@@ -183,13 +205,18 @@ __device__ inline bool peer_publish(const PeerArgs &a, unsigned *ticket, unsigne
 __device__ inline void peer_wait(const PeerArgs &a)
 {
     if (threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
+        SpinClock clock;
         for (int side = 0; side < 2; side++) {
             if (!a.box[side]) continue;
             const unsigned *flag = reinterpret_cast<const unsigned *>(a.box[side]);
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
-                if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
-                    atomicOr(a.err, 1u);
+                if (clock.expired()) {
+                    if (!(atomicOr(a.err, 1u) & 1u)) {  // the first to give up says what it saw (opal_link_peer_status)
+                        a.err[2] = (unsigned)side;
+                        a.err[3] = a.seq;
+                        a.err[4] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        a.err[5] = blockIdx.x;
+                    }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
@@ -201,7 +228,8 @@ __device__ inline void peer_wait(const PeerArgs &a)
         // the neighbours' were not yet here -- link latency if it is the same few microseconds on every subdomain, imbalance
         // or clock skew if some subdomains wait long and others not at all (bench.py: per_rank.tail_wait_us_per_step).
         if (blockIdx.x == 0 && a.wait) {
-            a.wait[0] += (unsigned long long)(wall_clock64() - t0);
+            clock.expired();
+            a.wait[0] += (unsigned long long)clock.spent;
             a.wait[1] += 1ull;
         }
     }

@@ -773,7 +773,8 @@ void recut_done(opal_sim_t *s)
     s->recuts++;
     s->recut_pending = false;
     if (getenv("OPAL_RECUT_DEBUG") && s->rank == 0) {
-        fprintf(stderr, "[recut] step %zu: sizes", s->step_index);
+        static const auto t_first = std::chrono::steady_clock::now();
+        fprintf(stderr, "[recut] %.3f s, step %zu: sizes", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_first).count(), s->step_index);
         for (int r = 0; r < s->numtasks; r++) fprintf(stderr, " %zu", s->nxs[(size_t)r]);
         fprintf(stderr, "\n");
     }
