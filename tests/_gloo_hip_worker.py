@@ -297,6 +297,21 @@ def main():
             init["link_growth_at_start"] = np.array(link.growth())
         sim.step(steps)
         sim.sync()
+        if mode == "sim_stall":
+            # subdomain 0 takes a step its neighbour never takes: its tail kernel polls its mailboxes for a message nobody
+            # sends, gives up after 20 s of its own polling, and the next sync must say so -- and what it saw
+            if rank == 0:
+                try:
+                    sim.step(1)
+                    sim.sync()
+                    said = "no error"
+                except oa.OpalError as e:
+                    said = str(e)
+                with open(os.path.join(outdir, "stall_rank0.txt"), "w") as f:
+                    f.write(said)
+            dist.barrier()  # (the others keep their mailboxes mapped meanwhile)
+            dist.destroy_process_group()
+            return
         if link is not None and hasattr(link, "growth"):
             init["link_growth"] = np.array(link.growth())
         dump(outdir, rank, sim.grid, sim.electrons, sim.ions, init)

@@ -164,6 +164,19 @@ def test_five_process_ring_over_the_mailboxes(oracle, tmp_path, monkeypatch):
     test_sim_fused_step_one_exchange_per_step(oracle, tmp_path, 5, 1, 800, "sim", "peer")
 
 
+def test_a_neighbour_that_stops_is_a_fatal_error_that_says_what_it_saw(tmp_path, monkeypatch):
+    """The reference's blocking MPI exchange cannot lose a message silently (mod.rs:303-354); the mailboxes must not either:
+    a subdomain whose neighbour stops stepping gives up after 20 s of polling and the next sync fails with OPAL_ERR_LINK, naming
+    the subdomain, the side, the sequence number it waited for and the one its mailbox held."""
+    monkeypatch.setenv("OPAL_TEST_LINK", "peer")
+    _launch("_gloo_hip_worker.py", 2, ["sim_stall", tmp_path, 64, 16, 6, 1])
+    said = open(os.path.join(tmp_path, "stall_rank0.txt")).read()
+    assert "did not arrive within 20 s" in said and "subdomain 0" in said and "was waited for" in said, said
+    import re
+    m = re.search(r"held sequence number (\d+) where (\d+) was waited for", said)
+    assert m and int(m.group(2)) > int(m.group(1)), said  # (an older message of the same mailbox, never a newer one)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_decomposed_thin_plasma_is_ballistic(tmp_path, world, link_kind):
     """A plasma too thin to act on itself, cut into 2 and 3 subdomains, 700 steps under the adaptive re-binning policy:
