@@ -949,7 +949,9 @@ def main():
         reference's partition (made once, at t = 0) -- what balance is worth can only be measured there, and is not known
         before the first run on such a node: the block is the faster of the two, the other one is kept beside it
         (`other_partition`).  Ranks that share a card take turns on it, so that only the cost of moving cuts would show:
-        one run there (OPAL_BENCH_BOTH_PARTITIONS=1 / 0 forces the one or the other)."""
+        one run there (OPAL_BENCH_BOTH_PARTITIONS=1 / 0 forces the one or the other).  Both runs share the block's deadline: with
+        a card per rank a run takes seconds (23 000 steps of ~0.3 ms), and a block that hangs must not hold the line back longer
+        than it did with one."""
         res = run(recut)
         if not recut or runs_per_block() == 1:
             return res
@@ -1354,7 +1356,7 @@ def main():
             # cells at a time).  OPAL_BENCH_LP_RECUT=0: the reference's partition.
             return both_partitions(lp_run, recut_spec("OPAL_BENCH_LP_RECUT", "25,1.12,32"))
 
-        guarded("laser_plasma_interaction", float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300")) * runs_per_block(), lp_body)
+        guarded("laser_plasma_interaction", float(os.environ.get("OPAL_BENCH_LP_DEADLINE", "300")), lp_body)
 
     if world > 1 and full_line and not args.no_colliding_beams:
         # BASELINE configs[4] on the same N GPUs: 4000 cells in N subdomains, the beam and its photons crossing the cuts at
@@ -1375,7 +1377,7 @@ def main():
         def cb_body():
             return both_partitions(cb_run, recut_spec("OPAL_BENCH_CB_RECUT", "32,1.10,48"))
 
-        guarded("colliding_beams", float(os.environ.get("OPAL_BENCH_CB_DEADLINE", "240")) * runs_per_block(), cb_body)
+        guarded("colliding_beams", float(os.environ.get("OPAL_BENCH_CB_DEADLINE", "240")), cb_body)
 
     if rank == 0:
         if world == 1 and args.workload == "two_stream" and not weak and not args.no_secondary and not args.self_exchange \
