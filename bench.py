@@ -996,6 +996,11 @@ def main():
         # The beam is 500 cells long and crosses the 4000-cell domain at c: under the reference's partition (made once, at
         # t = 0) it is on one or two subdomains at a time.  The cuts go with it (checked every 32 steps, in which it moves 30
         # cells; a cut moves 48 at the most).  OPAL_BENCH_CB_RECUT=0: the reference's partition.
+        # (Not over a link whose buffers are torch's: they stay as created, every plan is held to them, the cuts fall behind the
+        # beam and each step ships the whole bound through the host -- 60 ms a step in the rehearsal in which the mailboxes'
+        # self-test once failed.)
+        if cb_recut and getattr(link_cb, "transport_kind", None) in ("gloo", "torch"):
+            cb_recut = None
         if cb_recut:
             simc.set_recut(*cb_recut)
         barrier()
@@ -1334,6 +1339,8 @@ def main():
             sim3._bench_link = link3
             sizes = [None] * world
             dist.all_gather_object(sizes, int(sim3.grid.size))
+            if lp_recut and kind3 in ("gloo", "torch"):
+                lp_recut = None  # (buffers that belong to torch do not grow: a plan would be held to them -- see colliding_beams)
             if lp_recut:
                 sim3.set_recut(*lp_recut)
             m3 = measure(sim3, lp_steps, lp_warm, preheat=False, workload_key=f"laser_plasma:{lp_npc}")
@@ -1368,6 +1375,7 @@ def main():
             link4, kind4 = make_link(rank, world, link_device, cap, stream=stream, photon_emission=True, to_left=rank != 0,
                                      to_right=rank != world - 1, prefer=order,
                                      log=lambda m_: print(m_.replace("[opal_amd]", "[bench]"), file=sys.stderr))
+            link4.transport_kind = kind4
             res = colliding_beams(link4, CB_WHAT + "; " + (f"{world} GPUs" if backend == "nccl" else
                                                              f"{world} subdomains sharing {ndev} GPU(s) (REHEARSAL)"), cb_recut)
             res.update(link=kind4, n_gpus=world, link_particle_capacity=cap)

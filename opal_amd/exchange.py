@@ -253,11 +253,13 @@ class PeerLink:
         """n checked halo-only exchanges with the neighbours, 4 n back to back, one more checked; True only if all of
         that went well on EVERY subdomain (collective)."""
         ok = self._lib.opal_link_self_test(self.h, 1 if to_left else 0, 1 if to_right else 0, n) == 0
+        said = None if ok else f"subdomain {self.transport.rank}: " + self._lib.opal_last_error().decode()
         if self.world > 1:
-            oks = [None] * self.world
-            dist.all_gather_object(oks, ok, group=self.group)
-            ok = all(oks)
-        return ok
+            all_said = [None] * self.world
+            dist.all_gather_object(all_said, said, group=self.group)
+            said = next((t for t in all_said if t), None)
+        self.self_test_said = said  # (what the first subdomain that failed saw: make_link's log)
+        return said is None
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -339,7 +341,7 @@ def make_link(rank, world, device, particle_capacity, stream=None, photon_emissi
             if kind == "peer":
                 link = PeerLink(rank, world, device, group=ctl, **kw)
                 if not link.self_test(to_left=to_left, to_right=to_right):
-                    err, link = "the mailboxes' self-test failed on some subdomain", None
+                    err, link = f"the mailboxes' self-test failed: {link.self_test_said}", None
                 else:
                     link.transport.group = None  # the output-time collectives run on the default group
             elif kind == "rccl" and device.type == "cuda":
