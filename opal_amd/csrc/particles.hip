@@ -810,6 +810,11 @@ __global__ __launch_bounds__(BLOCK, ES ? OPAL_ES_WAVES : OPAL_PAIR_WAVES) void k
 // message towards a neighbour: only then is the weight read).  No tile, so no tile misses: photons are
 // re-binned only to squeeze out vacated slots (maybe_sort).
 constexpr int PHOTON_PPT = 8;
+#ifndef OPAL_PHOTON_GROUP
+#define OPAL_PHOTON_GROUP 4
+#endif
+constexpr int PHOTON_GROUP = OPAL_PHOTON_GROUP;
+static_assert(PHOTON_PPT % PHOTON_GROUP == 0, "whole groups");
 template <bool SENDX>
 __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
 {
@@ -821,25 +826,43 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
     const double *kxp = a.ux + chunk0, *kyp = a.uy + chunk0, *kzp = a.uz + chunk0;
     const unsigned nloc = (unsigned)min((size_t)BLOCK * PHOTON_PPT, (size_t)n - chunk0);
     int err = 0;
+    // The slots are loaded PHOTON_GROUP at a time before any of them is processed: as one loop the compiler sinks a slot's
+    // x and k loads behind the test of its cell (a dead slot needs neither), so that a wave had a 4-byte load in flight, waited,
+    // then 32 bytes, waited -- two latencies per slot and 5.4 TB/s over the colliding-beams run (round 5's counters).  A slot
+    // past the chunk's end re-loads its last one and is skipped below: the loads need no branch.
+    for (int p0 = 0; p0 < PHOTON_PPT; p0 += PHOTON_GROUP) {
+    int cs[PHOTON_GROUP];
+    double xs[PHOTON_GROUP];
+    V3 ks[PHOTON_GROUP];
 #pragma unroll
-    for (int p = 0; p < PHOTON_PPT; p++) {
-        const unsigned kc = (unsigned)p * BLOCK + threadIdx.x;
-        if (kc >= nloc) break;
-        const int c = ldk(cellp, kc);
-        const double xi = ldk(xp, kc);
-        const V3 k = {ldk(kxp, kc), ldk(kyp, kc), ldk(kzp, kc)};
-        if (c == DEAD_CELL) continue;
-        if ((unsigned)c >= (unsigned)a.size) {  // yee.rs:501-502 (fields_at is still called by the reference)
-            err |= 2;
-            continue;
-        }
+    for (int q = 0; q < PHOTON_GROUP; q++) {
+        const unsigned kl = min((unsigned)(p0 + q) * BLOCK + threadIdx.x, nloc - 1u);
+        cs[q] = ldk(cellp, kl);
+        xs[q] = ldk(xp, kl);
+        ks[q] = V3{ldk(kxp, kl), ldk(kyp, kl), ldk(kzp, kl)};
+    }
+#pragma unroll
+    for (int q = 0; q < PHOTON_GROUP; q++) {
+        const unsigned kc = (unsigned)(p0 + q) * BLOCK + threadIdx.x;
+        const int c = cs[q];
+        const double xi = xs[q];
+        const V3 k = ks[q];
+        const bool live = kc < nloc && c != DEAD_CELL;
         const V3 none = {0.0, 0.0, 0.0};
         const Pushed r = photon_push<false>(k, none, none, a.dt_over_dx);
-        if (!(r.dxi < 1.0)) err |= 1;  // photon.rs:169
         double xn = xi + r.dxi;
         const double fl = floor(xn);
         const int s = min(max((int)fl, -1), 1);
         xn -= fl;
+        // (asked of the whole wave, before anything depends on a slot being live: every lane's x and k are used here, so
+        // their loads stay with the group's instead of moving behind the test of the cell)
+        const bool stepped = __ballot(live && s != 0) != 0ull || a.out_shift != 0;
+        if (!live) continue;
+        if ((unsigned)c >= (unsigned)a.size) {  // yee.rs:501-502 (fields_at is still called by the reference)
+            err |= 2;
+            continue;
+        }
+        if (!(r.dxi < 1.0)) err |= 1;  // photon.rs:169
         int newc = c + s - a.out_shift;  // (the frame the result is stored in: PushArgs)
         bool deleted = false;
         int send_side = -1;
@@ -860,7 +883,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
                 atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[0]) + a.zone_word, 1u);
             if (a.right_mode == EDGE_SEND && newc >= a.out_size - a.zone)
                 atomicAdd(reinterpret_cast<unsigned *>(a.send_msg[1]) + a.zone_word, 1u);
-            if (__ballot(newc != c)) stk(cellp, kc, newc);
+            if (stepped && __ballot(newc != c)) stk(cellp, kc, newc);  // (no live lane left its cell: nothing to ask)
             stk(xp, kc, xn);
         } else if (deleted) {
             cellp[kc] = DEAD_CELL;
@@ -889,6 +912,7 @@ __global__ __launch_bounds__(BLOCK) void k_push_photon(PushArgs a)
             }
             cellp[kc] = DEAD_CELL;
         }
+    }
     }
     if (err) atomicOr(&a.ctr->err, err);
 }
