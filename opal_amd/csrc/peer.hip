@@ -529,7 +529,8 @@ int opal_link_self_test(opal_link_t *l, int to_left, int to_right, int n)
             for (int i = 0; i < ND; i++)
                 if (buf[i] != pattern(from, their_side, k, i)) {
                     set_error("link self-test: round %d, halo word %d from subdomain %d reads %.17g, not %.17g (a late, stale or "
-                              "torn message)", k, i, from, buf[i], pattern(from, their_side, k, i));
+                              "torn message; mailbox memory kind %d: 0 uncached, 1 fine-grained, 2 plain)", k, i, from, buf[i],
+                              pattern(from, their_side, k, i), l->peer ? l->peer->alloc_kind : -1);
                     return OPAL_ERR_LINK;
                 }
         }
