@@ -42,8 +42,12 @@ struct QedCdf {
 // different iterate than the reference's (Rust never fuses).  Unfused, the device differs from the CPU
 // restatement only by the last-ulp differences of log/exp/pow/acos, and tests/test_gpu_qed.py holds the
 // golden vectors of tests/golden/qed_sample_reference_tables.json to 1e-12.  k_radiate is ~70 us of a colliding-beams step
-// at its peak (1e5-3e5 emitters): VALU-bound -- 17.5e6 wave-instructions per launch over 1024 SIMDs (round 4's counters),
-// not a latency chain: two lanes per emitter, each inverting one table of each interpolation stage, changed nothing.
+// at its peak (1e5-3e5 emitters).  What it pays for is the iteration's long tail: an inversion takes 3.5 passes of the loop on
+// average, but 1 % take 8-30, and a wave runs every loop until its slowest lane is done -- 8.7 passes on average over 64 lanes
+// (tests/test_qed_oracle.py::test_brent_iterations_have_a_long_tail counts them), with one or two lanes active in the later
+// ones.  That is why neither more resident waves, nor fewer instructions outside the loop (cube roots for the three powers
+// with a rational exponent: 13 % of the kernel's code, -1.5 % of its time), nor two lanes per emitter changed it
+// (profiles/r05_ab/ab_radiate_*.txt); the reference's iterates are the result, so the loop itself stays as it is.
 #pragma clang fp contract(off)
 
 constexpr int RECURSION_LIMIT = 32;      // pwmci.rs:3
@@ -338,8 +342,12 @@ __global__ __launch_bounds__(256) void k_list_emitters(const int *__restrict__ c
 
 __device__ void radiate_one(const RadiateArgs &a, size_t i);
 
-// Pass 2: Electron::radiate + the filters of emit_radiation, one listed emitter per thread
-__global__ __launch_bounds__(256) void k_radiate(RadiateArgs a)
+// Pass 2: Electron::radiate + the filters of emit_radiation, one listed emitter per thread.  One-wave workgroups: the kernel
+// holds 2 waves per SIMD (201 VGPRs) and a launch is 2-5 waves per SIMD of work, so the last round is dispatched wave by wave
+// instead of four at a time (-3 % on the kernel; more resident waves bought with scratch are slower, and so is everything
+// else that was tried on it: profiles/r05_ab/ab_radiate_occupancy.txt, ab_radiate_instructions.txt).
+constexpr int RADIATE_BLOCK = 64;
+__global__ __launch_bounds__(RADIATE_BLOCK) void k_radiate(RadiateArgs a)
 {
     // the list length is read from the device: the host may not know it (asynchronous mode), so the grid is
     // sized for the most it can be and strides over the list
@@ -544,7 +552,8 @@ int opal_emit_radiation(opal_pop_t *e, opal_pop_t *ph, uint64_t seed, uint32_t s
     a.seed = seed; a.step = step;
     a.min_energy = min_energy; a.max_angle = max_angle; a.max_formation_length = max_formation_length;
     prof_begin(KERNEL_RADIATE, e->stream);
-    k_radiate<<<(unsigned)std::min<size_t>((emitters + 255) / 256, 2048), 256, 0, e->stream>>>(a);
+    k_radiate<<<(unsigned)std::min<size_t>((emitters + RADIATE_BLOCK - 1) / RADIATE_BLOCK, 2048 * (256 / RADIATE_BLOCK)), RADIATE_BLOCK, 0,
+                e->stream>>>(a);
     prof_end(KERNEL_RADIATE, e->stream);
     OPAL_HIP(hipGetLastError());
     ph->sorted_exact = false;

@@ -455,3 +455,26 @@ def test_table_prefixes_are_monotone():
             noisy += any(v[i + 1] < v[i] for i in range(len(v) - 1))
     assert noisy == 17
 
+
+
+def test_brent_iterations_have_a_long_tail():
+    """What k_radiate (opal_amd/csrc/qed.hip) pays for: pwmci::invert (pwmci.rs:113-228) takes ~3.5 passes of Brent's loop on
+    average over the quantum cdf tables, but about one inversion in a hundred takes 8-30, and a 64-lane wave runs the loop
+    until its slowest lane is done.  Counted here with the oracle's evaluation counter on seeded uniforms: the mean per
+    inversion, and the mean over groups of 64 of the slowest -- the figure the device's time follows
+    (profiles/r05_ab/ab_radiate_instructions.txt)."""
+    tables = _physics().committed_tables()["quantum"]
+    rng = np.random.default_rng(12)
+    per_lane, per_wave = [], []
+    for _ in range(300):
+        slowest = 0
+        for _ in range(64):
+            _, _, rows = tables[int(rng.integers(12, 28))]      # chi between 0.16 and 6.3
+            f = math.log(1.0 - rng.random())
+            n = 0 if f <= rows[0][1] else O.pwmci_invert(f, rows)[1]  # below the table: the power law, no iteration
+            per_lane.append(n)
+            slowest = max(slowest, n)
+        per_wave.append(slowest)
+    assert 3.0 < np.mean(per_lane) < 4.2, np.mean(per_lane)
+    assert 7.5 < np.mean(per_wave) < 10.5, np.mean(per_wave)
+    assert max(per_lane) <= 32                                 # RECURSION_LIMIT, pwmci.rs:3
