@@ -45,9 +45,11 @@ struct QedCdf {
 // at its peak (1e5-3e5 emitters).  What it pays for is the iteration's long tail: an inversion takes 3.5 passes of the loop on
 // average, but 1 % take 8-30, and a wave runs every loop until its slowest lane is done -- 8.7 passes on average over 64 lanes
 // (tests/test_qed_oracle.py::test_brent_iterations_have_a_long_tail counts them), with one or two lanes active in the later
-// ones.  That is why neither more resident waves, nor fewer instructions outside the loop (cube roots for the three powers
-// with a rational exponent: 13 % of the kernel's code, -1.5 % of its time), nor two lanes per emitter changed it
-// (profiles/r05_ab/ab_radiate_*.txt); the reference's iterates are the result, so the loop itself stays as it is.
+// ones: 28 of 64 lanes are active per issued VALU instruction (profiles/r05_radiate_pmc_sq.json).  That is why neither more
+// resident waves, nor fewer instructions outside the loop (cube roots for the three powers with a rational exponent: 13 %
+// of the kernel's code, -1.5 % of its time), nor two lanes per emitter, nor the two inversions of a stage side by side in
+// one loop (+5 to +11 %: scripts/archive/r05_radiate_paired_loop.patch) shortened it (profiles/r05_ab/ab_radiate_*.txt);
+// the reference's iterates are the result, so the loop itself stays as it is.
 #pragma clang fp contract(off)
 
 constexpr int RECURSION_LIMIT = 32;      // pwmci.rs:3
