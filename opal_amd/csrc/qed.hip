@@ -42,14 +42,16 @@ struct QedCdf {
 // different iterate than the reference's (Rust never fuses).  Unfused, the device differs from the CPU
 // restatement only by the last-ulp differences of log/exp/pow/acos, and tests/test_gpu_qed.py holds the
 // golden vectors of tests/golden/qed_sample_reference_tables.json to 1e-12.  k_radiate is ~70 us of a colliding-beams step
-// at its peak (1e5-3e5 emitters).  What it pays for is the iteration's long tail: an inversion takes 3.5 passes of the loop on
-// average, but 1 % take 8-30, and a wave runs every loop until its slowest lane is done -- 8.7 passes on average over 64 lanes
-// (tests/test_qed_oracle.py::test_brent_iterations_have_a_long_tail counts them), with one or two lanes active in the later
-// ones: 28 of 64 lanes are active per issued VALU instruction (profiles/r05_radiate_pmc_sq.json).  That is why neither more
-// resident waves, nor fewer instructions outside the loop (cube roots for the three powers with a rational exponent: 13 %
-// of the kernel's code, -1.5 % of its time), nor two lanes per emitter, nor the two inversions of a stage side by side in
-// one loop (+5 to +11 %: scripts/archive/r05_radiate_paired_loop.patch) shortened it (profiles/r05_ab/ab_radiate_*.txt);
-// the reference's iterates are the result, so the loop itself stays as it is.
+// at its peak (1e5-3e5 emitters).  In the steps it is long in, a launch is about one wave per SIMD, every wave resident from
+// the start: it lasts as long as one wave takes -- ~0.025 ms for the emitters' attributes gathered by slot, the scattered
+// stores and the photons' slots (the kernel with the sampler taken out), ~0.04 ms for the sampler's ~1e4 instructions one
+// after the other.  Brent's loop diverges (3.5 passes per inversion on average, 8.7 for the slowest of 64 lanes, 28 of 64
+// lanes active per VALU instruction: tests/test_qed_oracle.py::test_brent_iterations_have_a_long_tail,
+// profiles/r05_radiate_pmc_sq.json), but the launch does not wait for it: more resident waves, fewer instructions, the two
+// inversions of a stage side by side, a pool of inversions shared among a wave's lanes, the tables in LDS, shared instead
+// of inlined functions, even the loop cut off at 8 passes each move the kernel by -6 to +11 %
+// (profiles/r05_ab/ab_radiate_*.txt; patches under scripts/archive/).  The reference's iterates are the result, so the
+// loop stays as it is; what is left to gain is the launch BESIDE the photons' push (the GPU is nearly idle meanwhile).
 #pragma clang fp contract(off)
 
 constexpr int RECURSION_LIMIT = 32;      // pwmci.rs:3
