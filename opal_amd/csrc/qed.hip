@@ -347,9 +347,9 @@ __global__ __launch_bounds__(256) void k_list_emitters(const int *__restrict__ c
 __device__ void radiate_one(const RadiateArgs &a, size_t i);
 
 // Pass 2: Electron::radiate + the filters of emit_radiation, one listed emitter per thread.  One-wave workgroups: the kernel
-// holds 2 waves per SIMD (201 VGPRs) and a launch is 2-5 waves per SIMD of work, so the last round is dispatched wave by wave
-// instead of four at a time (-3 % on the kernel; more resident waves bought with scratch are slower, and so is everything
-// else that was tried on it: profiles/r05_ab/ab_radiate_occupancy.txt, ab_radiate_instructions.txt).
+// holds 2 waves per SIMD (201 VGPRs) and a launch is 1-5 waves per SIMD of work, dispatched wave by wave instead of four
+// at a time (-3 % on the kernel; more resident waves bought with scratch are slower, and nothing else that was tried on it
+// moved it by more: the notes at the top of this file, profiles/r05_ab/ab_radiate_*.txt).
 constexpr int RADIATE_BLOCK = 64;
 __global__ __launch_bounds__(RADIATE_BLOCK) void k_radiate(RadiateArgs a)
 {

@@ -458,11 +458,11 @@ def test_table_prefixes_are_monotone():
 
 
 def test_brent_iterations_have_a_long_tail():
-    """What k_radiate (opal_amd/csrc/qed.hip) pays for: pwmci::invert (pwmci.rs:113-228) takes ~3.5 passes of Brent's loop on
-    average over the quantum cdf tables, but about one inversion in a hundred takes 8-30, and a 64-lane wave runs the loop
-    until its slowest lane is done.  Counted here with the oracle's evaluation counter on seeded uniforms: the mean per
-    inversion, and the mean over groups of 64 of the slowest -- the figure the device's time follows
-    (profiles/r05_ab/ab_radiate_instructions.txt)."""
+    """How Brent's loop diverges in k_radiate (opal_amd/csrc/qed.hip): pwmci::invert (pwmci.rs:113-228) takes ~3.5 passes of
+    the loop on average over the quantum cdf tables, but about one inversion in a hundred takes 8-30, and a 64-lane wave runs
+    the loop until its slowest lane is done.  Counted here with the oracle's evaluation counter on seeded uniforms: the mean
+    per inversion, and the mean over groups of 64 of the slowest (the device's counters agree: 28 of 64 lanes active per VALU
+    instruction).  It is not what bounds the kernel, though: profiles/r05_ab/ab_radiate_diagnostics.txt."""
     tables = _physics().committed_tables()["quantum"]
     rng = np.random.default_rng(12)
     per_lane, per_wave = [], []
